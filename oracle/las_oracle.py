@@ -1,0 +1,351 @@
+"""CPU oracle for the ASR training hot path  --  TEST INFRASTRUCTURE ONLY.
+
+A plain-PyTorch-CPU restatement of the Listen-Attend-Spell train step of
+cadia-lvl/ss_asr.  It exists to *check* the HIP path; it is never the thing
+shipped or measured as the product.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this file.  ``ss_asr_amd`` never imports it.
+
+Parity status: PINNED.  ``oracle/make_golden.py`` ran the real reference
+(imported from /root/reference in the build container) on seeded inputs and
+committed its inputs/outputs under ``tests/golden/``; ``tests/test_oracle.py``
+checks every function here against those vectors.  The reference holds no
+tests, fixtures or golden vectors of its own.
+
+Two layers live here:
+
+* ``OracleASR`` and friends use ``torch.nn.LSTM`` / ``LSTMCell`` the way the
+  reference does, so that timing it on the host cores is a fair "reference CPU
+  path" (bench.py ``cpu_baseline.kind == "port"``).
+* the ``*_explicit`` functions spell the same arithmetic out gate by gate
+  (float64 capable).  Kernel-level GPU tests compare against these.
+
+Reference citations are ``file:line`` under /root/reference.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+# vocabulary constants, src/preprocess.py:17-27
+CHARS = 'abcdefghijklmnoprstuvxy0123456789'
+ICE_CHARS = 'áéíóúýæöþð'
+SPECIAL_CHARS = ' .,?'
+ALL_CHARS = CHARS + ICE_CHARS + SPECIAL_CHARS
+TOKENS = '<>$'
+VOCAB = len(TOKENS + ALL_CHARS)  # 50
+
+
+# --------------------------------------------------------------------------
+# nn-based model (mirrors the reference's op structure)
+# --------------------------------------------------------------------------
+class OraclePyramid(nn.Module):
+    """pBLSTM, src/asr.py:394-450: packed BiLSTM then pairwise frame concat."""
+
+    def __init__(self, in_dim, hid):
+        super().__init__()
+        self.layer = nn.LSTM(in_dim, hid, bidirectional=True, batch_first=True)
+
+    def forward(self, x, lens):
+        packed = pack_padded_sequence(x, lens, batch_first=True)      # asr.py:413
+        out, _ = self.layer(packed)                                   # asr.py:414
+        out, out_lens = pad_packed_sequence(out, batch_first=True)    # asr.py:417
+        t = out.shape[1] - (out.shape[1] % 2)                         # asr.py:443-446
+        out = out[:, :t, :].contiguous().view(out.shape[0], t // 2, -1)
+        return out, [int(l / 2) for l in out_lens.tolist()]           # asr.py:424
+
+
+class OracleListener(nn.Module):
+    """Listener, src/asr.py:214-264."""
+
+    def __init__(self, hid, feat):
+        super().__init__()
+        self.state_size = hid
+        self.out_dim = 2 * hid
+        self.blstm_1 = OraclePyramid(feat, hid)
+        self.blstm_2 = OraclePyramid(4 * hid, hid)
+        self.blstm_3 = OraclePyramid(4 * hid, hid)
+        # asr.py:237-238 -- NOT batch_first: recurs over the utterance axis.
+        self.blstm_4 = nn.LSTM(4 * hid, hid, bidirectional=True)
+
+    def forward(self, x, lens):
+        x, lens = self.blstm_1(x, lens)
+        x, lens = self.blstm_2(x, lens)
+        x, lens = self.blstm_3(x, lens)
+        x, _ = self.blstm_4(x)                                        # asr.py:262
+        return x, lens
+
+
+class OracleAttention(nn.Module):
+    """Attention, src/asr.py:328-392 (content based, cached psi projection)."""
+
+    def __init__(self, mlp, enc_dim, dec_dim):
+        super().__init__()
+        self.phi = nn.Linear(dec_dim, mlp, bias=False)
+        self.psi = nn.Linear(enc_dim, mlp)
+        self.comp = None
+        self.mask = None
+
+    def reset_enc_mem(self):
+        self.comp = None
+        self.mask = None
+
+    def forward(self, state, feat, lens):
+        if self.comp is None:
+            idx = torch.arange(feat.shape[1]).unsqueeze(0)
+            self.mask = idx >= torch.as_tensor(list(lens)).unsqueeze(1)   # asr.py:374-380
+            self.comp = torch.tanh(self.psi(feat))                        # asr.py:381
+        q = torch.tanh(self.phi(state))                                   # asr.py:383
+        energy = torch.bmm(self.comp, q.unsqueeze(2)).squeeze(2)          # asr.py:385-386
+        energy = energy.masked_fill(self.mask, float('-inf'))             # asr.py:387
+        alpha = torch.softmax(energy, dim=-1)                             # asr.py:388
+        ctx = torch.bmm(alpha.unsqueeze(1), feat).squeeze(1)              # asr.py:389-390
+        return alpha, ctx
+
+
+class OracleSpeller(nn.Module):
+    """Speller, src/asr.py:267-326: two stacked LSTMCells."""
+
+    def __init__(self, hid, enc_dim):
+        super().__init__()
+        self.layer_1 = nn.LSTMCell(enc_dim + hid, hid)
+        self.layer_2 = nn.LSTMCell(hid, hid)
+        self.state_size = hid
+        self.state_list, self.cell_list = [], []
+
+    def init_rnn(self, batch, device=None):
+        z = torch.zeros(batch, self.state_size)
+        self.state_list = [z, z]
+        self.cell_list = [z, z]
+
+    def forward(self, inp):
+        h1, c1 = self.layer_1(inp, (self.state_list[0], self.cell_list[0]))
+        h2, c2 = self.layer_2(h1, (self.state_list[1], self.cell_list[1]))
+        self.state_list = [h1, h2]
+        self.cell_list = [c1, c2]
+        return h2
+
+
+class OracleASR(nn.Module):
+    """ASR, src/asr.py:15-212.  Same constructor kwargs, same state_dict keys."""
+
+    def __init__(self, output_dim, encoder_state_size, decoder_state_size,
+                 mlp_out_size, feature_dim, tf_rate):
+        super().__init__()
+        self.encoder = OracleListener(encoder_state_size, feature_dim)
+        self.attention = OracleAttention(mlp_out_size, 2 * encoder_state_size,
+                                         decoder_state_size)
+        self.decoder = OracleSpeller(decoder_state_size, 2 * encoder_state_size)
+        self.embed = nn.Embedding(output_dim, decoder_state_size)
+        self.char_trans = nn.Linear(decoder_state_size, output_dim)
+        self.tf_rate = tf_rate
+        self.init_parameters()
+
+    def init_parameters(self):
+        """src/asr.py:175-212: biases 0, matrices N(0, 1/sqrt(fan_in)),
+        embedding N(0,1), speller bias_ih forget slice = 1."""
+        for p in self.parameters():
+            if p.dim() == 1:
+                p.data.zero_()
+            elif p.dim() == 2:
+                p.data.normal_(0, 1.0 / math.sqrt(p.size(1)))
+            else:
+                raise NotImplementedError
+        self.embed.weight.data.normal_(0, 1)
+        for cell in (self.decoder.layer_1, self.decoder.layer_2):
+            n = cell.bias_ih.numel()
+            cell.bias_ih.data[n // 4:n // 2].fill_(1.0)
+
+    def forward(self, audio_feature, decode_step, teacher=None, state_len=None):
+        feat, enc_len = self.encoder(audio_feature, state_len)            # asr.py:63
+        emb_teacher = self.embed(teacher) if teacher is not None else None
+        batch = audio_feature.shape[0]
+        self.decoder.init_rnn(batch)
+        self.attention.reset_enc_mem()
+        last = self.embed(torch.zeros(batch, dtype=torch.long))           # asr.py:73
+        logits, atts = [], []
+        for t in range(decode_step):                                      # asr.py:79
+            alpha, ctx = self.attention(self.decoder.state_list[0], feat, enc_len)
+            out = self.decoder(torch.cat([last, ctx], dim=-1))
+            cur = self.char_trans(out)
+            if emb_teacher is not None:
+                if random.random() <= self.tf_rate:                       # asr.py:94
+                    last = emb_teacher[:, t + 1, :]
+                else:
+                    pick = torch.distributions.Categorical(
+                        F.softmax(cur, dim=-1)).sample()
+                    last = self.embed(pick)
+            else:
+                last = self.embed(torch.argmax(cur, dim=-1))              # asr.py:100
+            logits.append(cur)
+            atts.append(alpha.detach())
+        return enc_len, torch.stack(logits, dim=1), torch.stack(atts, dim=1)
+
+
+def masked_ce_loss(logits, y, ans_len):
+    """src/trainer.py:426-434: CE(ignore 0) summed per utterance, divided by
+    the count of non-zero labels in the whole row of y, mean over batch."""
+    label = y[:, 1:ans_len + 1].contiguous()
+    b, t, c = logits.shape
+    per_tok = F.cross_entropy(logits.reshape(b * t, c), label.reshape(-1),
+                              ignore_index=0, reduction='none')
+    per_utt = per_tok.view(b, t).sum(-1) / (y != 0).sum(-1).to(torch.float32)
+    return per_utt.mean()
+
+
+def label_lengths(y):
+    """src/ASRDataset.py:338: count(y != 0) + 1."""
+    return [int(v) + 1 for v in (y != 0).sum(-1)]
+
+
+def frame_lengths(x):
+    """src/ASRDataset.py:314: frames whose feature sum is non-zero."""
+    return [int(v) for v in (x.sum(-1) != 0).sum(-1)]
+
+
+def solver_step(params, optim, grad_clip=5):
+    """src/trainer.py:131-148.  Returns (grad_norm, stepped)."""
+    norm = nn.utils.clip_grad_norm_(params, grad_clip)
+    if math.isnan(float(norm)):
+        return float(norm), False
+    optim.step()
+    return float(norm), True
+
+
+def train_step(model, optim, x, y):
+    """One iteration of ASRTrainer.exec, src/trainer.py:415-438.  Returns
+    (loss, grad_norm)."""
+    lens = frame_lengths(x)
+    ans_len = max(label_lengths(y)) - 1
+    optim.zero_grad()
+    _, logits, _ = model(x, ans_len, teacher=y, state_len=lens)
+    loss = masked_ce_loss(logits, y, ans_len)
+    loss.backward()
+    norm, _ = solver_step(list(model.parameters()), optim)
+    return float(loss), norm
+
+
+def make_optimizer(model):
+    """src/trainer.py:401-403 with conf/default.yaml:2-4."""
+    return torch.optim.Adadelta(model.parameters(), lr=1.0, eps=1e-8)
+
+
+# --------------------------------------------------------------------------
+# explicit arithmetic (kernel-level oracle)
+# --------------------------------------------------------------------------
+def lstm_gates_explicit(pre, c_prev):
+    """One LSTM cell update from gate pre-activations ``pre`` [.., 4H] in the
+    PyTorch row order i, f, g, o."""
+    h = pre.shape[-1] // 4
+    i = torch.sigmoid(pre[..., 0:h])
+    f = torch.sigmoid(pre[..., h:2 * h])
+    g = torch.tanh(pre[..., 2 * h:3 * h])
+    o = torch.sigmoid(pre[..., 3 * h:4 * h])
+    c = f * c_prev + i * g
+    return o * torch.tanh(c), c
+
+
+def lstm_dir_explicit(x, lens, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of a packed LSTM over time-major input.
+
+    x: [S, N, I]; lens: N ints or None (full length).  Column n is updated at
+    step s only while s < lens[n]; the reverse direction walks s downwards, so
+    each column effectively starts from zero state at its own last frame.
+    Outputs past a column's length are zero (pad_packed_sequence)."""
+    steps, cols, _ = x.shape
+    hid = w_hh.shape[1]
+    h = x.new_zeros(cols, hid)
+    c = x.new_zeros(cols, hid)
+    out = x.new_zeros(steps, cols, hid)
+    if lens is None:
+        lens_t = torch.full((cols,), steps, dtype=torch.long)
+    else:
+        lens_t = torch.as_tensor(list(lens), dtype=torch.long)
+    order = range(steps - 1, -1, -1) if reverse else range(steps)
+    for s in order:
+        pre = x[s] @ w_ih.t() + h @ w_hh.t() + b_ih + b_hh
+        h_new, c_new = lstm_gates_explicit(pre, c)
+        live = (s < lens_t).unsqueeze(1)
+        h = torch.where(live, h_new, h)
+        c = torch.where(live, c_new, c)
+        out[s] = torch.where(live, h_new, torch.zeros_like(h_new))
+    return out
+
+
+def bilstm_explicit(x, lens, weights):
+    """Bidirectional layer.  ``weights`` = (w_ih, w_hh, b_ih, b_hh) for the
+    forward direction followed by the same four for the reverse direction.
+    x is time-major [S, N, I]; returns [S, N, 2H]."""
+    fwd = lstm_dir_explicit(x, lens, *weights[0:4], reverse=False)
+    bwd = lstm_dir_explicit(x, lens, *weights[4:8], reverse=True)
+    return torch.cat([fwd, bwd], dim=-1)
+
+
+def pyramid_explicit(x_bt, lens, weights):
+    """pBLSTM on batch-first input: packed BiLSTM up to max(lens) frames, drop
+    an odd last frame, concatenate frame pairs (src/asr.py:406-450)."""
+    tmax = max(lens)
+    y = bilstm_explicit(x_bt[:, :tmax].transpose(0, 1), lens, weights)
+    y = y.transpose(0, 1)
+    t = tmax - (tmax % 2)
+    y = y[:, :t].contiguous().view(y.shape[0], t // 2, -1)
+    return y, [int(l / 2) for l in lens]
+
+
+def attention_step_explicit(state, feat, comp, lens, w_phi):
+    """One Attention.forward call after the cached psi projection
+    (src/asr.py:383-390).  Returns (alpha [B,T'], ctx [B,E])."""
+    q = torch.tanh(state @ w_phi.t())
+    energy = torch.einsum('bta,ba->bt', comp, q)
+    idx = torch.arange(feat.shape[1]).unsqueeze(0)
+    energy = energy.masked_fill(idx >= torch.as_tensor(list(lens)).unsqueeze(1),
+                                float('-inf'))
+    alpha = torch.softmax(energy, dim=-1)
+    return alpha, torch.einsum('bt,bte->be', alpha, feat)
+
+
+def lstm_cell_explicit(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """nn.LSTMCell arithmetic (src/asr.py:320-324)."""
+    return lstm_gates_explicit(x @ w_ih.t() + h @ w_hh.t() + b_ih + b_hh, c)
+
+
+def clip_adadelta_explicit(params, grads, sq_avg, acc_delta, max_norm=5.0,
+                           lr=1.0, rho=0.9, eps=1e-8):
+    """clip_grad_norm_ (src/trainer.py:144) followed by torch.optim.Adadelta
+    (src/trainer.py:148, :401-403), on lists of tensors, in place.
+    Returns (total_norm, stepped)."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    if math.isnan(float(total)):
+        return float(total), False
+    coef = min(1.0, max_norm / (float(total) + 1e-6))
+    for p, g, sq, ad in zip(params, grads, sq_avg, acc_delta):
+        g = g * coef
+        sq.mul_(rho).addcmul_(g, g, value=1 - rho)
+        delta = (ad + eps).sqrt() / (sq + eps).sqrt() * g
+        ad.mul_(rho).addcmul_(delta, delta, value=1 - rho)
+        p.sub_(lr * delta)
+    return float(total), True
+
+
+def seeded_weights(model, seed):
+    """Overwrites every parameter with numpy-PCG64 draws that follow the
+    reference's init law (N(0, 1/sqrt(fan_in)), embedding N(0,1), biases 0,
+    speller forget bias 1).  Used where a fixture must not carry 41 MB of
+    weights: the same call reproduces them on any host."""
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 1:
+                p.zero_()
+            else:
+                std = 1.0 if name == 'embed.weight' else 1.0 / math.sqrt(p.shape[1])
+                p.copy_(torch.from_numpy(
+                    (rng.standard_normal(tuple(p.shape)) * std).astype(np.float32)))
+        for cell in (model.decoder.layer_1, model.decoder.layer_2):
+            n = cell.bias_ih.numel()
+            cell.bias_ih[n // 4:n // 2] = 1.0
+    return model

@@ -1,0 +1,157 @@
+"""Generates tests/golden/*.npz by RUNNING THE REAL REFERENCE on CPU.
+
+Build-container only (needs /root/reference; see oracle/ref_harness.py).
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Every fixture is data: seeded inputs, the reference's outputs, and (for the
+small model) its weights.  Full-size cases carry no weights; they are
+re-created on any host by ``las_oracle.seeded_weights(model, seed)``, a numpy
+PCG64 stream.  The loss / clip / Adadelta lines below restate
+src/trainer.py:426-438 around the reference's own ``ASR`` class, because
+``ASRTrainer`` itself cannot be constructed without tensorboardX and a dataset
+on disk.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_harness import import_reference  # noqa: E402
+from las_oracle import seeded_weights  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def synth_batch(rng, lens, feat, y_lens, vocab=50):
+    """Zero-padded N(0,1) fbanks with the given frame lengths and label rows
+    '<' chars '>' padded with 0 (src/ASRDataset.py:131-151)."""
+    b, t = len(lens), max(lens)
+    x = rng.standard_normal((b, t, feat)).astype(np.float32)
+    for i, l in enumerate(lens):
+        x[i, l:] = 0
+    width = max(y_lens) + 2
+    y = np.zeros((b, width), dtype=np.int64)
+    for i, l in enumerate(y_lens):
+        y[i, 1:1 + l] = rng.integers(3, vocab, size=l)
+        y[i, 1 + l] = 1
+    return torch.from_numpy(x), torch.from_numpy(y)
+
+
+def ref_loss(logits, y, ans_len):
+    # src/trainer.py:426-434
+    metric = nn.CrossEntropyLoss(ignore_index=0, reduction='none')
+    label = y[:, 1:ans_len + 1].contiguous()
+    b, t, c = logits.shape
+    loss = metric(logits.view(b * t, c), label.view(-1))
+    loss = torch.sum(loss.view(b, t), dim=-1) / torch.sum(y != 0, dim=-1).to(torch.float32)
+    return torch.mean(loss)
+
+
+def capture(asr_mod, name, dims, lens, y_lens, tf_rate, seed, weights_seed=None,
+            teacher=True, pad_to=None, keep='all', extra_decode=0):
+    seed_all(seed)
+    model = asr_mod.ASR(*dims, tf_rate)
+    if weights_seed is not None:
+        seeded_weights(model, weights_seed)
+    rng = np.random.default_rng(seed + 1000)
+    x, y = synth_batch(rng, lens, dims[4], y_lens, dims[0])
+    if pad_to is not None:       # dataset-wide zero padding beyond the batch max
+        x = torch.cat([x, x.new_zeros(x.shape[0], pad_to - x.shape[1], x.shape[2])], 1)
+    ans_len = int(max((y != 0).sum(-1) + 1)) - 1
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+
+    taps = {}
+    hooks = []
+    for nm in ('blstm_1', 'blstm_2', 'blstm_3', 'blstm_4'):
+        def hook(_m, _i, out, nm=nm):
+            taps[nm] = out[0].detach().clone()
+        hooks.append(getattr(model.encoder, nm).register_forward_hook(hook))
+
+    optim = torch.optim.Adadelta(model.parameters(), lr=1.0, eps=1e-8)
+    optim.zero_grad()
+    seed_all(seed + 7)           # pins the coin flips / samples of the decode loop
+    steps = ans_len + extra_decode
+    enc_len, logits, att = model(x, steps, teacher=y if teacher else None,
+                                 state_len=list(lens))
+    for h in hooks:
+        h.remove()
+    loss = ref_loss(logits[:, :ans_len].contiguous(), y, ans_len)   # trainer.py:484-485
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    grad_norm = nn.utils.clip_grad_norm_(model.parameters(), 5)      # trainer.py:144
+    optim.step()                                                     # trainer.py:148
+    sd1 = model.state_dict()
+
+    out = dict(dims=np.array(dims), tf_rate=np.float64(tf_rate), seed=np.int64(seed),
+               weights_seed=np.int64(-1 if weights_seed is None else weights_seed),
+               teacher=np.int64(teacher), rng_seed=np.int64(seed + 7),
+               x=x.numpy(), y=y.numpy(), lens=np.array(lens), ans_len=np.int64(ans_len),
+               decode_steps=np.int64(steps),
+               enc_len=np.array(enc_len), logits=logits.detach().numpy(),
+               att=att.numpy(), loss=np.float64(loss.item()),
+               grad_norm=np.float64(float(grad_norm)))
+    names = list(grads.keys())
+    out['param_names'] = np.array(names)
+    out['grad_norms'] = np.array([grads[k].double().norm().item() for k in names])
+    out['update_norms'] = np.array([(sd1[k] - sd0[k]).double().norm().item() for k in names])
+    for nm, v in taps.items():
+        if keep in ('all', 'acts'):
+            out['act_' + nm] = v.numpy()
+        else:                     # compact: a strided sample plus a checksum
+            flat = v.reshape(-1)
+            out['act_' + nm + '_sample'] = flat[::max(1, flat.numel() // 512)][:512].numpy()
+            out['act_' + nm + '_abs_sum'] = np.float64(flat.double().abs().sum().item())
+    if keep == 'all':
+        for k in names:
+            out['w0/' + k] = sd0[k].numpy()
+            out['g/' + k] = grads[k].numpy()
+            out['w1/' + k] = sd1[k].numpy()
+    else:
+        for k in ('attention.phi.weight', 'encoder.blstm_1.layer.weight_hh_l0',
+                  'decoder.layer_1.weight_ih', 'char_trans.bias',
+                  'encoder.blstm_4.weight_ih_l0_reverse'):
+            out['g_head/' + k] = grads[k].reshape(-1)[:256].numpy()
+            out['w1_head/' + k] = sd1[k].reshape(-1)[:256].numpy()
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-18s loss %.6f  |g| %.6f  enc_len %s  %.1f KB' % (
+        name, loss.item(), float(grad_norm), enc_len[:6], os.path.getsize(path) / 1024))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    asr_mod = import_reference()
+    small = (50, 32, 32, 16, 12)         # output, enc H, dec H, mlp, feat
+    full = (50, 256, 256, 128, 80)       # conf/default.yaml:6-9 with feature_dim 80
+    capture(asr_mod, 'small_tf1', small, [64, 56, 48, 40], [10, 7, 5, 3], 1.0, 1)
+    capture(asr_mod, 'small_odd', small, [63, 51, 33, 17], [9, 9, 4, 6], 1.0, 2,
+            weights_seed=21, keep='acts')
+    capture(asr_mod, 'small_padded', small, [50, 50, 41, 24, 9], [3, 8, 8, 2, 5], 1.0, 3,
+            weights_seed=22, keep='acts', pad_to=72)
+    capture(asr_mod, 'small_greedy', small, [64, 56, 48, 40], [10, 7, 5, 3], 1.0, 4,
+            weights_seed=23, keep='acts', teacher=False, extra_decode=6)
+    capture(asr_mod, 'small_sampled', small, [64, 56, 48, 40], [10, 7, 5, 3], 0.5, 5,
+            weights_seed=24, keep='acts')
+    capture(asr_mod, 'full_b4', full, [64, 56, 48, 40], [10, 7, 5, 3], 1.0, 6,
+            weights_seed=11, keep='compact')
+    lens16 = sorted(np.random.default_rng(9).integers(200, 401, size=16).tolist(),
+                    reverse=True)
+    lens16[0] = 400
+    ylens16 = np.random.default_rng(10).integers(10, 41, size=16).tolist()
+    capture(asr_mod, 'full_b16_t400', full, lens16, ylens16, 1.0, 7,
+            weights_seed=12, keep='compact')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,123 @@
+"""Pins oracle/las_oracle.py against the golden vectors captured from the real
+reference (oracle/make_golden.py).  CPU only."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import las_oracle as lo
+
+CASES = ['small_tf1', 'small_odd', 'small_padded', 'small_greedy', 'small_sampled',
+         'full_b4']
+
+
+def build(fx):
+    dims = [int(v) for v in fx['dims']]
+    torch.manual_seed(0)
+    model = lo.OracleASR(*dims, float(fx['tf_rate']))
+    ws = int(fx['weights_seed'])
+    if ws >= 0:
+        lo.seeded_weights(model, ws)
+    else:
+        sd = {k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith('w0/')}
+        model.load_state_dict(sd)
+    return model
+
+
+def run(fx, model):
+    x = torch.from_numpy(fx['x'])
+    y = torch.from_numpy(fx['y'])
+    lens = [int(v) for v in fx['lens']]
+    ans_len = int(fx['ans_len'])
+    s = int(fx['rng_seed'])
+    random.seed(s); np.random.seed(s); torch.manual_seed(s)
+    enc_len, logits, att = model(x, int(fx['decode_steps']),
+                                 teacher=y if int(fx['teacher']) else None,
+                                 state_len=lens)
+    loss = lo.masked_ce_loss(logits[:, :ans_len], y, ans_len)
+    return enc_len, logits, att, loss
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_forward_matches_reference(golden, name):
+    fx = golden(name)
+    model = build(fx)
+    enc_len, logits, att, loss = run(fx, model)
+    assert enc_len == [int(v) for v in fx['enc_len']]
+    np.testing.assert_allclose(logits.detach().numpy(), fx['logits'], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(att.numpy(), fx['att'], atol=1e-6, rtol=0)
+    assert abs(float(loss) - float(fx['loss'])) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'full_b4'])
+def test_backward_and_step_match_reference(golden, name):
+    fx = golden(name)
+    model = build(fx)
+    optim = lo.make_optimizer(model)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    _, _, _, loss = run(fx, model)
+    loss.backward()
+    names = [str(n) for n in fx['param_names']]
+    params = dict(model.named_parameters())
+    got = np.array([params[n].grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(got, fx['grad_norms'], rtol=2e-4, atol=1e-7)
+    norm, stepped = lo.solver_step(list(model.parameters()), optim)
+    assert stepped and abs(norm - float(fx['grad_norm'])) < 1e-5
+    after = model.state_dict()
+    upd = np.array([(after[n] - before[n]).double().norm().item() for n in names])
+    np.testing.assert_allclose(upd, fx['update_norms'], rtol=2e-4, atol=1e-7)
+    if name == 'small_tf1':
+        for n in names:
+            np.testing.assert_allclose(after[n].numpy(), fx['w1/' + n], atol=2e-6, rtol=0)
+
+
+def test_explicit_encoder_matches_reference_activations(golden):
+    """The gate-by-gate restatement reproduces the reference's packed BiLSTM,
+    pyramid reshape and the utterance-axis recurrence of blstm_4."""
+    for name in ('small_tf1', 'small_odd', 'small_padded'):
+        fx = golden(name)
+        model = build(fx)
+        sd = model.state_dict()
+        x = torch.from_numpy(fx['x'])
+        lens = [int(v) for v in fx['lens']]
+        for layer in ('blstm_1', 'blstm_2', 'blstm_3'):
+            w = [sd['encoder.%s.layer.%s_l0%s' % (layer, k, sfx)]
+                 for sfx in ('', '_reverse')
+                 for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+            x, lens = lo.pyramid_explicit(x, lens, w)
+            np.testing.assert_allclose(x.numpy(), fx['act_' + layer], atol=2e-6, rtol=0)
+        w = [sd['encoder.blstm_4.%s_l0%s' % (k, sfx)] for sfx in ('', '_reverse')
+             for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        out = lo.bilstm_explicit(x, None, w)     # time axis = utterance axis
+        np.testing.assert_allclose(out.numpy(), fx['act_blstm_4'], atol=2e-6, rtol=0)
+        assert lens == [int(v) for v in fx['enc_len']]
+
+
+def test_explicit_clip_adadelta_matches_reference(golden):
+    fx = golden('small_tf1')
+    names = [str(n) for n in fx['param_names']]
+    params = [torch.from_numpy(fx['w0/' + n]).clone() for n in names]
+    grads = [torch.from_numpy(fx['g/' + n]).clone() for n in names]
+    sq = [torch.zeros_like(p) for p in params]
+    ad = [torch.zeros_like(p) for p in params]
+    norm, stepped = lo.clip_adadelta_explicit(params, grads, sq, ad)
+    assert stepped and abs(norm - float(fx['grad_norm'])) < 1e-6
+    for p, n in zip(params, names):
+        np.testing.assert_allclose(p.numpy(), fx['w1/' + n], atol=1e-6, rtol=0)
+
+
+def test_length_recovery_helpers(golden):
+    fx = golden('small_padded')
+    assert lo.frame_lengths(torch.from_numpy(fx['x'])) == [int(v) for v in fx['lens']]
+    y = torch.from_numpy(fx['y'])
+    assert max(lo.label_lengths(y)) - 1 == int(fx['ans_len'])
+
+
+@pytest.mark.slow
+def test_config1_shape_b16_t400(golden):
+    fx = golden('full_b16_t400')
+    model = build(fx)
+    enc_len, logits, att, loss = run(fx, model)
+    assert enc_len == [int(v) for v in fx['enc_len']]
+    assert abs(float(loss) - float(fx['loss'])) < 1e-4
