@@ -1,0 +1,195 @@
+/* ssasr.h -- C ABI of libssasr_hip.so: the MI355X (gfx950) kernels behind the
+ * ASR training hot path of cadia-lvl/ss_asr.
+ *
+ * The reference has no FFI layer: its "operator API" for this path is the
+ * nn.Module surface of src/asr.py plus Solver.step() in src/trainer.py, and
+ * all arithmetic is delegated to stock torch ops.  Each entry point below names
+ * the reference lines whose arithmetic it replaces.  The Python host side
+ * (ss_asr_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions (all entry points):
+ *   - plain C symbols; every pointer is a DEVICE pointer unless it says host;
+ *   - fp32 data, int32 lengths / character ids, int64_t sizes and strides
+ *     (strides in ELEMENTS);
+ *   - the caller owns every buffer, including workspaces; nothing is
+ *     allocated, no global state is kept, nothing synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t) by the calling thread;
+ *   - return 0 on success, a negative value for an argument error, a positive
+ *     hipError_t for a HIP failure.
+ */
+#ifndef SSASR_H
+#define SSASR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int ssasr_abi_version(void);
+
+/* C[b] = act(alpha * op(A[b]) . op(B[b]) + bias) + beta * C[b], fp32 MFMA.
+ * ta = 0: A is [M][K] (ld = lda); ta = 1: A is [K][M].
+ * tb = 0: B is [N][K] (torch Linear weight layout); tb = 1: B is [K][N].
+ * act: 0 none, 1 tanh.  splitk > 1 adds partial products atomically into a
+ * caller-initialised C (beta is then ignored).
+ * Replaces: torch.nn.Linear / torch.bmm call sites of src/asr.py:381,:385,:389
+ * and the dense halves of nn.LSTM (src/asr.py:414,:262). */
+int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                   int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
+                   const float* bias, int act, int64_t batch, int64_t strideA, int64_t strideB,
+                   int64_t strideC, int splitk, void* stream);
+
+/* Bidirectional LSTM layer with packed-sequence semantics.
+ * Logical input [S steps][N columns][I]: element (s, n, i) at
+ * x[s * xs_s + n * xs_n + i].  A pBLSTM layer (batch-first [B, T, I]) passes
+ * S = max(lens), N = B, xs_s = I, xs_n = T * I; blstm_4, which the reference
+ * runs over the utterance axis (src/asr.py:237-238, :262), passes S = B,
+ * N = T', lens = NULL.
+ * lens: int32[N] or NULL; column n is live while s < lens[n]; dead positions
+ * produce zeros in y (pad_packed_sequence, src/asr.py:417).
+ * y element (s, n, d * H + u) at y[s * ys_s + n * ys_n + d * H + u].
+ * Saved for backward: gates [2][S*N][4H], cs [2][S*N][H], hs [2][S*N][H].
+ * Replaces: pBLSTM.forward / nn.LSTM, src/asr.py:406-427, :262. */
+int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
+                     int64_t H, const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
+                     const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,
+                     const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* y,
+                     int64_t ys_s, int64_t ys_n, float* gates, float* cs, float* hs, void* stream);
+
+/* Backward of ssasr_bilstm_fwd.  `gates` is consumed (overwritten with the
+ * gate pre-activation derivatives).  dx may be NULL.  db_* is the derivative
+ * of b_ih and of b_hh alike.  Workspaces: ws_whhT [2][H][4H], ws_dc [2][2][N][H]. */
+int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
+                     int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H, const int32_t* lens,
+                     const float* w_ih_f, const float* w_hh_f, const float* w_ih_r,
+                     const float* w_hh_r, float* gates, const float* cs, const float* hs, float* dx,
+                     int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f, float* db_f,
+                     float* dw_ih_r, float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc,
+                     void* stream);
+
+/* One nn.LSTMCell step (src/asr.py:320-324); input given as column blocks
+ * x1 | x2 (x2 may be NULL).  gates [N][4H] receives the activated i,f,g,o. */
+int ssasr_lstm_cell_fwd(const float* x1, int64_t ldx1, int64_t k1, const float* x2, int64_t ldx2,
+                        int64_t k2, const float* h_prev, const float* c_prev, const float* w_ih,
+                        const float* w_hh, const float* b_ih, const float* b_hh, int64_t N,
+                        int64_t H, float* gates, float* h_out, float* c_out, void* stream);
+
+/* Gate derivatives of one cell step: dgates [N][4H], dc_prev [N][H]. */
+int ssasr_lstm_cell_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev,
+                        const float* c, int64_t N, int64_t H, float* dgates, float* dc_prev,
+                        void* stream);
+
+/* comp = tanh(feat . W_psi^T + b_psi), the cached half of Attention.forward
+ * (src/asr.py:381).  feat [rows][E], comp [rows][A]. */
+int ssasr_attn_precompute_fwd(const float* feat, const float* w_psi, const float* b_psi,
+                              int64_t rows, int64_t E, int64_t A, float* comp, void* stream);
+
+/* Backward of the above.  dcomp is consumed (becomes the pre-tanh
+ * derivative).  dfeat is ACCUMULATED into (beta = 1); dw_psi / db_psi are
+ * overwritten. */
+int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const float* feat,
+                              const float* w_psi, int64_t rows, int64_t E, int64_t A, float* dfeat,
+                              float* dw_psi, float* db_psi, void* stream);
+
+/* One Attention.forward call after the cache exists (src/asr.py:383-390).
+ * state [B][D] (NULL = zeros), w_phi_t [D][A] (phi.weight transposed),
+ * comp [B][T][A], feat [B][T][E], enc_len int32[B].
+ * Outputs: q [B][A] = tanh(phi(state)), att [B][T], ctx [B][E]. */
+int ssasr_attn_step_fwd(const float* state, const float* w_phi_t, const float* comp,
+                        const float* feat, const int32_t* enc_len, int64_t B, int64_t T, int64_t A,
+                        int64_t E, int64_t D, float* q, float* att, float* ctx, void* stream);
+
+/* Backward of one step given dctx [B][E] and datt [B][T] (may be NULL):
+ * de [B][T] (derivative w.r.t. the masked energies) and dqpre [B][A]
+ * (derivative w.r.t. phi's output before tanh). */
+int ssasr_attn_step_bwd(const float* dctx, const float* datt, const float* att, const float* q,
+                        const float* comp, const float* feat, const int32_t* enc_len, int64_t B,
+                        int64_t T, int64_t A, int64_t E, float* de, float* dqpre, void* stream);
+
+/* The fused decode loop of ASR.forward (src/asr.py:67-110): U steps of
+ * attention -> Speller cell 1 -> cell 2 (-> char_trans + next-character choice
+ * on steps that are not teacher forced), then char_trans for all steps. */
+typedef struct ssasr_decoder {
+  /* sizes */
+  int64_t B, T, E, A, D, V, U;
+  /* inputs */
+  const float* feat;        /* [B][T][E] listener output                         */
+  const float* comp;        /* [B][T][A] tanh(psi(feat))                         */
+  const int32_t* enc_len;   /* [B]                                               */
+  const int32_t* teacher;   /* [B][teacher_ld] character ids, or NULL            */
+  int64_t teacher_ld;
+  const int32_t* step_mode; /* HOST int32[U]: 0 teacher, 1 sample, 2 argmax      */
+  const float* uniforms;    /* [U][B] uniforms for sampled steps, or NULL        */
+  /* parameters (PyTorch layouts) */
+  const float* w_phi;       /* [A][D]                                            */
+  const float* w_ih1; const float* w_hh1; const float* b_ih1; const float* b_hh1; /* cell 1: I = D + E */
+  const float* w_ih2; const float* w_hh2; const float* b_ih2; const float* b_hh2; /* cell 2: I = D     */
+  const float* embed;       /* [V][D]                                            */
+  const float* w_ct; const float* b_ct;   /* [V][D], [V]                         */
+  /* outputs */
+  float* logits;            /* [B][U][V]                                         */
+  float* att;               /* [B][U][T]                                         */
+  /* saved for backward / workspaces */
+  float* w_phi_t;           /* [D][A]                                            */
+  float* q;                 /* [U][B][A]                                         */
+  float* ctx;               /* [U][B][E]                                         */
+  float* emb_in;            /* [U+1][B][D] embedding fed to each step            */
+  int32_t* chars;           /* [U+1][B]    character fed to each step            */
+  float* gates1; float* c1; float* h1;   /* [U][B][4D], [U][B][D], [U][B][D]     */
+  float* gates2; float* c2; float* h2;
+} ssasr_decoder;
+
+int ssasr_decoder_fwd(const ssasr_decoder* d, void* stream);
+
+typedef struct ssasr_decoder_grads {
+  const float* dlogits;     /* [B][U][V]                                         */
+  /* outputs (overwritten) */
+  float* dfeat;             /* [B][T][E] through the context vectors             */
+  float* dcomp;             /* [B][T][A]                                         */
+  float* dw_phi;
+  float* dw_ih1; float* dw_hh1; float* db1;   /* db = d b_ih = d b_hh            */
+  float* dw_ih2; float* dw_hh2; float* db2;
+  float* dembed; float* dw_ct; float* db_ct;
+  /* workspaces */
+  float* ws_t_ih1;          /* [D+E][4D] transposes of the cell weights          */
+  float* ws_t_hh1;          /* [D][4D]                                           */
+  float* ws_t_ih2;          /* [D][4D]                                           */
+  float* ws_t_hh2;          /* [D][4D]                                           */
+  float* ws_dh2;            /* [U][B][D]                                         */
+  float* ws_dctx;           /* [U][B][E]                                         */
+  float* ws_de;             /* [B][U][T]                                         */
+  float* ws_dqpre;          /* [U][B][A]                                         */
+  float* ws_dc;             /* [2][2][B][D]                                      */
+  float* ws_demb;           /* [U][B][D]                                         */
+} ssasr_decoder_grads;
+
+/* Backward of ssasr_decoder_fwd.  gates1 / gates2 of `d` are consumed. */
+int ssasr_decoder_bwd(const ssasr_decoder* d, const ssasr_decoder_grads* g, void* stream);
+
+/* Masked cross entropy of src/trainer.py:426-434.  logits [B][U][V]; labels
+ * int32 [B][U] (0 = ignore); denom [B] = count(y != 0) per row as float.
+ * loss is one float; lse [B][U] is saved for backward. */
+int ssasr_ce_loss_fwd(const float* logits, const int32_t* labels, const float* denom, int64_t B,
+                      int64_t U, int64_t V, float* lse, float* loss, void* stream);
+int ssasr_ce_loss_bwd(const float* logits, const int32_t* labels, const float* denom,
+                      const float* lse, const float* dloss, int64_t B, int64_t U, int64_t V,
+                      float* dlogits, void* stream);
+
+/* Solver.step (src/trainer.py:131-148) with torch.optim.Adadelta
+ * (src/trainer.py:401-403) on flat buffers of n floats: total L2 norm of
+ * grad * grad_scale, NaN guard, clip to max_norm, Adadelta update.
+ * stats: float[2] = {grad_norm, skipped (1 if the norm was NaN)}.
+ * ws: float[1 + blocks] scratch, blocks = ssasr_clip_adadelta_ws(n) - 1. */
+int64_t ssasr_clip_adadelta_ws(int64_t n);
+int ssasr_clip_adadelta(float* param, const float* grad, float* square_avg, float* acc_delta,
+                        int64_t n, float grad_scale, float max_norm, float lr, float rho,
+                        float eps, float* ws, float* stats, void* stream);
+
+/* Frame lengths of zero-padded fbanks, prepare_x (src/ASRDataset.py:314):
+ * lens[b] = number of frames whose feature sum is non-zero. */
+int ssasr_frame_lengths(const float* x, int64_t B, int64_t T, int64_t F, int32_t* lens,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

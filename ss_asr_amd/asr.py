@@ -1,0 +1,247 @@
+"""Listen-Attend-Spell model with the nn.Module surface of the reference's
+``src/asr.py`` (ASR :15-212, Listener :214-264, Speller :267-326, Attention
+:328-392, pBLSTM :394-450), computing on MI355X through libssasr_hip.so.
+
+The torch.nn modules held below (nn.LSTM, nn.LSTMCell, nn.Linear,
+nn.Embedding) are parameter containers only: they give the same
+``state_dict`` keys, parameter order and constructor-time RNG consumption as
+the reference, so checkpoints and seeded initialisations interchange.  Their
+``forward`` is never called; all arithmetic goes through ``ss_asr_amd.ops``.
+"""
+import math
+import random
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+EOS_INDEX = 1   # '>' in TOKENS + ALL_CHARS (src/preprocess.py:17-27)
+
+
+def _check_lengths(state_len, tmax):
+    """pack_padded_sequence's input contract (src/asr.py:413)."""
+    prev = None
+    for l in state_len:
+        if l <= 0:
+            raise RuntimeError('Length of all samples has to be greater than 0, '
+                               'but found an element in \'lengths\' that is <= 0')
+        if prev is not None and l > prev:
+            raise RuntimeError('`lengths` array must be sorted in decreasing order when '
+                               '`enforce_sorted` is True.')
+        prev = l
+    if state_len[0] > tmax:
+        raise RuntimeError('Expected sequence length to be larger than or equal to the '
+                           'maximum length in `lengths`')
+
+
+def _lstm_weights(lstm):
+    return [getattr(lstm, n + sfx) for sfx in ('', '_reverse')
+            for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+
+
+class pBLSTM(nn.Module):
+    """src/asr.py:394-450: packed BiLSTM, then concatenation of frame pairs."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.layer = nn.LSTM(in_dim, out_dim, bidirectional=True, batch_first=True)
+
+    def forward(self, input_x, state=None, state_len=None, pack_input=False, len_dev=None):
+        if state is not None:
+            raise NotImplementedError('initial states are always zero on the hot path')
+        if pack_input:
+            assert state_len is not None, \
+                "Please specify seq len for pack_padded_sequence."
+            state_len = [int(s) for s in state_len]
+            _check_lengths(state_len, input_x.shape[1])
+            steps = state_len[0]
+            if len_dev is None:
+                len_dev = torch.tensor(state_len, dtype=torch.int32, device=input_x.device)
+        else:
+            steps, len_dev = input_x.shape[1], None
+        output = ops.bilstm(input_x, len_dev, steps, True, _lstm_weights(self.layer))
+        output = self.downsample(output)
+        if state_len is not None:
+            return output, None, [int(s / 2) for s in state_len]
+        return output, None
+
+    def downsample(self, x):
+        """[B, T, F] -> [B, T//2, 2F]; an odd last frame is dropped (src/asr.py:429-450)."""
+        t_dim, f_dim = x.shape[1], x.shape[2]
+        if t_dim % 2 != 0:
+            x = x[:, :t_dim - 1, :]
+            t_dim -= 1
+        return x.contiguous().view([-1, int(t_dim / 2), f_dim * 2])
+
+
+class Listener(nn.Module):
+    """src/asr.py:214-264."""
+
+    def __init__(self, state_size, feature_dim):
+        super().__init__()
+        self.state_size = state_size
+        self.out_dim = 2 * self.state_size
+        self.blstm_1 = pBLSTM(feature_dim, self.state_size)
+        self.blstm_2 = pBLSTM(self.state_size * 2 * 2, self.state_size)
+        self.blstm_3 = pBLSTM(self.state_size * 2 * 2, self.state_size)
+        # Not batch_first in the reference (src/asr.py:237-238): the recurrence
+        # runs over the utterance axis, independently per encoder time index.
+        self.blstm_4 = nn.LSTM(self.state_size * 2 * 2, self.state_size, bidirectional=True)
+
+    def get_outdim(self):
+        return self.out_dim
+
+    def forward(self, x, state_len, pack_input=True):
+        len_dev = None
+        if pack_input:
+            len_dev = torch.tensor([int(s) for s in state_len], dtype=torch.int32, device=x.device)
+        for layer in (self.blstm_1, self.blstm_2, self.blstm_3):
+            x, _, state_len = layer(x, state_len=state_len, pack_input=pack_input, len_dev=len_dev)
+            if len_dev is not None:
+                len_dev = torch.div(len_dev, 2, rounding_mode='floor').to(torch.int32)
+        x = ops.bilstm(x, None, x.shape[0], False, _lstm_weights(self.blstm_4))   # src/asr.py:262
+        return x, state_len
+
+
+class Speller(nn.Module):
+    """src/asr.py:267-326."""
+
+    def __init__(self, state_size, encoder_out_size):
+        super().__init__()
+        self.layer_1 = nn.LSTMCell(input_size=encoder_out_size + state_size, hidden_size=state_size)
+        self.layer_2 = nn.LSTMCell(input_size=state_size, hidden_size=state_size)
+        self.state_list = []
+        self.cell_list = []
+        self.state_size = state_size
+        self.num_layers = 2
+
+    def init_rnn(self, batch_size, device):
+        self.state_list = [torch.zeros(batch_size, self.state_size, device=device)] * self.num_layers
+        self.cell_list = [torch.zeros(batch_size, self.state_size, device=device)] * self.num_layers
+
+    @property
+    def hidden_state(self):
+        return [s.clone().detach().cpu() for s in self.state_list], \
+            [c.clone().detach().cpu() for c in self.cell_list]
+
+    @hidden_state.setter
+    def hidden_state(self, state):
+        device = self.state_list[0].device
+        self.state_list = [s.to(device) for s in state[0]]
+        self.cell_list = [c.to(device) for c in state[1]]
+
+    def forward(self, input_context):
+        l1, l2 = self.layer_1, self.layer_2
+        self.state_list[0], self.cell_list[0] = ops.lstm_cell(
+            input_context, self.state_list[0], self.cell_list[0],
+            l1.weight_ih, l1.weight_hh, l1.bias_ih, l1.bias_hh)
+        self.state_list[1], self.cell_list[1] = ops.lstm_cell(
+            self.state_list[0], self.state_list[1], self.cell_list[1],
+            l2.weight_ih, l2.weight_hh, l2.bias_ih, l2.bias_hh)
+        return self.state_list[-1]
+
+
+class Attention(nn.Module):
+    """src/asr.py:328-392 (content based; psi projection cached per utterance batch)."""
+
+    def __init__(self, mlp_out_size, encoder_out_size, decoder_state_size):
+        super().__init__()
+        self.phi = nn.Linear(decoder_state_size, mlp_out_size, bias=False)
+        self.psi = nn.Linear(encoder_out_size, mlp_out_size)
+        self.comp_listener_feature = None
+        self.state_mask = None      # here: int32 lengths on the device
+
+    def reset_enc_mem(self):
+        self.comp_listener_feature = None
+        self.state_mask = None
+
+    def forward(self, decoder_state, listener_feature, state_len):
+        if self.comp_listener_feature is None:
+            self.state_mask = torch.tensor([int(s) for s in state_len], dtype=torch.int32,
+                                           device=listener_feature.device)
+            self.comp_listener_feature = ops.attn_precompute(
+                listener_feature, self.psi.weight, self.psi.bias)
+        return ops.attn_step(decoder_state, self.phi.weight, self.comp_listener_feature,
+                             listener_feature, self.state_mask)
+
+
+class ASR(nn.Module):
+    """src/asr.py:15-212; same constructor arguments and state_dict."""
+
+    def __init__(self, output_dim, encoder_state_size, decoder_state_size, mlp_out_size,
+                 feature_dim, tf_rate):
+        super().__init__()
+        enc_out_dim = encoder_state_size * 2
+        self.encoder = Listener(encoder_state_size, feature_dim)
+        self.attention = Attention(mlp_out_size, enc_out_dim, decoder_state_size)
+        self.decoder = Speller(decoder_state_size, enc_out_dim)
+        self.embed = nn.Embedding(output_dim, decoder_state_size)
+        self.char_trans = nn.Linear(decoder_state_size, output_dim)
+        self.tf_rate = tf_rate
+        # When True (default) the training-mode attention map is copied to the
+        # host asynchronously (pinned memory); call torch.cuda.synchronize()
+        # or self.att_event.synchronize() before reading it.  eval() mode
+        # always returns a finished copy.
+        self.async_att = True
+        self.att_event = None
+        self.last_chars = None
+        self.init_parameters()
+
+    def init_parameters(self):
+        """src/asr.py:175-212."""
+        for p in self.parameters():
+            data = p.data
+            if data.dim() == 1:
+                data.zero_()
+            elif data.dim() == 2:
+                data.normal_(0, 1. / math.sqrt(data.size(1)))
+            else:
+                raise NotImplementedError
+        self.embed.weight.data.normal_(0, 1)
+        for bias in (self.decoder.layer_1.bias_ih, self.decoder.layer_2.bias_ih):
+            n = bias.size(0)
+            bias.data[n // 4:n // 2].fill_(1.)
+
+    def _decoder_params(self):
+        l1, l2 = self.decoder.layer_1, self.decoder.layer_2
+        return dict(w_phi=self.attention.phi.weight,
+                    w_ih1=l1.weight_ih, w_hh1=l1.weight_hh, b_ih1=l1.bias_ih, b_hh1=l1.bias_hh,
+                    w_ih2=l2.weight_ih, w_hh2=l2.weight_hh, b_ih2=l2.bias_ih, b_hh2=l2.bias_hh,
+                    embed=self.embed.weight, w_ct=self.char_trans.weight,
+                    b_ct=self.char_trans.bias)
+
+    def forward(self, audio_feature, decode_step, teacher=None, state_len=None):
+        """Returns (encode_len: list[int], logits [B,U,V] on the device,
+        attention [B,U,T'] on the host, detached) -- src/asr.py:52-110."""
+        encode_feature, encode_len = self.encoder(audio_feature, state_len)
+        dev = encode_feature.device
+        enc_len_dev = torch.tensor([int(s) for s in encode_len], dtype=torch.int32, device=dev)
+        self.decoder.init_rnn(encode_feature.shape[0], dev)
+        self.attention.reset_enc_mem()
+        comp = ops.attn_precompute(encode_feature, self.attention.psi.weight,
+                                   self.attention.psi.bias)
+
+        # One host coin flip per step, as the reference draws them (src/asr.py:94).
+        if teacher is not None:
+            modes = [0 if random.random() <= self.tf_rate else 1 for _ in range(decode_step)]
+            teacher_i32 = teacher.to(torch.int32)
+        else:
+            modes = [2] * decode_step
+            teacher_i32 = None
+        uniforms = None
+        if 1 in modes:
+            # Categorical(...).sample() of the reference (src/asr.py:97): one
+            # uniform per (step, utterance), inverse-CDF draw inside the kernel.
+            uniforms = torch.rand(decode_step, encode_feature.shape[0], device=dev)
+        logits, att, chars = ops.decoder_loop(encode_feature, comp, enc_len_dev, teacher_i32,
+                                              modes, uniforms, self._decoder_params())
+        self.last_chars = chars
+        if self.training and self.async_att:
+            host = torch.empty(att.shape, dtype=att.dtype, pin_memory=True)
+            host.copy_(att.detach(), non_blocking=True)
+            self.att_event = torch.cuda.Event()
+            self.att_event.record()
+        else:
+            host = att.detach().cpu()
+        return encode_len, logits, host

@@ -1,0 +1,75 @@
+// Shared device helpers for the ss_asr hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SSASR_OK 0
+#define SSASR_EARG (-1)
+
+// Launch check used by every host entry point: argument errors are negative,
+// HIP errors are returned as positive hipError_t values.
+#define SSASR_LAUNCH_CHECK()                         \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+#define SSASR_HIP(call)                              \
+  do {                                               \
+    hipError_t e__ = (call);                         \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+// address of row i of a matrix whose rows are either dense (i * ld) or laid
+// out as (outer, inner) pairs: i = outer * inner_count + inner.  The second
+// form reads a batch-first [B, T, F] tensor as the time-major row s * B + b
+// without a transposing copy.
+struct RowMap {
+  int64_t ld;
+  int64_t inner;  // 0 => dense
+  int64_t so;     // stride of the outer index
+  int64_t si;     // stride of the inner index
+};
+
+__device__ __forceinline__ int64_t rm_off(const RowMap& m, int64_t i) {
+  return m.inner ? (i / m.inner) * m.so + (i % m.inner) * m.si : i * m.ld;
+}
+
+static inline RowMap rm_dense(int64_t ld) { return RowMap{ld, 0, 0, 0}; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// 64-lane butterfly reductions (wave64).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- internal launchers shared between translation units -----------------
+struct GemmDesc {
+  const float* A;
+  const float* B;
+  float* C;
+  RowMap ma, mb, mc;   // ma maps A's major index (row m, or k when ta), etc.
+  int M, N, K;
+  int ta;              // 0: A stored [M][K]   1: A stored [K][M]
+  int tb;              // 0: B stored [N][K]   1: B stored [K][N]
+  const float* bias1;  // per output column, optional
+  const float* bias2;  // per output column, optional
+  int act;             // 0 none, 1 tanh
+  float alpha, beta;   // C = act(alpha * A.B + bias) + beta * C
+  int splitk;          // >1: partial products are atomically added into C
+  int batch;
+  int64_t sa, sb, sc, sbias;
+};
+int ssasr_launch_gemm(const GemmDesc& g, hipStream_t st);
+int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);
+int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st);

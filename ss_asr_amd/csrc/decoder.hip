@@ -1,0 +1,387 @@
+// Attention entry points and the fused Speller decode loop.
+// Reference: ASR.forward decode loop src/asr.py:67-110, Attention src/asr.py:328-392,
+// Speller src/asr.py:267-326.  Kernels: attn_kernels.h, rnn_kernels.h.
+#include "../../include/ssasr.h"
+#include "attn_kernels.h"
+#include "rnn_kernels.h"
+
+extern "C" int ssasr_abi_version(void) { return 1; }
+
+// ------------------------------ attention ---------------------------------
+extern "C" int ssasr_attn_precompute_fwd(const float* feat, const float* w_psi, const float* b_psi,
+                                         int64_t rows, int64_t E, int64_t A, float* comp,
+                                         void* stream) {
+  if (!feat || !w_psi || !comp || rows <= 0 || E <= 0 || A <= 0) return SSASR_EARG;
+  GemmDesc g{};
+  g.A = feat; g.ma = rm_dense(E);
+  g.B = w_psi; g.mb = rm_dense(E);
+  g.C = comp; g.mc = rm_dense(A);
+  g.M = (int)rows; g.N = (int)A; g.K = (int)E;
+  g.bias1 = b_psi; g.act = 1; g.alpha = 1.f; g.beta = 0.f; g.splitk = 1; g.batch = 1;
+  return ssasr_launch_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const float* feat,
+                                         const float* w_psi, int64_t rows, int64_t E, int64_t A,
+                                         float* dfeat, float* dw_psi, float* db_psi, void* stream) {
+  if (!dcomp || !comp || !feat || !w_psi || rows <= 0) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = rows * A;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dcomp, comp, n);
+  SSASR_LAUNCH_CHECK();
+  int rc;
+  if (dfeat) {   // dfeat += dpre . W_psi
+    GemmDesc g{};
+    g.A = dcomp; g.ma = rm_dense(A);
+    g.B = w_psi; g.mb = rm_dense(E);
+    g.C = dfeat; g.mc = rm_dense(E);
+    g.M = (int)rows; g.N = (int)E; g.K = (int)A;
+    g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.batch = 1;
+    if ((rc = ssasr_launch_gemm(g, st))) return rc;
+  }
+  if (dw_psi) {  // dW_psi = dpre^T . feat
+    SSASR_HIP(hipMemsetAsync(dw_psi, 0, sizeof(float) * A * E, st));
+    GemmDesc g{};
+    g.A = dcomp; g.ma = rm_dense(A);
+    g.B = feat; g.mb = rm_dense(E);
+    g.C = dw_psi; g.mc = rm_dense(E);
+    g.M = (int)A; g.N = (int)E; g.K = (int)rows;
+    g.ta = 1; g.tb = 1; g.alpha = 1.f; g.batch = 1;
+    g.splitk = rows >= 2048 ? 16 : 1;
+    if ((rc = ssasr_launch_gemm(g, st))) return rc;
+  }
+  if (db_psi) {
+    SSASR_HIP(hipMemsetAsync(db_psi, 0, sizeof(float) * A, st));
+    if ((rc = ssasr_launch_colsum(dcomp, rows, (int)A, A, db_psi, st))) return rc;
+  }
+  return SSASR_OK;
+}
+
+namespace {
+
+bool attn_dims_ok(int64_t B, int64_t T, int64_t A, int64_t E, int64_t D) {
+  return B > 0 && T > 0 && A > 0 && E > 0 && D >= 0 && A % 4 == 0 && E % 4 == 0 && D % 4 == 0 &&
+         T <= 16384 && A <= 2048 && E <= 8192;
+}
+
+int launch_attn_fwd(const AttnFwd& p, hipStream_t st) {
+  hipLaunchKernelGGL(attn_step_fwd_kernel, dim3((unsigned)p.B, (unsigned)p.nch), dim3(256),
+                     attn_fwd_lds(p.D, p.A, p.T), st, p);
+  return SSASR_OK;
+}
+
+int launch_attn_bwd(const AttnBwd& p, hipStream_t st) {
+  hipLaunchKernelGGL(attn_step_bwd_kernel, dim3((unsigned)p.B), dim3(512), attn_bwd_lds(p.E, p.T), st, p);
+  return SSASR_OK;
+}
+
+}  // namespace
+
+extern "C" int ssasr_attn_step_fwd(const float* state, const float* w_phi_t, const float* comp,
+                                   const float* feat, const int32_t* enc_len, int64_t B, int64_t T,
+                                   int64_t A, int64_t E, int64_t D, float* q, float* att,
+                                   float* ctx, void* stream) {
+  if (!w_phi_t || !comp || !feat || !q || !att || !ctx || !attn_dims_ok(B, T, A, E, D)) return SSASR_EARG;
+  AttnFwd p{};
+  p.s = state; p.lds = D; p.wphiT = w_phi_t; p.comp = comp; p.feat = feat; p.lens = enc_len;
+  p.q = q; p.att = att; p.att_sb = T; p.ctx = ctx; p.ctx_ld = E;
+  p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.D = (int)D; p.nch = attn_pick_nch((int)E);
+  launch_attn_fwd(p, (hipStream_t)stream);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_attn_step_bwd(const float* dctx, const float* datt, const float* att,
+                                   const float* q, const float* comp, const float* feat,
+                                   const int32_t* enc_len, int64_t B, int64_t T, int64_t A,
+                                   int64_t E, float* de, float* dqpre, void* stream) {
+  if (!dctx || !att || !q || !comp || !feat || !de || !dqpre || !attn_dims_ok(B, T, A, E, 0)) return SSASR_EARG;
+  AttnBwd p{};
+  p.dctx = dctx; p.dctx_ld = E; p.datt = datt; p.datt_sb = T; p.att = att; p.att_sb = T; p.q = q;
+  p.comp = comp; p.feat = feat; p.lens = enc_len; p.de = de; p.de_sb = T; p.dqpre = dqpre;
+  p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E;
+  launch_attn_bwd(p, (hipStream_t)stream);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+// ------------------------------ decode loop --------------------------------
+extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
+  if (!dp) return SSASR_EARG;
+  const ssasr_decoder& d = *dp;
+  const int64_t B = d.B, T = d.T, E = d.E, A = d.A, D = d.D, V = d.V, U = d.U;
+  if (!attn_dims_ok(B, T, A, E, D) || D % 16 != 0 || V <= 0 || U <= 0) return SSASR_EARG;
+  if (!d.feat || !d.comp || !d.enc_len || !d.step_mode || !d.logits || !d.att || !d.w_phi_t || !d.q ||
+      !d.ctx || !d.emb_in || !d.chars || !d.gates1 || !d.c1 || !d.h1 || !d.gates2 || !d.c2 || !d.h2)
+    return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  bool any_teacher = false, any_sample = false;
+  for (int64_t t = 0; t < U; ++t) {
+    if (d.step_mode[t] == 0) any_teacher = true;
+    else if (d.step_mode[t] == 1) any_sample = true;
+    else if (d.step_mode[t] != 2) return SSASR_EARG;
+  }
+  if (any_teacher && (!d.teacher || d.teacher_ld < U + 1)) return SSASR_EARG;
+  if (any_sample && !d.uniforms) return SSASR_EARG;
+
+  if ((rc = ssasr_launch_transpose(d.w_phi, d.w_phi_t, (int)A, (int)D, st))) return rc;
+
+  // chars[0] = <sos> = 0 (src/asr.py:73); chars[t] = teacher[:, t] (src/asr.py:95).
+  // Steps that are not teacher forced overwrite their successor's entry in the loop.
+  {
+    const int n = (int)(B * (U + 1));
+    hipLaunchKernelGGL(teacher_chars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d.teacher,
+                       d.teacher_ld, d.chars, (int)B, (int)(U + 1));
+  }
+  // Embeddings of every known input character in one gather; rows of sampled
+  // steps are overwritten inside the loop.
+  hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)((U + 1) * B)), dim3(64), 0, st, d.embed, d.chars,
+                     d.emb_in, (U + 1) * B, (int)D);
+  SSASR_LAUNCH_CHECK();
+
+  const int nch = attn_pick_nch((int)E);
+  dim3 cgrid((unsigned)(D / 4), 1, (unsigned)((B + 31) / 32)), cblock(256);
+  for (int64_t t = 0; t < U; ++t) {
+    AttnFwd p{};
+    p.s = t ? d.h1 + (t - 1) * B * D : nullptr; p.lds = D;
+    p.wphiT = d.w_phi_t; p.comp = d.comp; p.feat = d.feat; p.lens = d.enc_len;
+    p.q = d.q + t * B * A; p.att = d.att + t * T; p.att_sb = U * T;
+    p.ctx = d.ctx + t * B * E; p.ctx_ld = E;
+    p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.D = (int)D; p.nch = nch;
+    launch_attn_fwd(p, st);
+
+    CellFwdPair c1{};
+    {
+      CellFwd& c = c1.d[0];
+      int ns = 0;
+      seg_set(c.sl, ns++, d.emb_in + t * B * D, D, d.w_ih1, D + E, (int)D);
+      seg_set(c.sl, ns++, d.ctx + t * B * E, E, d.w_ih1 + D, D + E, (int)E);
+      if (t) {
+        seg_set(c.sl, ns++, d.h1 + (t - 1) * B * D, D, d.w_hh1, D, (int)D);
+        c.c_prev = d.c1 + (t - 1) * B * D;
+      }
+      c.sl.nseg = ns;
+      c.b1 = d.b_ih1; c.b2 = d.b_hh1;
+      c.gates = d.gates1 + t * B * 4 * D; c.c_out = d.c1 + t * B * D; c.h_out = d.h1 + t * B * D;
+      c.N = (int)B; c.H = (int)D;
+    }
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, cgrid, cblock, 0, st, c1);
+
+    CellFwdPair c2{};
+    {
+      CellFwd& c = c2.d[0];
+      int ns = 0;
+      seg_set(c.sl, ns++, d.h1 + t * B * D, D, d.w_ih2, D, (int)D);
+      if (t) {
+        seg_set(c.sl, ns++, d.h2 + (t - 1) * B * D, D, d.w_hh2, D, (int)D);
+        c.c_prev = d.c2 + (t - 1) * B * D;
+      }
+      c.sl.nseg = ns;
+      c.b1 = d.b_ih2; c.b2 = d.b_hh2;
+      c.gates = d.gates2 + t * B * 4 * D; c.c_out = d.c2 + t * B * D; c.h_out = d.h2 + t * B * D;
+      c.N = (int)B; c.H = (int)D;
+    }
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, cgrid, cblock, 0, st, c2);
+
+    if (d.step_mode[t] != 0) {
+      CharSelect s{};
+      s.h2 = d.h2 + t * B * D; s.wct = d.w_ct; s.bct = d.b_ct; s.embed = d.embed;
+      s.uni = d.uniforms ? d.uniforms + t * B : nullptr;
+      s.chars_next = d.chars + (t + 1) * B; s.emb_next = d.emb_in + (t + 1) * B * D;
+      s.B = (int)B; s.D = (int)D; s.V = (int)V; s.mode = d.step_mode[t];
+      hipLaunchKernelGGL(char_select_kernel, dim3((unsigned)B), dim3(256), sizeof(float) * (V + 16), st, s);
+    }
+  }
+  SSASR_LAUNCH_CHECK();
+
+  // logits[b][t][:] = h2[t][b][:] . W_ct^T + b_ct   (src/asr.py:89), all steps at once
+  GemmDesc g{};
+  g.A = d.h2; g.ma = rm_dense(D);
+  g.B = d.w_ct; g.mb = rm_dense(D);
+  g.C = d.logits; g.mc = RowMap{0, B, V, U * V};   // row t*B+b -> b*U*V + t*V
+  g.M = (int)(U * B); g.N = (int)V; g.K = (int)D;
+  g.bias1 = d.b_ct; g.alpha = 1.f; g.beta = 0.f; g.splitk = 1; g.batch = 1;
+  return ssasr_launch_gemm(g, st);
+}
+
+namespace {
+
+int gemm_tn_acc(const float* A, RowMap ma, const float* B, RowMap mb, float* C, int64_t ldc, int64_t M,
+                int64_t N, int64_t K, hipStream_t st) {
+  // C[M][N] += A^T . B with A stored [K][M], B stored [K][N]; C pre-zeroed.
+  if (K <= 0) return SSASR_OK;
+  GemmDesc g{};
+  g.A = A; g.ma = ma; g.B = B; g.mb = mb; g.C = C; g.mc = rm_dense(ldc);
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.ta = 1; g.tb = 1;
+  g.alpha = 1.f; g.batch = 1;
+  const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  int sk = (int)(256 / tiles); if (sk < 1) sk = 1; if (sk > 16) sk = 16;
+  if (K < 128 * sk) sk = K >= 256 ? 2 : 1;
+  g.splitk = sk < 2 ? 2 : sk;      // always the accumulate form
+  return ssasr_launch_gemm(g, st);
+}
+
+}  // namespace
+
+extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_grads* gp, void* stream) {
+  if (!dp || !gp) return SSASR_EARG;
+  const ssasr_decoder& d = *dp;
+  const ssasr_decoder_grads& g = *gp;
+  const int64_t B = d.B, T = d.T, E = d.E, A = d.A, D = d.D, V = d.V, U = d.U;
+  if (!attn_dims_ok(B, T, A, E, D) || D % 16 != 0 || V <= 0 || U <= 0) return SSASR_EARG;
+  if (!g.dlogits || !g.dfeat || !g.dcomp || !g.dw_phi || !g.dw_ih1 || !g.dw_hh1 || !g.db1 || !g.dw_ih2 ||
+      !g.dw_hh2 || !g.db2 || !g.dembed || !g.dw_ct || !g.db_ct || !g.ws_t_ih1 || !g.ws_t_hh1 ||
+      !g.ws_t_ih2 || !g.ws_t_hh2 || !g.ws_dh2 || !g.ws_dctx || !g.ws_de || !g.ws_dqpre || !g.ws_dc ||
+      !g.ws_demb)
+    return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  const int64_t rows = U * B;
+  const RowMap logit_rows{0, B, V, U * V};        // row t*B+b of a [B][U][V] tensor
+
+  // char_trans: dh2 = dlogits . W_ct ; dW_ct = dlogits^T . h2 ; db_ct = colsum
+  {
+    GemmDesc m{};
+    m.A = g.dlogits; m.ma = logit_rows;
+    m.B = d.w_ct; m.mb = rm_dense(D);
+    m.C = g.ws_dh2; m.mc = rm_dense(D);
+    m.M = (int)rows; m.N = (int)D; m.K = (int)V; m.ta = 0; m.tb = 1;
+    m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
+    if ((rc = ssasr_launch_gemm(m, st))) return rc;
+  }
+  SSASR_HIP(hipMemsetAsync(g.dw_ct, 0, sizeof(float) * V * D, st));
+  if ((rc = gemm_tn_acc(g.dlogits, logit_rows, d.h2, rm_dense(D), g.dw_ct, D, V, D, rows, st))) return rc;
+  SSASR_HIP(hipMemsetAsync(g.db_ct, 0, sizeof(float) * V, st));
+  if ((rc = ssasr_launch_colsum(g.dlogits, B * U, (int)V, V, g.db_ct, st))) return rc;
+
+  // K-contiguous copies of the recurrent weights for the per-step products.
+  if ((rc = ssasr_launch_transpose(d.w_ih1, g.ws_t_ih1, (int)(4 * D), (int)(D + E), st))) return rc;
+  if ((rc = ssasr_launch_transpose(d.w_hh1, g.ws_t_hh1, (int)(4 * D), (int)D, st))) return rc;
+  if ((rc = ssasr_launch_transpose(d.w_ih2, g.ws_t_ih2, (int)(4 * D), (int)D, st))) return rc;
+  if ((rc = ssasr_launch_transpose(d.w_hh2, g.ws_t_hh2, (int)(4 * D), (int)D, st))) return rc;
+
+  dim3 cgrid((unsigned)(D / 16), 1, (unsigned)((B + 31) / 32)), cblock(256);
+  float* dc1 = g.ws_dc;               // [2][B][D]
+  float* dc2 = g.ws_dc + 2 * B * D;   // [2][B][D]
+  for (int64_t t = U - 1; t >= 0; --t) {
+    const int64_t i = U - 1 - t;
+    const bool last = (t == U - 1);
+    // cell 2: dh2_t = dH2L[t] + dG2[t+1] . W_hh2
+    CellBwdPair p2{};
+    {
+      CellBwd& c = p2.d[0];
+      int ns = 0;
+      if (!last) {
+        seg_set(c.sl, ns++, d.gates2 + (t + 1) * B * 4 * D, 4 * D, g.ws_t_hh2, 4 * D, (int)(4 * D));
+        c.dc_in = dc2 + (i & 1) * B * D;
+      }
+      c.sl.nseg = ns;
+      c.add1 = g.ws_dh2 + t * B * D; c.ld1 = D;
+      c.gates = d.gates2 + t * B * 4 * D; c.dgates = d.gates2 + t * B * 4 * D;
+      c.c_prev = t ? d.c2 + (t - 1) * B * D : nullptr;
+      c.c = d.c2 + t * B * D;
+      c.dc_out = dc2 + ((i + 1) & 1) * B * D;
+      c.N = (int)B; c.H = (int)D;
+    }
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, cgrid, cblock, 0, st, p2);
+
+    // cell 1: dh1_t = dG2[t] . W_ih2 + dG1[t+1] . W_hh1 + dqpre[t+1] . W_phi
+    CellBwdPair p1{};
+    {
+      CellBwd& c = p1.d[0];
+      int ns = 0;
+      seg_set(c.sl, ns++, d.gates2 + t * B * 4 * D, 4 * D, g.ws_t_ih2, 4 * D, (int)(4 * D));
+      if (!last) {
+        seg_set(c.sl, ns++, d.gates1 + (t + 1) * B * 4 * D, 4 * D, g.ws_t_hh1, 4 * D, (int)(4 * D));
+        seg_set(c.sl, ns++, g.ws_dqpre + (t + 1) * B * A, A, d.w_phi_t, A, (int)A);
+        c.dc_in = dc1 + (i & 1) * B * D;
+      }
+      c.sl.nseg = ns;
+      c.gates = d.gates1 + t * B * 4 * D; c.dgates = d.gates1 + t * B * 4 * D;
+      c.c_prev = t ? d.c1 + (t - 1) * B * D : nullptr;
+      c.c = d.c1 + t * B * D;
+      c.dc_out = dc1 + ((i + 1) & 1) * B * D;
+      c.N = (int)B; c.H = (int)D;
+    }
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, cgrid, cblock, 0, st, p1);
+
+    // dctx_t = dG1[t] . W_ih1[:, D:]
+    PlainMm pm{};
+    pm.sl.nseg = 1;
+    seg_set(pm.sl, 0, d.gates1 + t * B * 4 * D, 4 * D, g.ws_t_ih1 + D * 4 * D, 4 * D, (int)(4 * D));
+    pm.out = g.ws_dctx + t * B * E; pm.ldo = E; pm.N = (int)B; pm.R = (int)E;
+    hipLaunchKernelGGL(seg_matmul_plain_kernel, dim3((unsigned)((E + 15) / 16), 1, (unsigned)((B + 31) / 32)),
+                       dim3(256), 0, st, pm);
+
+    // attention step backward (step 0 has q = 0 and s = 0: only the context
+    // path carries gradient, handled by the batched product below)
+    if (t > 0) {
+      AttnBwd ab{};
+      ab.dctx = g.ws_dctx + t * B * E; ab.dctx_ld = E;
+      ab.att = d.att + t * T; ab.att_sb = U * T;
+      ab.q = d.q + t * B * A; ab.comp = d.comp; ab.feat = d.feat; ab.lens = d.enc_len;
+      ab.de = g.ws_de + t * T; ab.de_sb = U * T;
+      ab.dqpre = g.ws_dqpre + t * B * A;
+      ab.B = (int)B; ab.T = (int)T; ab.A = (int)A; ab.E = (int)E;
+      launch_attn_bwd(ab, st);
+    }
+  }
+  SSASR_LAUNCH_CHECK();
+  // step 0 contributes nothing through the energies
+  SSASR_HIP(hipMemset2DAsync(g.ws_de, sizeof(float) * U * T, 0, sizeof(float) * T, B, st));
+  SSASR_HIP(hipMemsetAsync(g.ws_dqpre, 0, sizeof(float) * B * A, st));
+
+  // ---- products over all steps ----
+  {   // dfeat[b] = att[b]^T . dctx[:, b, :]        [T][E] per utterance
+    GemmDesc m{};
+    m.A = d.att; m.ma = rm_dense(T); m.sa = U * T;
+    m.B = g.ws_dctx; m.mb = rm_dense(B * E); m.sb = E;
+    m.C = g.dfeat; m.mc = rm_dense(E); m.sc = T * E;
+    m.M = (int)T; m.N = (int)E; m.K = (int)U; m.ta = 1; m.tb = 1;
+    m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = (int)B;
+    if ((rc = ssasr_launch_gemm(m, st))) return rc;
+  }
+  {   // dcomp[b] = de[b]^T . q[:, b, :]            [T][A] per utterance
+    GemmDesc m{};
+    m.A = g.ws_de; m.ma = rm_dense(T); m.sa = U * T;
+    m.B = d.q; m.mb = rm_dense(B * A); m.sb = A;
+    m.C = g.dcomp; m.mc = rm_dense(A); m.sc = T * A;
+    m.M = (int)T; m.N = (int)A; m.K = (int)U; m.ta = 1; m.tb = 1;
+    m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = (int)B;
+    if ((rc = ssasr_launch_gemm(m, st))) return rc;
+  }
+  // dW_phi = sum_{t>=1} dqpre[t]^T . h1[t-1]
+  SSASR_HIP(hipMemsetAsync(g.dw_phi, 0, sizeof(float) * A * D, st));
+  if ((rc = gemm_tn_acc(g.ws_dqpre + B * A, rm_dense(A), d.h1, rm_dense(D), g.dw_phi, D, A, D, (U - 1) * B, st))) return rc;
+  // cell 1: dW_ih1 = dG1^T . [emb_in | ctx], dW_hh1 = dG1[1:]^T . h1[:-1], db1
+  SSASR_HIP(hipMemsetAsync(g.dw_ih1, 0, sizeof(float) * 4 * D * (D + E), st));
+  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.emb_in, rm_dense(D), g.dw_ih1, D + E, 4 * D, D, rows, st))) return rc;
+  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.ctx, rm_dense(E), g.dw_ih1 + D, D + E, 4 * D, E, rows, st))) return rc;
+  SSASR_HIP(hipMemsetAsync(g.dw_hh1, 0, sizeof(float) * 4 * D * D, st));
+  if ((rc = gemm_tn_acc(d.gates1 + B * 4 * D, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_hh1, D, 4 * D, D, (U - 1) * B, st))) return rc;
+  SSASR_HIP(hipMemsetAsync(g.db1, 0, sizeof(float) * 4 * D, st));
+  if ((rc = ssasr_launch_colsum(d.gates1, rows, (int)(4 * D), 4 * D, g.db1, st))) return rc;
+  // cell 2
+  SSASR_HIP(hipMemsetAsync(g.dw_ih2, 0, sizeof(float) * 4 * D * D, st));
+  if ((rc = gemm_tn_acc(d.gates2, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_ih2, D, 4 * D, D, rows, st))) return rc;
+  SSASR_HIP(hipMemsetAsync(g.dw_hh2, 0, sizeof(float) * 4 * D * D, st));
+  if ((rc = gemm_tn_acc(d.gates2 + B * 4 * D, rm_dense(4 * D), d.h2, rm_dense(D), g.dw_hh2, D, 4 * D, D, (U - 1) * B, st))) return rc;
+  SSASR_HIP(hipMemsetAsync(g.db2, 0, sizeof(float) * 4 * D, st));
+  if ((rc = ssasr_launch_colsum(d.gates2, rows, (int)(4 * D), 4 * D, g.db2, st))) return rc;
+  // embedding: demb = dG1 . W_ih1[:, :D], scattered onto the rows that were fed
+  {
+    GemmDesc m{};
+    m.A = d.gates1; m.ma = rm_dense(4 * D);
+    m.B = d.w_ih1; m.mb = rm_dense(D + E);
+    m.C = g.ws_demb; m.mc = rm_dense(D);
+    m.M = (int)rows; m.N = (int)D; m.K = (int)(4 * D); m.ta = 0; m.tb = 1;
+    m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
+    if ((rc = ssasr_launch_gemm(m, st))) return rc;
+  }
+  SSASR_HIP(hipMemsetAsync(g.dembed, 0, sizeof(float) * V * D, st));
+  hipLaunchKernelGGL(embed_scatter_add_kernel, dim3((unsigned)rows), dim3(64), 0, st, g.ws_demb, d.chars,
+                     g.dembed, rows, (int)D);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}

@@ -1,0 +1,264 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_16x16x4_f32: exact f32, one
+// rounding per product, the same arithmetic a chain of fmaf would give).
+//
+// Used where the ASR train step has a true dense contraction: the
+// input->hidden projections of every (p)BLSTM layer over all time steps at
+// once (reference: the i2h half of nn.LSTM, src/asr.py:414 / :262), the psi
+// projection of the listener features (src/asr.py:381), and every weight /
+// input gradient of those layers and of the speller cells.
+//
+// Tiling: 256 threads = 4 waves in a 2x2 grid; block tile BM x BN (128x128 or
+// 64x64), K step 16.  Tiles are staged global -> registers -> LDS with one
+// barrier per K step (two LDS buffers); the next tile's global loads are in
+// flight while the current one feeds the MFMAs.  Either operand may be stored
+// with K contiguous or with its M/N index contiguous; the LDS image keeps the
+// source's contiguous axis so that staging stores are 16-byte writes.  Inside
+// one 16-deep K step MFMA j (j = 0..3) consumes k = 4 * (lane >> 4) + j from
+// both operands, which lets a K-contiguous operand be fetched with a single
+// ds_read_b128 per 16x16 fragment.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int LDK = BK + 4;   // K-contiguous LDS image: [rows][LDK]
+
+template <int BMN, bool T>
+struct TileGeom {
+  static constexpr int LDM = BMN + 4;                       // MN-contiguous image: [BK][LDM]
+  static constexpr int FLOATS = T ? BK * LDM : BMN * LDK;
+  static constexpr int NV = BMN * BK / 4 / 256;             // float4 loads per thread per tile
+};
+
+struct Operand {
+  const float* p;
+  RowMap m;
+  int extent;   // M or N
+  bool vec;     // 16-byte loads are legal
+};
+
+// Loads this thread's share of one BMN x BK operand tile into registers.
+template <int BMN, bool T>
+__device__ __forceinline__ void load_tile(const Operand& op, int mn0, int k0, int kend, int tid,
+                                          float4 (&v)[TileGeom<BMN, T>::NV]) {
+#pragma unroll
+  for (int i = 0; i < TileGeom<BMN, T>::NV; ++i) {
+    const int f = tid + i * 256;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (!T) {
+      const int row = mn0 + (f >> 2);
+      const int k = k0 + (f & 3) * 4;
+      if (row < op.extent && k < kend) {
+        const float* src = op.p + rm_off(op.m, row) + k;
+        if (op.vec && k + 3 < kend) {
+          x = *reinterpret_cast<const float4*>(src);
+        } else {
+          x.x = src[0];
+          if (k + 1 < kend) x.y = src[1];
+          if (k + 2 < kend) x.z = src[2];
+          if (k + 3 < kend) x.w = src[3];
+        }
+      }
+    } else {
+      constexpr int PER_ROW = BMN / 4;
+      const int k = k0 + f / PER_ROW;
+      const int mn = mn0 + (f % PER_ROW) * 4;
+      if (k < kend && mn < op.extent) {
+        const float* src = op.p + rm_off(op.m, k) + mn;
+        if (op.vec && mn + 3 < op.extent) {
+          x = *reinterpret_cast<const float4*>(src);
+        } else {
+          x.x = src[0];
+          if (mn + 1 < op.extent) x.y = src[1];
+          if (mn + 2 < op.extent) x.z = src[2];
+          if (mn + 3 < op.extent) x.w = src[3];
+        }
+      }
+    }
+    v[i] = x;
+  }
+}
+
+template <int BMN, bool T>
+__device__ __forceinline__ void store_tile(float* lds, int tid,
+                                           const float4 (&v)[TileGeom<BMN, T>::NV]) {
+#pragma unroll
+  for (int i = 0; i < TileGeom<BMN, T>::NV; ++i) {
+    const int f = tid + i * 256;
+    if constexpr (!T) {
+      *reinterpret_cast<float4*>(lds + (f >> 2) * LDK + (f & 3) * 4) = v[i];
+    } else {
+      constexpr int PER_ROW = BMN / 4;
+      *reinterpret_cast<float4*>(lds + (f / PER_ROW) * TileGeom<BMN, T>::LDM + (f % PER_ROW) * 4) = v[i];
+    }
+  }
+}
+
+// Fragment of one 16-wide slice for the four MFMAs of a K step.
+template <int BMN, bool T>
+__device__ __forceinline__ float4 read_frag(const float* lds, int base, int r, int q) {
+  if constexpr (!T) {
+    return *reinterpret_cast<const float4*>(lds + (base + r) * LDK + 4 * q);
+  } else {
+    constexpr int LDM = TileGeom<BMN, T>::LDM;
+    const float* p = lds + (4 * q) * LDM + base + r;
+    return make_float4(p[0], p[LDM], p[2 * LDM], p[3 * LDM]);
+  }
+}
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bool vecB) {
+  constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
+  constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 fragments per wave
+  using GA = TileGeom<BM, TA>;
+  using GB = TileGeom<BN, TB>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (GA::FLOATS + GB::FLOATS)];
+  constexpr int STAGE = GA::FLOATS + GB::FLOATS;   // A image then B image, two stages
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int bz = blockIdx.z / g.splitk;
+  const int kz = blockIdx.z - bz * g.splitk;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  int kchunk = (g.K + g.splitk - 1) / g.splitk;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  const int kbeg = kz * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+
+  Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
+  Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[GA::NV], rb[GB::NV];
+  if (kbeg < kend) {
+    load_tile<BM, TA>(opA, m0, kbeg, kend, tid, ra);
+    load_tile<BN, TB>(opB, n0, kbeg, kend, tid, rb);
+    store_tile<BM, TA>(lds, tid, ra);
+    store_tile<BN, TB>(lds + GA::FLOATS, tid, rb);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) {
+      load_tile<BM, TA>(opA, m0, k0 + BK, kend, tid, ra);
+      load_tile<BN, TB>(opB, n0, k0 + BK, kend, tid, rb);
+    }
+    const float* curA = lds + buf * STAGE;
+    const float* curB = curA + GA::FLOATS;
+    float4 fa[TM], fb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = read_frag<BM, TA>(curA, wm * WM + i * 16, r, q);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = read_frag<BN, TB>(curB, wn * WN + j * 16, r, q);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+      }
+    if (more) {
+      float* nxt = lds + (buf ^ 1) * STAGE;
+      store_tile<BM, TA>(nxt, tid, ra);
+      store_tile<BN, TB>(nxt + GA::FLOATS, tid, rb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // Epilogue.  D fragment: column = lane & 15, row = 4 * (lane >> 4) + reg.
+  float* C = g.C + (int64_t)bz * g.sc;
+  const float* b1 = g.bias1 ? g.bias1 + (int64_t)bz * g.sbias : nullptr;
+  const float* b2 = g.bias2 ? g.bias2 + (int64_t)bz * g.sbias : nullptr;
+  const bool lead = (kz == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = m0 + wm * WM + i * 16 + 4 * q + e;
+      if (m >= g.M) continue;
+      const int64_t rowoff = rm_off(g.mc, m);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + r;
+        if (n >= g.N) continue;
+        float v = g.alpha * acc[i][j][e];
+        if (lead) {
+          if (b1) v += b1[n];
+          if (b2) v += b2[n];
+        }
+        if (g.splitk > 1) {
+          atomicAdd(C + rowoff + n, v);
+        } else {
+          if (g.act == 1) v = tanhf(v);
+          if (g.beta != 0.f) v += g.beta * C[rowoff + n];
+          C[rowoff + n] = v;
+        }
+      }
+    }
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool map_vec_ok(const RowMap& m) {
+  return m.inner ? (m.so % 4 == 0 && m.si % 4 == 0) : (m.ld % 4 == 0);
+}
+
+template <int BM, int BN>
+int launch_tiles(const GemmDesc& g, bool vecA, bool vecB, hipStream_t st) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * g.splitk);
+  dim3 block(256);
+  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g, vecA, vecB);
+  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g, vecA, vecB);
+  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g, vecA, vecB);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, g, vecA, vecB);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+}  // namespace
+
+int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
+  GemmDesc g = gin;
+  if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return SSASR_OK;
+  if (g.K < 0 || !g.A || !g.B || !g.C) return SSASR_EARG;
+  if (g.splitk < 1) g.splitk = 1;
+  if (g.splitk > 1 && g.act != 0) return SSASR_EARG;
+  if (g.batch * g.splitk > 65535) return SSASR_EARG;
+  const bool vecA = aligned16(g.A) && map_vec_ok(g.ma) && (g.sa % 4 == 0);
+  const bool vecB = aligned16(g.B) && map_vec_ok(g.mb) && (g.sb % 4 == 0);
+  // 128x128 tiles only when they still give every CU work.
+  const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
+  if (big >= 256) return launch_tiles<128, 128>(g, vecA, vecB, st);
+  return launch_tiles<64, 64>(g, vecA, vecB, st);
+}
+
+// C-ABI entry (include/ssasr.h).
+extern "C" int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
+                              const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+                              float* C, int64_t ldc, const float* bias, int act, int64_t batch,
+                              int64_t strideA, int64_t strideB, int64_t strideC, int splitk,
+                              void* stream) {
+  GemmDesc g{};
+  g.A = A; g.B = B; g.C = C;
+  g.ma = rm_dense(lda); g.mb = rm_dense(ldb); g.mc = rm_dense(ldc);
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.ta = ta; g.tb = tb;
+  g.bias1 = bias; g.bias2 = nullptr; g.act = act;
+  g.alpha = alpha; g.beta = beta; g.splitk = splitk;
+  g.batch = (int)batch; g.sa = strideA; g.sb = strideB; g.sc = strideC; g.sbias = 0;
+  return ssasr_launch_gemm(g, (hipStream_t)stream);
+}

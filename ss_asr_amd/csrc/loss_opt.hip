@@ -1,0 +1,203 @@
+// Masked cross entropy (src/trainer.py:426-434), Solver.step = grad-norm clip +
+// NaN guard + Adadelta (src/trainer.py:131-148, :401-403), and the frame-length
+// recovery of prepare_x (src/ASRDataset.py:314).  All HBM-bound streaming work.
+#include "../../include/ssasr.h"
+#include "common.h"
+
+namespace {
+
+// One workgroup per utterance, one wave per (b, t) row of V logits.
+// lse[b*U+t] = logsumexp(row); tail[b] = sum_t tok(b,t) / denom[b].
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const int32_t* labels,
+                                                     const float* denom, int U, int V, float* lse,
+                                                     float* tail) {
+  __shared__ float sm[4];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float tok = 0.f;
+  for (int t = wave; t < U; t += 4) {
+    const float* row = logits + ((int64_t)b * U + t) * V;
+    float m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, row[v]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(row[v] - m);
+    s = wave_sum(s);
+    const float l = m + logf(s);
+    const int lab = labels[(int64_t)b * U + t];
+    if (lane == 0) {
+      lse[(int64_t)b * U + t] = l;
+      if (lab != 0) tok += l - row[lab];
+    }
+  }
+  if (lane == 0) sm[wave] = tok;
+  __syncthreads();
+  if (threadIdx.x == 0) tail[b] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / denom[b];
+}
+
+__global__ void ce_mean_kernel(const float* tail, int B, float* loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += tail[b];
+    *loss = s / (float)B;
+  }
+}
+
+__global__ void ce_bwd_kernel(const float* logits, const int32_t* labels, const float* denom,
+                              const float* lse, const float* dloss, int B, int U, int V,
+                              float* dlogits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)B * U * V;
+  if (i >= n) return;
+  const int64_t row = i / V;
+  const int v = (int)(i - row * V);
+  const int b = (int)(row / U);
+  const int lab = labels[row];
+  float g = 0.f;
+  if (lab != 0) {
+    const float p = expf(logits[i] - lse[row]);
+    g = (p - (v == lab ? 1.f : 0.f)) * (*dloss) / ((float)B * denom[b]);
+  }
+  dlogits[i] = g;
+}
+
+constexpr int NORM_BLOCK = 256;
+constexpr int NORM_PER_BLOCK = NORM_BLOCK * 16;   // floats reduced by one workgroup
+
+__global__ __launch_bounds__(NORM_BLOCK) void sumsq_kernel(const float* g, int64_t n, float* part) {
+  __shared__ double sm[NORM_BLOCK / 64];
+  const int64_t base = (int64_t)blockIdx.x * NORM_PER_BLOCK;
+  float acc = 0.f;
+  const bool vec = ((reinterpret_cast<uintptr_t>(g) & 15) == 0);
+  if (vec && base + NORM_PER_BLOCK <= n) {
+    const float4* p = reinterpret_cast<const float4*>(g + base);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = p[threadIdx.x + i * NORM_BLOCK];
+      acc = fmaf(v.x, v.x, acc);
+      acc = fmaf(v.y, v.y, acc);
+      acc = fmaf(v.z, v.z, acc);
+      acc = fmaf(v.w, v.w, acc);
+    }
+  } else {
+    for (int64_t i = base + threadIdx.x; i < base + NORM_PER_BLOCK && i < n; i += NORM_BLOCK)
+      acc = fmaf(g[i], g[i], acc);
+  }
+  double d = (double)acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (float)(sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// ws[0] <- multiplier applied to every gradient (clip coefficient * grad_scale),
+// stats <- {norm, skipped}
+__global__ __launch_bounds__(256) void clip_coef_kernel(float* ws, int nblk, float grad_scale,
+                                                        float max_norm, float* stats) {
+  __shared__ double sm[4];
+  double d = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) d += (double)ws[1 + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float total = (float)sqrt(sm[0] + sm[1] + sm[2] + sm[3]) * fabsf(grad_scale);
+    const bool bad = isnan(total);
+    float coef = max_norm / (total + 1e-6f);          // torch clip_grad_norm_
+    if (coef > 1.f) coef = 1.f;
+    ws[0] = bad ? 0.f : coef * grad_scale;
+    stats[0] = total;
+    stats[1] = bad ? 1.f : 0.f;
+  }
+}
+
+// torch.optim.Adadelta single-tensor update (weight_decay = 0).
+__global__ __launch_bounds__(256) void adadelta_kernel(float* p, const float* g, float* sq, float* ad,
+                                                       int64_t n, const float* ws, const float* stats,
+                                                       float lr, float rho, float eps) {
+  if (stats[1] != 0.f) return;                        // NaN guard: skip the step
+  const float mul = ws[0];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = i; j < n; j += stride) {
+    const float gr = g[j] * mul;
+    const float s = sq[j] * rho + gr * gr * (1.f - rho);
+    const float a = ad[j];
+    const float delta = sqrtf(a + eps) / sqrtf(s + eps) * gr;
+    sq[j] = s;
+    ad[j] = a * rho + delta * delta * (1.f - rho);
+    p[j] -= lr * delta;
+  }
+}
+
+__global__ __launch_bounds__(256) void frame_len_kernel(const float* x, int T, int F, int32_t* lens) {
+  __shared__ int sm[4];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int cnt = 0;
+  for (int t = wave; t < T; t += 4) {
+    const float* row = x + ((int64_t)b * T + t) * F;
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s += row[f];
+    s = wave_sum(s);
+    cnt += (s != 0.f) ? 1 : 0;
+  }
+  if (lane == 0) sm[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) lens[b] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+}  // namespace
+
+extern "C" int ssasr_ce_loss_fwd(const float* logits, const int32_t* labels, const float* denom,
+                                 int64_t B, int64_t U, int64_t V, float* lse, float* loss,
+                                 void* stream) {
+  if (!logits || !labels || !denom || !lse || !loss || B <= 0 || U <= 0 || V <= 0) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  // lse holds B*U values followed by B per-utterance partial losses.
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, st, logits, labels, denom, (int)U, (int)V,
+                     lse, lse + B * U);
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, st, lse + B * U, (int)B, loss);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_ce_loss_bwd(const float* logits, const int32_t* labels, const float* denom,
+                                 const float* lse, const float* dloss, int64_t B, int64_t U,
+                                 int64_t V, float* dlogits, void* stream) {
+  if (!logits || !labels || !denom || !lse || !dloss || !dlogits || B <= 0 || U <= 0 || V <= 0) return SSASR_EARG;
+  const int64_t n = B * U * V;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                     labels, denom, lse, dloss, (int)B, (int)U, (int)V, dlogits);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int64_t ssasr_clip_adadelta_ws(int64_t n) {
+  return 1 + (n + NORM_PER_BLOCK - 1) / NORM_PER_BLOCK;
+}
+
+extern "C" int ssasr_clip_adadelta(float* param, const float* grad, float* square_avg,
+                                   float* acc_delta, int64_t n, float grad_scale, float max_norm,
+                                   float lr, float rho, float eps, float* ws, float* stats,
+                                   void* stream) {
+  if (!param || !grad || !square_avg || !acc_delta || !ws || !stats || n <= 0) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)((n + NORM_PER_BLOCK - 1) / NORM_PER_BLOCK);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(NORM_BLOCK), 0, st, grad, n, ws + 1);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, ws, nblk, grad_scale, max_norm, stats);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adadelta_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, square_avg, acc_delta,
+                     n, ws, stats, lr, rho, eps);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_frame_lengths(const float* x, int64_t B, int64_t T, int64_t F, int32_t* lens,
+                                   void* stream) {
+  if (!x || !lens || B <= 0 || T <= 0 || F <= 0) return SSASR_EARG;
+  hipLaunchKernelGGL(frame_len_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, (int)T, (int)F, lens);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}

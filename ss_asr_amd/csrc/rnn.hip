@@ -1,0 +1,240 @@
+// Host entry points for the BiLSTM layers and the single LSTM cell step.
+// Kernels: rnn_kernels.h.
+#include "rnn_kernels.h"
+
+int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(32, 8);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, src, dst, rows, cols);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st) {
+  int64_t gy64 = (rows + 255) / 256;
+  int gy = gy64 > 64 ? 64 : (int)gy64;
+  if (gy < 1) gy = 1;
+  dim3 grid((cols + 63) / 64, gy), block(256);
+  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, m, rows, cols, ld, out);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C-ABI: bidirectional LSTM layer over a logical time-major [S, N, I] input.
+// ---------------------------------------------------------------------------
+extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N,
+                                int64_t I, int64_t H, const int32_t* lens,
+                                const float* w_ih_f, const float* w_hh_f, const float* b_ih_f,
+                                const float* b_hh_f, const float* w_ih_r, const float* w_hh_r,
+                                const float* b_ih_r, const float* b_hh_r, float* y, int64_t ys_s,
+                                int64_t ys_n, float* gates, float* cs, float* hs, void* stream) {
+  if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
+  if (!x || !y || !gates || !cs || !hs) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = S * N;
+  const float* wih[2] = {w_ih_f, w_ih_r};
+  const float* whh[2] = {w_hh_f, w_hh_r};
+  const float* bih[2] = {b_ih_f, b_ih_r};
+  const float* bhh[2] = {b_hh_f, b_hh_r};
+
+  // (1) input->hidden for every time step: gates[d] = X . W_ih[d]^T + b_ih + b_hh
+  for (int d = 0; d < 2; ++d) {
+    GemmDesc g{};
+    g.A = x; g.ma = RowMap{0, N, xs_s, xs_n};
+    g.B = wih[d]; g.mb = rm_dense(I);
+    g.C = gates + d * rows * 4 * H; g.mc = rm_dense(4 * H);
+    g.M = (int)rows; g.N = (int)(4 * H); g.K = (int)I;
+    g.ta = 0; g.tb = 0; g.bias1 = bih[d]; g.bias2 = bhh[d];
+    g.alpha = 1.f; g.beta = 0.f; g.splitk = 1; g.batch = 1;
+    int rc = ssasr_launch_gemm(g, st);
+    if (rc) return rc;
+  }
+
+  // (2) the recurrence, one launch per step, both directions per launch
+  dim3 grid((unsigned)(H / 4), 2, (unsigned)((N + 31) / 32)), block(256);
+  for (int64_t i = 0; i < S; ++i) {
+    CellFwdPair pr;
+    CellFwd* a = pr.d;
+    for (int d = 0; d < 2; ++d) {
+      const int64_t s = d ? S - 1 - i : i;
+      const int64_t sp = d ? s + 1 : s - 1;
+      CellFwd& c = a[d];
+      c = CellFwd{};
+      float* gd = gates + (d * rows + s * N) * 4 * H;
+      float* cd = cs + d * rows * H;
+      float* hd = hs + d * rows * H;
+      c.sl.nseg = 0;
+      if (i > 0) {
+        c.sl.nseg = 1;
+        seg_set(c.sl, 0, hd + sp * N * H, H, whh[d], H, (int)H);
+        c.c_prev = cd + sp * N * H;
+      }
+      c.pre = gd; c.gates = gd;
+      c.c_out = cd + s * N * H;
+      c.h_out = hd + s * N * H;
+      c.y = y + s * ys_s + d * H; c.ys_n = ys_n;
+      c.lens = lens; c.s = (int)s; c.N = (int)N; c.H = (int)H;
+    }
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, grid, block, 0, st, pr);
+  }
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+// Backward of the layer.  `gates` is consumed: on return it holds the gate
+// pre-activation derivatives.  dw_* / db_* are overwritten.
+extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
+                                int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
+                                int64_t H, const int32_t* lens, const float* w_ih_f,
+                                const float* w_hh_f, const float* w_ih_r, const float* w_hh_r,
+                                float* gates, const float* cs, const float* hs, float* dx,
+                                int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f,
+                                float* db_f, float* dw_ih_r, float* dw_hh_r, float* db_r,
+                                float* ws_whhT /* [2][H][4H] */, float* ws_dc /* [2][2][N][H] */,
+                                void* stream) {
+  if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
+  if (!dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = S * N;
+  const float* wih[2] = {w_ih_f, w_ih_r};
+  const float* whh[2] = {w_hh_f, w_hh_r};
+  float* dwih[2] = {dw_ih_f, dw_ih_r};
+  float* dwhh[2] = {dw_hh_f, dw_hh_r};
+  float* db[2] = {db_f, db_r};
+  int rc;
+
+  for (int d = 0; d < 2; ++d) {
+    rc = ssasr_launch_transpose(whh[d], ws_whhT + d * 4 * H * H, (int)(4 * H), (int)H, st);
+    if (rc) return rc;
+  }
+
+  // BPTT: one launch per step, both directions per launch.
+  dim3 grid((unsigned)(H / 16), 2, (unsigned)((N + 31) / 32)), block(256);
+  for (int64_t i = 0; i < S; ++i) {
+    CellBwdPair pr;
+    CellBwd* a = pr.d;
+    for (int d = 0; d < 2; ++d) {
+      const int64_t s = d ? i : S - 1 - i;        // reverse of the forward order
+      const int64_t sn = d ? s - 1 : s + 1;       // step handled by the previous launch
+      const int64_t sp = d ? s + 1 : s - 1;       // forward-order predecessor
+      const bool has_prev = d ? (s < S - 1) : (s > 0);
+      CellBwd& c = a[d];
+      c = CellBwd{};
+      float* gd = gates + d * rows * 4 * H;
+      const float* cd = cs + d * rows * H;
+      float* dcb = ws_dc + d * 2 * N * H;
+      c.sl.nseg = 0;
+      if (i > 0) {
+        c.sl.nseg = 1;
+        seg_set(c.sl, 0, gd + sn * N * 4 * H, 4 * H, ws_whhT + d * 4 * H * H, 4 * H, (int)(4 * H));
+        c.dc_in = dcb + (i & 1) * N * H;
+      }
+      c.add1 = dy + s * ys_s + d * H; c.ld1 = ys_n;
+      c.gates = gd + s * N * 4 * H; c.dgates = gd + s * N * 4 * H;
+      c.c_prev = has_prev ? cd + sp * N * H : nullptr;
+      c.c = cd + s * N * H;
+      c.dc_out = dcb + ((i + 1) & 1) * N * H;
+      c.lens = lens; c.s = (int)s; c.N = (int)N; c.H = (int)H;
+    }
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, grid, block, 0, st, pr);
+  }
+  SSASR_LAUNCH_CHECK();
+
+  // Dense contractions over all time steps.
+  for (int d = 0; d < 2; ++d) {
+    const float* dG = gates + d * rows * 4 * H;
+    if (dx) {   // dx += dG . W_ih
+      GemmDesc g{};
+      g.A = dG; g.ma = rm_dense(4 * H);
+      g.B = wih[d]; g.mb = rm_dense(I);
+      g.C = dx; g.mc = RowMap{0, N, dxs_s, dxs_n};
+      g.M = (int)rows; g.N = (int)I; g.K = (int)(4 * H);
+      g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = d ? 1.f : 0.f; g.splitk = 1; g.batch = 1;
+      rc = ssasr_launch_gemm(g, st);
+      if (rc) return rc;
+    }
+    {           // dW_ih = dG^T . X
+      SSASR_HIP(hipMemsetAsync(dwih[d], 0, sizeof(float) * 4 * H * I, st));
+      GemmDesc g{};
+      g.A = dG; g.ma = rm_dense(4 * H);
+      g.B = x; g.mb = RowMap{0, N, xs_s, xs_n};
+      g.C = dwih[d]; g.mc = rm_dense(I);
+      g.M = (int)(4 * H); g.N = (int)I; g.K = (int)rows;
+      g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 0.f; g.batch = 1;
+      const int64_t tiles = ((4 * H + 63) / 64) * ((I + 63) / 64);
+      int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
+      if (rows < 64 * sk) sk = 1;
+      g.splitk = sk;
+      rc = ssasr_launch_gemm(g, st);
+      if (rc) return rc;
+    }
+    {           // dW_hh = sum_s dG[s]^T . h[s_prev]
+      SSASR_HIP(hipMemsetAsync(dwhh[d], 0, sizeof(float) * 4 * H * H, st));
+      if (S > 1) {
+        GemmDesc g{};
+        g.A = d ? dG : dG + N * 4 * H; g.ma = rm_dense(4 * H);
+        g.B = d ? hs + d * rows * H + N * H : hs; g.mb = rm_dense(H);
+        g.C = dwhh[d]; g.mc = rm_dense(H);
+        g.M = (int)(4 * H); g.N = (int)H; g.K = (int)((S - 1) * N);
+        g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 0.f; g.batch = 1;
+        const int64_t tiles = ((4 * H + 63) / 64) * ((H + 63) / 64);
+        int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
+        if ((S - 1) * N < 64 * sk) sk = 1;
+        g.splitk = sk;
+        rc = ssasr_launch_gemm(g, st);
+        if (rc) return rc;
+      }
+    }
+    SSASR_HIP(hipMemsetAsync(db[d], 0, sizeof(float) * 4 * H, st));
+    rc = ssasr_launch_colsum(dG, rows, (int)(4 * H), 4 * H, db[d], st);
+    if (rc) return rc;
+  }
+  return SSASR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C-ABI: single LSTMCell step (nn.LSTMCell, src/asr.py:277-283, :320-324).
+// The input may be given as up to two column blocks (x1 | x2) so that callers
+// need not materialise torch.cat([last_char, context]) (src/asr.py:85).
+// ---------------------------------------------------------------------------
+extern "C" int ssasr_lstm_cell_fwd(const float* x1, int64_t ldx1, int64_t k1, const float* x2,
+                                   int64_t ldx2, int64_t k2, const float* h_prev,
+                                   const float* c_prev, const float* w_ih, const float* w_hh,
+                                   const float* b_ih, const float* b_hh, int64_t N, int64_t H,
+                                   float* gates, float* h_out, float* c_out, void* stream) {
+  if (N <= 0 || H <= 0 || H % 16 != 0 || !x1 || k1 <= 0 || !w_ih || !w_hh || !gates || !h_out || !c_out)
+    return SSASR_EARG;
+  CellFwdPair pr{};
+  CellFwd& c = pr.d[0];
+  const int64_t I = k1 + (x2 ? k2 : 0);
+  int ns = 0;
+  seg_set(c.sl, ns++, x1, ldx1, w_ih, I, (int)k1);
+  if (x2) seg_set(c.sl, ns++, x2, ldx2, w_ih + k1, I, (int)k2);
+  if (h_prev) seg_set(c.sl, ns++, h_prev, H, w_hh, H, (int)H);
+  c.sl.nseg = ns;
+  c.b1 = b_ih; c.b2 = b_hh; c.gates = gates; c.c_prev = c_prev; c.c_out = c_out; c.h_out = h_out;
+  c.N = (int)N; c.H = (int)H;
+  dim3 grid((unsigned)(H / 4), 1, (unsigned)((N + 31) / 32)), block(256);
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, grid, block, 0, (hipStream_t)stream, pr);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+// Gate derivatives of one cell step from the derivative of its outputs.
+// dgates[N,4H] is written; dc_prev[N,H] is written.  The products with the
+// weights (dx, dh_prev, dW) are left to GEMM calls by the caller.
+extern "C" int ssasr_lstm_cell_bwd(const float* dh, const float* dc, const float* gates,
+                                   const float* c_prev, const float* c, int64_t N, int64_t H,
+                                   float* dgates, float* dc_prev, void* stream) {
+  if (N <= 0 || H <= 0 || H % 16 != 0 || !dh || !gates || !c || !dgates || !dc_prev) return SSASR_EARG;
+  CellBwdPair pr{};
+  CellBwd& b = pr.d[0];
+  b.sl.nseg = 0;
+  b.add1 = dh; b.ld1 = H; b.dc_in = dc; b.gates = gates; b.c_prev = c_prev; b.c = c;
+  b.dgates = dgates; b.dc_out = dc_prev; b.N = (int)N; b.H = (int)H;
+  dim3 grid((unsigned)(H / 16), 1, (unsigned)((N + 31) / 32)), block(256);
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, grid, block, 0, (hipStream_t)stream, pr);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+

@@ -1,0 +1,407 @@
+"""torch.autograd bindings of the HIP kernels (C ABI: include/ssasr.h).
+
+Every function here runs on a CUDA(=HIP) device tensor through
+libssasr_hip.so.  There is no CPU implementation: calling these with CPU
+tensors, or without the shared object, raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('ss_asr_amd ops need tensors on the GPU (no CPU path); got %s'
+                               % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError('expected float32, got %s' % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------
+# plain GEMM (no autograd): C = act(alpha * op(A) op(B) + bias) + beta * C
+# ---------------------------------------------------------------------------
+def gemm(a, b, ta=False, tb=False, out=None, bias=None, act=0, alpha=1.0, beta=0.0, splitk=1):
+    """2-D or batched 3-D fp32 GEMM on the MFMA kernel.  ``tb=False`` means b is
+    stored [N, K] (the torch Linear weight layout)."""
+    lib = _lib.load()
+    _need_gpu(a, b)
+    a, b = _f32c(a), _f32c(b)
+    batched = a.dim() == 3
+    am, bm = (a[0], b[0]) if batched else (a, b)
+    M, K = (am.shape[1], am.shape[0]) if ta else (am.shape[0], am.shape[1])
+    N = bm.shape[1] if tb else bm.shape[0]
+    kb = bm.shape[0] if tb else bm.shape[1]
+    if kb != K:
+        raise ValueError('gemm: inner dimensions differ (%d vs %d)' % (K, kb))
+    batch = a.shape[0] if batched else 1
+    if out is None:
+        shape = (batch, M, N) if batched else (M, N)
+        out = (torch.zeros if splitk > 1 else torch.empty)(shape, device=a.device,
+                                                           dtype=torch.float32)
+    check(lib.ssasr_gemm_f32(int(ta), int(tb), M, N, K, alpha, _p(a), am.stride(0), _p(b),
+                             bm.stride(0), beta, _p(out), out.stride(-2), _p(bias), act, batch,
+                             a.stride(0) if batched else 0, b.stride(0) if batched else 0,
+                             out.stride(0) if batched else 0, splitk, _stream()), 'ssasr_gemm_f32')
+    return out
+
+
+# ---------------------------------------------------------------------------
+# bidirectional LSTM layer (packed semantics)
+# ---------------------------------------------------------------------------
+class _BiLSTM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lens, steps, batch_first, *w):
+        lib = _lib.load()
+        _need_gpu(x, *w)
+        x = _f32c(x)
+        w = [_f32c(t) for t in w]
+        H = w[1].shape[1]
+        I = x.shape[2]
+        if batch_first:
+            N, S = x.shape[0], int(steps)
+            xs_s, xs_n = I, x.shape[1] * I
+            y = torch.empty(N, S, 2 * H, device=x.device, dtype=torch.float32)
+            ys_s, ys_n = 2 * H, S * 2 * H
+        else:
+            S, N = x.shape[0], x.shape[1]
+            xs_s, xs_n = N * I, I
+            y = torch.empty(S, N, 2 * H, device=x.device, dtype=torch.float32)
+            ys_s, ys_n = N * 2 * H, 2 * H
+        gates = torch.empty(2, S * N, 4 * H, device=x.device, dtype=torch.float32)
+        cs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
+        hs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
+        check(lib.ssasr_bilstm_fwd(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
+                                   _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _stream()),
+              'ssasr_bilstm_fwd')
+        ctx.save_for_backward(x, lens, gates, cs, hs, *w)
+        ctx.geom = (S, N, I, H, xs_s, xs_n, ys_s, ys_n, bool(batch_first))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, lens, gates, cs, hs, *w = ctx.saved_tensors
+        S, N, I, H, xs_s, xs_n, ys_s, ys_n, batch_first = ctx.geom
+        dy = _f32c(dy)
+        dev = x.device
+        need_dx = ctx.needs_input_grad[0]
+        dx = None
+        if need_dx:
+            # frames past `steps` of a batch-first input get no gradient
+            full = (not batch_first) or x.shape[1] == S
+            dx = (torch.empty_like if full else torch.zeros_like)(x)
+        dw = [torch.empty_like(w[0]), torch.empty_like(w[1]), torch.empty(4 * H, device=dev),
+              torch.empty_like(w[4]), torch.empty_like(w[5]), torch.empty(4 * H, device=dev)]
+        ws_t = torch.empty(2, H, 4 * H, device=dev)
+        ws_dc = torch.empty(2, 2, N, H, device=dev)
+        check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
+                                   _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
+                                   _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
+                                   _p(ws_dc), _stream()), 'ssasr_bilstm_bwd')
+        # inputs: x, lens, steps, batch_first, then w_ih,w_hh,b_ih,b_hh per direction
+        return (dx, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
+                dw[3], dw[4], dw[5], dw[5].clone())
+
+
+def bilstm(x, lens, steps, batch_first, weights):
+    """weights = (w_ih, w_hh, b_ih, b_hh) forward then the same four reverse.
+    batch_first: x [N, T, I], the first ``steps`` frames are processed and the
+    result is [N, steps, 2H]; otherwise x is [S, N, I] -> [S, N, 2H].
+    lens: int32 device tensor [N] or None."""
+    return _BiLSTM.apply(x, lens, steps, batch_first, *weights)
+
+
+# ---------------------------------------------------------------------------
+# attention: cached projection, single step
+# ---------------------------------------------------------------------------
+class _AttnPrecompute(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, w_psi, b_psi):
+        lib = _lib.load()
+        _need_gpu(feat, w_psi, b_psi)
+        feat, w_psi, b_psi = _f32c(feat), _f32c(w_psi), _f32c(b_psi)
+        B, T, E = feat.shape
+        A = w_psi.shape[0]
+        comp = torch.empty(B, T, A, device=feat.device, dtype=torch.float32)
+        check(lib.ssasr_attn_precompute_fwd(_p(feat), _p(w_psi), _p(b_psi), B * T, E, A, _p(comp),
+                                            _stream()), 'ssasr_attn_precompute_fwd')
+        ctx.save_for_backward(feat, w_psi, comp)
+        return comp
+
+    @staticmethod
+    def backward(ctx, dcomp):
+        lib = _lib.load()
+        feat, w_psi, comp = ctx.saved_tensors
+        B, T, E = feat.shape
+        A = w_psi.shape[0]
+        dpre = dcomp.contiguous().clone()
+        dfeat = torch.zeros_like(feat)
+        dw = torch.empty_like(w_psi)
+        db = torch.empty(A, device=feat.device, dtype=torch.float32)
+        check(lib.ssasr_attn_precompute_bwd(_p(dpre), _p(comp), _p(feat), _p(w_psi), B * T, E, A,
+                                            _p(dfeat), _p(dw), _p(db), _stream()),
+              'ssasr_attn_precompute_bwd')
+        return dfeat, dw, db
+
+
+def attn_precompute(feat, w_psi, b_psi):
+    """tanh(psi(feat)), src/asr.py:381."""
+    return _AttnPrecompute.apply(feat, w_psi, b_psi)
+
+
+class _AttnStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, w_phi, comp, feat, enc_len):
+        lib = _lib.load()
+        _need_gpu(state, w_phi, comp, feat, enc_len)
+        state, w_phi, comp, feat = _f32c(state), _f32c(w_phi), _f32c(comp), _f32c(feat)
+        B, T, E = feat.shape
+        A, D = w_phi.shape
+        w_phi_t = w_phi.t().contiguous()
+        q = torch.empty(B, A, device=feat.device)
+        att = torch.empty(B, T, device=feat.device)
+        cx = torch.empty(B, E, device=feat.device)
+        check(lib.ssasr_attn_step_fwd(_p(state), _p(w_phi_t), _p(comp), _p(feat), _p(enc_len), B, T,
+                                      A, E, D, _p(q), _p(att), _p(cx), _stream()),
+              'ssasr_attn_step_fwd')
+        ctx.save_for_backward(state, w_phi, comp, feat, enc_len, q, att)
+        return att, cx
+
+    @staticmethod
+    def backward(ctx, datt, dctx):
+        lib = _lib.load()
+        state, w_phi, comp, feat, enc_len, q, att = ctx.saved_tensors
+        B, T, E = feat.shape
+        A, D = w_phi.shape
+        dctx = _f32c(dctx) if dctx is not None else torch.zeros(B, E, device=feat.device)
+        datt = _f32c(datt) if datt is not None else None
+        de = torch.empty(B, T, device=feat.device)
+        dqpre = torch.empty(B, A, device=feat.device)
+        check(lib.ssasr_attn_step_bwd(_p(dctx), _p(datt), _p(att), _p(q), _p(comp), _p(feat),
+                                      _p(enc_len), B, T, A, E, _p(de), _p(dqpre), _stream()),
+              'ssasr_attn_step_bwd')
+        dstate = gemm(dqpre, w_phi, tb=True)                       # [B,A] . [A,D]
+        dw_phi = gemm(dqpre, state, ta=True, tb=True)              # [A,B] . [B,D]
+        # outer products per utterance: K = 1 batched GEMMs
+        dcomp = gemm(de.unsqueeze(1), q.unsqueeze(1), ta=True, tb=True)        # [B,T,A]
+        dfeat = gemm(att.unsqueeze(1), dctx.unsqueeze(1), ta=True, tb=True)    # [B,T,E]
+        return dstate, dw_phi, dcomp, dfeat, None
+
+
+def attn_step(state, w_phi, comp, feat, enc_len):
+    """One Attention.forward after the cache exists (src/asr.py:383-390)."""
+    return _AttnStep.apply(state, w_phi, comp, feat, enc_len)
+
+
+# ---------------------------------------------------------------------------
+# single LSTM cell step
+# ---------------------------------------------------------------------------
+class _LSTMCell(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h, c, w_ih, w_hh, b_ih, b_hh):
+        lib = _lib.load()
+        _need_gpu(x, h, c, w_ih, w_hh, b_ih, b_hh)
+        x, h, c = _f32c(x), _f32c(h), _f32c(c)
+        w_ih, w_hh, b_ih, b_hh = _f32c(w_ih), _f32c(w_hh), _f32c(b_ih), _f32c(b_hh)
+        N, I = x.shape
+        H = w_hh.shape[1]
+        gates = torch.empty(N, 4 * H, device=x.device)
+        h1 = torch.empty(N, H, device=x.device)
+        c1 = torch.empty(N, H, device=x.device)
+        check(lib.ssasr_lstm_cell_fwd(_p(x), I, I, None, 0, 0, _p(h), _p(c), _p(w_ih), _p(w_hh),
+                                      _p(b_ih), _p(b_hh), N, H, _p(gates), _p(h1), _p(c1),
+                                      _stream()), 'ssasr_lstm_cell_fwd')
+        ctx.save_for_backward(x, h, c, w_ih, w_hh, gates, c1)
+        return h1, c1
+
+    @staticmethod
+    def backward(ctx, dh1, dc1):
+        lib = _lib.load()
+        x, h, c, w_ih, w_hh, gates, c1 = ctx.saved_tensors
+        N, H = h.shape
+        dh1 = _f32c(dh1) if dh1 is not None else torch.zeros_like(h)
+        dc1 = _f32c(dc1) if dc1 is not None else None
+        dg = torch.empty_like(gates)
+        dc = torch.empty_like(c)
+        check(lib.ssasr_lstm_cell_bwd(_p(dh1), _p(dc1), _p(gates), _p(c), _p(c1), N, H, _p(dg),
+                                      _p(dc), _stream()), 'ssasr_lstm_cell_bwd')
+        dx = gemm(dg, w_ih, tb=True)
+        dh = gemm(dg, w_hh, tb=True)
+        dw_ih = gemm(dg, x, ta=True, tb=True)
+        dw_hh = gemm(dg, h, ta=True, tb=True)
+        db = dg.sum(0)
+        return dx, dh, dc, dw_ih, dw_hh, db, db.clone()
+
+
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """nn.LSTMCell step (src/asr.py:320-324) -> (h', c')."""
+    return _LSTMCell.apply(x, h, c, w_ih, w_hh, b_ih, b_hh)
+
+
+# ---------------------------------------------------------------------------
+# fused decode loop
+# ---------------------------------------------------------------------------
+_DEC_PARAMS = ('w_phi', 'w_ih1', 'w_hh1', 'b_ih1', 'b_hh1', 'w_ih2', 'w_hh2', 'b_ih2', 'b_hh2',
+               'embed', 'w_ct', 'b_ct')
+
+
+class _DecoderLoop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, comp, enc_len, teacher, step_mode, uniforms, *params):
+        lib = _lib.load()
+        _need_gpu(feat, comp, enc_len, *params)
+        feat, comp = _f32c(feat), _f32c(comp)
+        params = [_f32c(t) for t in params]
+        pw = dict(zip(_DEC_PARAMS, params))
+        dev = feat.device
+        B, T, E = feat.shape
+        A, D = pw['w_phi'].shape
+        V = pw['w_ct'].shape[0]
+        U = len(step_mode)
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        bufs = dict(logits=f(B, U, V), att=f(B, U, T), w_phi_t=f(D, A), q=f(U, B, A),
+                    ctx=f(U, B, E), emb_in=f(U + 1, B, D),
+                    chars=torch.empty(U + 1, B, device=dev, dtype=torch.int32),
+                    gates1=f(U, B, 4 * D), c1=f(U, B, D), h1=f(U, B, D),
+                    gates2=f(U, B, 4 * D), c2=f(U, B, D), h2=f(U, B, D))
+        modes = (C.c_int32 * U)(*[int(m) for m in step_mode])
+        d = _lib.Decoder()
+        d.B, d.T, d.E, d.A, d.D, d.V, d.U = B, T, E, A, D, V, U
+        d.feat, d.comp, d.enc_len = feat.data_ptr(), comp.data_ptr(), enc_len.data_ptr()
+        if teacher is not None:
+            teacher = teacher.contiguous()
+            d.teacher, d.teacher_ld = teacher.data_ptr(), teacher.stride(0)
+        d.step_mode = C.cast(modes, C.c_void_p)
+        if uniforms is not None:
+            d.uniforms = uniforms.data_ptr()
+        for k, t in pw.items():
+            setattr(d, k, t.data_ptr())
+        for k, t in bufs.items():
+            setattr(d, k, t.data_ptr())
+        check(lib.ssasr_decoder_fwd(C.byref(d), _stream()), 'ssasr_decoder_fwd')
+        ctx.dec = d
+        ctx.keep = (feat, comp, enc_len, teacher, modes, uniforms, params, bufs)
+        ctx.mark_non_differentiable(bufs['att'])
+        return bufs['logits'], bufs['att'], bufs['chars']
+
+    @staticmethod
+    def backward(ctx, dlogits, _datt, _dchars):
+        lib = _lib.load()
+        d = ctx.dec
+        feat, comp, enc_len, teacher, modes, uniforms, params, bufs = ctx.keep
+        pw = dict(zip(_DEC_PARAMS, params))
+        dev = feat.device
+        B, T, E, A, D, V, U = d.B, d.T, d.E, d.A, d.D, d.V, d.U
+        dlogits = _f32c(dlogits)
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        out = dict(dfeat=f(B, T, E), dcomp=f(B, T, A), dw_phi=f(A, D), dw_ih1=f(4 * D, D + E),
+                   dw_hh1=f(4 * D, D), db1=f(4 * D), dw_ih2=f(4 * D, D), dw_hh2=f(4 * D, D),
+                   db2=f(4 * D), dembed=f(V, D), dw_ct=f(V, D), db_ct=f(V))
+        ws = dict(ws_t_ih1=f(D + E, 4 * D), ws_t_hh1=f(D, 4 * D), ws_t_ih2=f(D, 4 * D),
+                  ws_t_hh2=f(D, 4 * D), ws_dh2=f(U, B, D), ws_dctx=f(U, B, E),
+                  ws_de=f(B, U, T), ws_dqpre=f(U, B, A), ws_dc=f(2, 2, B, D),
+                  ws_demb=f(U, B, D))
+        g = _lib.DecoderGrads()
+        g.dlogits = dlogits.data_ptr()
+        for k, t in list(out.items()) + list(ws.items()):
+            setattr(g, k, t.data_ptr())
+        check(lib.ssasr_decoder_bwd(C.byref(d), C.byref(g), _stream()), 'ssasr_decoder_bwd')
+        o = out
+        return (o['dfeat'], o['dcomp'], None, None, None, None,
+                o['dw_phi'], o['dw_ih1'], o['dw_hh1'], o['db1'], o['db1'].clone(),
+                o['dw_ih2'], o['dw_hh2'], o['db2'], o['db2'].clone(),
+                o['dembed'], o['dw_ct'], o['db_ct'])
+
+
+def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params):
+    """The decode loop of ASR.forward (src/asr.py:67-110).
+
+    step_mode: host sequence of U ints (0 teacher forced, 1 sample, 2 argmax).
+    teacher: int32 [B, L] device tensor of character ids or None.
+    params: dict with the keys of ``_DEC_PARAMS``.
+    Returns (logits [B,U,V], att [B,U,T] (no grad), chars [U+1,B] int32)."""
+    return _DecoderLoop.apply(feat, comp, enc_len, teacher, list(step_mode), uniforms,
+                              *[params[k] for k in _DEC_PARAMS])
+
+
+# ---------------------------------------------------------------------------
+# masked cross entropy
+# ---------------------------------------------------------------------------
+class _CELoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, denom):
+        lib = _lib.load()
+        _need_gpu(logits, labels, denom)
+        logits = _f32c(logits)
+        B, U, V = logits.shape
+        lse = torch.empty(B * U + B, device=logits.device, dtype=torch.float32)
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        check(lib.ssasr_ce_loss_fwd(_p(logits), _p(labels), _p(denom), B, U, V, _p(lse), _p(loss),
+                                    _stream()), 'ssasr_ce_loss_fwd')
+        ctx.save_for_backward(logits, labels, denom, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        logits, labels, denom, lse = ctx.saved_tensors
+        B, U, V = logits.shape
+        dloss = dloss.to(torch.float32).contiguous()
+        dlogits = torch.empty_like(logits)
+        check(lib.ssasr_ce_loss_bwd(_p(logits), _p(labels), _p(denom), _p(lse), _p(dloss), B, U, V,
+                                    _p(dlogits), _stream()), 'ssasr_ce_loss_bwd')
+        return dlogits, None, None
+
+
+def masked_ce_loss(logits, y, ans_len):
+    """src/trainer.py:426-434.  logits [B,U,V] (U >= ans_len), y [B,L] int."""
+    label = y[:, 1:ans_len + 1].to(torch.int32).contiguous()
+    denom = (y != 0).sum(-1).to(torch.float32)
+    if logits.shape[1] != ans_len:
+        logits = logits[:, :ans_len].contiguous()
+    return _CELoss.apply(logits, label, denom)
+
+
+# ---------------------------------------------------------------------------
+# misc
+# ---------------------------------------------------------------------------
+def frame_lengths(x):
+    """prepare_x length recovery on the device (src/ASRDataset.py:314) -> int32 [B]."""
+    lib = _lib.load()
+    _need_gpu(x)
+    x = _f32c(x)
+    B, T, F = x.shape
+    lens = torch.empty(B, device=x.device, dtype=torch.int32)
+    check(lib.ssasr_frame_lengths(_p(x), B, T, F, _p(lens), _stream()), 'ssasr_frame_lengths')
+    return lens
+
+
+def clip_adadelta_(param, grad, square_avg, acc_delta, ws, stats, grad_scale=1.0, max_norm=5.0,
+                   lr=1.0, rho=0.9, eps=1e-8):
+    """Solver.step on flat buffers (src/trainer.py:131-148).  stats <- [norm, skipped]."""
+    lib = _lib.load()
+    _need_gpu(param, grad, square_avg, acc_delta, ws, stats)
+    check(lib.ssasr_clip_adadelta(_p(param), _p(grad), _p(square_avg), _p(acc_delta), param.numel(),
+                                  grad_scale, float(max_norm), lr, rho, eps, _p(ws), _p(stats),
+                                  _stream()), 'ssasr_clip_adadelta')
+
+
+def clip_adadelta_ws(n, device):
+    lib = _lib.load()
+    return torch.empty(int(lib.ssasr_clip_adadelta_ws(n)), device=device, dtype=torch.float32)

@@ -1,0 +1,92 @@
+"""Flat parameter/gradient storage and the fused clip + Adadelta step.
+
+Solver.step in the reference (src/trainer.py:131-148) clips the global
+gradient norm over 42 tensors, checks it for NaN on the host, and calls
+torch.optim.Adadelta.step (src/trainer.py:401-403), i.e. ~10 passes over
+41 MB in ~170 small kernels.  Here every parameter is a view into one flat
+buffer, every gradient a view into another, and one C-ABI call
+(ssasr_clip_adadelta) does norm, NaN guard, clip and update in three kernels
+without a host round trip.  The same flat gradient buffer is what the data
+parallel wrapper all-reduces (one RCCL call).
+"""
+import torch
+
+from . import ops
+
+
+class FlatParameters:
+    """Re-homes a module's parameters (and their .grad) into two flat buffers."""
+
+    def __init__(self, module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError('module has no trainable parameters')
+        dev, dt = params[0].device, params[0].dtype
+        # keep every tensor 16-byte aligned inside the buffer
+        offs, total = [], 0
+        for p in params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError('all parameters must share one device and dtype')
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.params = params
+        self.offsets = offs
+        self.numel = total
+        self.data = torch.zeros(total, device=dev, dtype=dt)
+        self.grad = torch.zeros(total, device=dev, dtype=dt)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                n = p.numel()
+                self.data[o:o + n].copy_(p.data.reshape(-1))
+                p.data = self.data[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):     # re-attach if something detached them
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class FusedAdadelta(torch.optim.Optimizer):
+    """torch.optim.Adadelta(lr, rho, eps, weight_decay=0) over FlatParameters,
+    fused with clip_grad_norm_ and the NaN guard of Solver.step."""
+
+    def __init__(self, flat, lr=1.0, rho=0.9, eps=1e-6):
+        self.flat = flat
+        super().__init__(flat.params, dict(lr=lr, rho=rho, eps=eps))
+        dev = flat.data.device
+        self.square_avg = torch.zeros_like(flat.data)
+        self.acc_delta = torch.zeros_like(flat.data)
+        self._ws = ops.clip_adadelta_ws(flat.numel, dev)
+        self.stats = torch.zeros(2, device=dev)          # [grad_norm, skipped]
+        self._host_stats = torch.zeros(2, pin_memory=True)
+        self._pending = None
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def clip_and_step(self, max_norm=5.0, grad_scale=1.0):
+        g = self.param_groups[0]
+        ops.clip_adadelta_(self.flat.data, self.flat.grad, self.square_avg, self.acc_delta,
+                           self._ws, self.stats, grad_scale=grad_scale, max_norm=max_norm,
+                           lr=g['lr'], rho=g['rho'], eps=g['eps'])
+        # the norm / NaN flag reach the host asynchronously; see poll()
+        self._host_stats.copy_(self.stats, non_blocking=True)
+        self._pending = torch.cuda.Event()
+        self._pending.record()
+
+    def step(self, closure=None):
+        """Plain optimizer step (no clipping): max_norm = inf."""
+        self.clip_and_step(max_norm=float('inf'))
+
+    def poll(self, wait=False):
+        """Returns (grad_norm, skipped) of the most recent finished step, or None."""
+        if self._pending is None:
+            return None
+        if wait:
+            self._pending.synchronize()
+        elif not self._pending.query():
+            return None
+        self._pending = None
+        return float(self._host_stats[0]), bool(self._host_stats[1] != 0)

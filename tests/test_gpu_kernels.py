@@ -1,0 +1,262 @@
+"""Kernel-level parity: each C-ABI entry point against the CPU oracle
+(oracle/las_oracle.py, float64 restatement) on seeded inputs.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+import las_oracle as lo
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+def close(got, want, atol, what=''):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    assert err <= atol, '%s: max abs err %.3e > %.1e' % (what, err, atol)
+
+
+# ----------------------------------------------------------------- GEMM ----
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 16), (200, 136, 80), (129, 50, 37), (1024, 256, 300),
+                                   (33, 1024, 1024)])
+def test_gemm_orientations(ta, tb, M, N, K):
+    from ss_asr_amd import ops
+    a = rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)
+    b = rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)
+    want = (a.t() if ta else a) @ (b if tb else b.t())
+    got = ops.gemm(a.float().to(dev()), b.float().to(dev()), ta=bool(ta), tb=bool(tb))
+    close(got, want, 2e-4 * max(1.0, K ** 0.5 / 4), 'gemm %d%d %dx%dx%d' % (ta, tb, M, N, K))
+
+
+def test_gemm_is_exact_fp32_fma_chain():
+    """A = I with an asymmetric B catches a transposed C write; small integers
+    make every product exact."""
+    from ss_asr_amd import ops
+    n = 96
+    a = torch.eye(n)
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 17) - 3.0
+    got = ops.gemm(a.to(dev()), b.to(dev()), tb=True)
+    assert torch.equal(got.cpu(), b)
+    got = ops.gemm(a.to(dev()), b.to(dev()), tb=False)
+    assert torch.equal(got.cpu(), b.t())
+
+
+def test_gemm_bias_tanh_beta_batched_splitk():
+    from ss_asr_amd import ops
+    a, b, bias = rnd(300, 72, seed=3), rnd(40, 72, seed=4), rnd(40, seed=5)
+    got = ops.gemm(a.float().to(dev()), b.float().to(dev()), bias=bias.float().to(dev()), act=1)
+    close(got, torch.tanh(a @ b.t() + bias), 1e-5, 'bias+tanh')
+    c0 = rnd(300, 40, seed=6)
+    out = c0.float().to(dev())
+    ops.gemm(a.float().to(dev()), b.float().to(dev()), out=out, alpha=0.5, beta=2.0)
+    close(out, 0.5 * (a @ b.t()) + 2.0 * c0, 1e-4, 'alpha/beta')
+    ab, bb = rnd(5, 70, 33, seed=7), rnd(5, 20, 33, seed=8)
+    got = ops.gemm(ab.float().to(dev()), bb.float().to(dev()))
+    close(got, ab @ bb.transpose(1, 2), 1e-4, 'batched')
+    a, b = rnd(5000, 48, seed=9), rnd(5000, 24, seed=10)
+    got = ops.gemm(a.float().to(dev()), b.float().to(dev()), ta=True, tb=True, splitk=8)
+    close(got, a.t() @ b, 2e-3, 'split-K')
+
+
+# --------------------------------------------------------------- BiLSTM ----
+def lstm_weights(I, H, seed):
+    w = []
+    for d in range(2):
+        w += [rnd(4 * H, I, seed=seed + 10 * d, scale=I ** -0.5),
+              rnd(4 * H, H, seed=seed + 10 * d + 1, scale=H ** -0.5),
+              rnd(4 * H, seed=seed + 10 * d + 2, scale=0.1),
+              rnd(4 * H, seed=seed + 10 * d + 3, scale=0.1)]
+    return w
+
+
+@pytest.mark.parametrize('N,T,I,H,lens', [
+    (4, 12, 12, 32, [12, 9, 9, 4]),
+    (5, 9, 20, 16, [7, 6, 3, 2, 1]),          # input longer than max(lens)
+    (33, 6, 8, 16, [6] * 20 + [3] * 13),      # more than one 32-column chunk
+    (3, 10, 80, 256, [10, 8, 5]),             # production widths (vector path)
+])
+def test_bilstm_packed_forward_backward(N, T, I, H, lens):
+    from ss_asr_amd import ops
+    x = rnd(N, T, I, seed=11)
+    for i, l in enumerate(lens):
+        x[i, l:] = 0
+    w = lstm_weights(I, H, 20)
+    S = max(lens)
+    # oracle (float64, autograd)
+    xr = x.clone().requires_grad_(True)
+    wr = [t.clone().requires_grad_(True) for t in w]
+    yr = lo.bilstm_explicit(xr[:, :S].transpose(0, 1), lens, wr).transpose(0, 1)
+    gy = rnd(N, S, 2 * H, seed=12)
+    (yr * gy).sum().backward()
+    # HIP
+    xd = x.float().to(dev()).requires_grad_(True)
+    wd = [t.float().to(dev()).requires_grad_(True) for t in w]
+    ld = torch.tensor(lens, dtype=torch.int32, device=dev())
+    yd = ops.bilstm(xd, ld, S, True, wd)
+    close(yd, yr, 2e-5, 'y')
+    (yd * gy.float().to(dev())).sum().backward()
+    close(xd.grad, xr.grad, 5e-5, 'dx')
+    for name, a, b in zip(['w_ih', 'w_hh', 'b_ih', 'b_hh'] * 2, wd, wr):
+        close(a.grad, b.grad, 2e-4, 'd' + name)
+
+
+def test_bilstm_sequence_major_no_lengths():
+    """blstm_4 form: recurrence over dim 0, every column full length."""
+    from ss_asr_amd import ops
+    S, N, I, H = 7, 40, 64, 16
+    x = rnd(S, N, I, seed=13)
+    w = lstm_weights(I, H, 40)
+    xr = x.clone().requires_grad_(True)
+    wr = [t.clone().requires_grad_(True) for t in w]
+    yr = lo.bilstm_explicit(xr, None, wr)
+    gy = rnd(S, N, 2 * H, seed=14)
+    (yr * gy).sum().backward()
+    xd = x.float().to(dev()).requires_grad_(True)
+    wd = [t.float().to(dev()).requires_grad_(True) for t in w]
+    yd = ops.bilstm(xd, None, S, False, wd)
+    close(yd, yr, 2e-5, 'y')
+    (yd * gy.float().to(dev())).sum().backward()
+    close(xd.grad, xr.grad, 5e-5, 'dx')
+    for a, b in zip(wd, wr):
+        close(a.grad, b.grad, 2e-4, 'dw')
+
+
+# ------------------------------------------------------------ attention ----
+@pytest.mark.parametrize('B,T,A,E,D,lens', [
+    (4, 8, 16, 64, 32, [8, 7, 6, 5]),
+    (3, 100, 128, 512, 256, [100, 57, 1]),
+    (2, 375, 128, 512, 256, [375, 200]),
+])
+def test_attention_step_forward_backward(B, T, A, E, D, lens):
+    from ss_asr_amd import ops
+    feat, state = rnd(B, T, E, seed=21), rnd(B, D, seed=22)
+    w_phi = rnd(A, D, seed=23, scale=D ** -0.5)
+    w_psi, b_psi = rnd(A, E, seed=24, scale=E ** -0.5), rnd(A, seed=25, scale=0.1)
+    ga, gc = rnd(B, T, seed=26), rnd(B, E, seed=27)
+    leaves = [t.clone().requires_grad_(True) for t in (feat, state, w_phi, w_psi, b_psi)]
+    f, s, wp, ws, bs = leaves
+    comp = torch.tanh(f @ ws.t() + bs)
+    alpha, ctx = lo.attention_step_explicit(s, f, comp, lens, wp)
+    ((alpha * ga).sum() + (ctx * gc).sum()).backward()
+
+    dl = [t.float().to(dev()).requires_grad_(True) for t in (feat, state, w_phi, w_psi, b_psi)]
+    fd, sd, wpd, wsd, bsd = dl
+    compd = ops.attn_precompute(fd, wsd, bsd)
+    close(compd, comp, 1e-5, 'comp')
+    ld = torch.tensor(lens, dtype=torch.int32, device=dev())
+    ad, cd = ops.attn_step(sd, wpd, compd, fd, ld)
+    close(ad, alpha, 1e-6, 'alpha')
+    close(cd, ctx, 1e-5, 'ctx')
+    ((ad * ga.float().to(dev())).sum() + (cd * gc.float().to(dev())).sum()).backward()
+    for name, a, b in zip(['feat', 'state', 'w_phi', 'w_psi', 'b_psi'], dl, leaves):
+        close(a.grad, b.grad, 1e-4, 'd' + name)
+
+
+def test_attention_first_step_is_uniform_over_valid_frames():
+    """s = 0 and phi has no bias => alpha = 1/len on valid frames."""
+    from ss_asr_amd import ops
+    B, T, A, E, D = 3, 10, 16, 32, 16
+    lens = [10, 6, 3]
+    feat = rnd(B, T, E, seed=31).float().to(dev())
+    comp = torch.tanh(rnd(B, T, A, seed=32)).float().to(dev())
+    w_phi = rnd(A, D, seed=33).float().to(dev())
+    ld = torch.tensor(lens, dtype=torch.int32, device=dev())
+    att, _ = ops.attn_step(torch.zeros(B, D, device=dev()), w_phi, comp, feat, ld)
+    for b, l in enumerate(lens):
+        np.testing.assert_allclose(att[b, :l].cpu().numpy(), 1.0 / l, rtol=1e-6)
+        assert float(att[b, l:].abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------- LSTM cell ----
+@pytest.mark.parametrize('N,I,H', [(4, 96, 32), (32, 768, 256), (37, 50, 16)])
+def test_lstm_cell_forward_backward(N, I, H):
+    from ss_asr_amd import ops
+    t = [rnd(N, I, seed=41), rnd(N, H, seed=42), rnd(N, H, seed=43),
+         rnd(4 * H, I, seed=44, scale=I ** -0.5), rnd(4 * H, H, seed=45, scale=H ** -0.5),
+         rnd(4 * H, seed=46, scale=0.1), rnd(4 * H, seed=47, scale=0.1)]
+    gh, gc = rnd(N, H, seed=48), rnd(N, H, seed=49)
+    r = [v.clone().requires_grad_(True) for v in t]
+    h1, c1 = lo.lstm_cell_explicit(*r)
+    ((h1 * gh).sum() + (c1 * gc).sum()).backward()
+    d = [v.float().to(dev()).requires_grad_(True) for v in t]
+    h1d, c1d = ops.lstm_cell(*d)
+    close(h1d, h1, 1e-5, 'h')
+    close(c1d, c1, 1e-5, 'c')
+    ((h1d * gh.float().to(dev())).sum() + (c1d * gc.float().to(dev())).sum()).backward()
+    for name, a, b in zip(['x', 'h', 'c', 'w_ih', 'w_hh', 'b_ih', 'b_hh'], d, r):
+        close(a.grad, b.grad, 1e-4, 'd' + name)
+
+
+# ----------------------------------------------------------- loss / step ----
+def test_masked_ce_loss_forward_backward():
+    from ss_asr_amd import ops
+    B, U, V = 5, 9, 50
+    logits = rnd(B, U, V, seed=51)
+    y = torch.zeros(B, U + 3, dtype=torch.long)
+    g = torch.Generator().manual_seed(52)
+    for b, l in enumerate([9, 7, 4, 2, 1]):
+        y[b, 1:1 + l] = torch.randint(1, V, (l,), generator=g)
+    lr = logits.clone().requires_grad_(True)
+    want = lo.masked_ce_loss(lr, y, U)
+    want.backward()
+    ld = logits.float().to(dev()).requires_grad_(True)
+    got = ops.masked_ce_loss(ld, y.to(dev()), U)
+    close(got, want, 1e-6, 'loss')
+    got.backward()
+    close(ld.grad, lr.grad, 1e-7, 'dlogits')
+
+
+@pytest.mark.parametrize('n', [1000, 4096 * 3 + 5, 1 << 20])
+def test_clip_adadelta_matches_oracle(n):
+    from ss_asr_amd import ops
+    for scale, steps in ((0.001, 2), (3.0, 2)):       # below and above the clip norm
+        p, g = rnd(n, seed=61).float(), (rnd(n, seed=62) * scale).float()
+        pr, sq, ad = [p.clone()], [torch.zeros(n)], [torch.zeros(n)]
+        pd, sqd, add = p.to(dev()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+        ws, stats = ops.clip_adadelta_ws(n, dev()), torch.zeros(2, device=dev())
+        for _ in range(steps):
+            norm, ok = lo.clip_adadelta_explicit(pr, [g.clone()], sq, ad)
+            ops.clip_adadelta_(pd, g.to(dev()), sqd, add, ws, stats)
+            s = stats.cpu()
+            assert ok and s[1] == 0
+            assert abs(float(s[0]) - norm) <= 1e-5 * max(1.0, norm)
+        close(pd, pr[0], 2e-6, 'param')
+        close(sqd, sq[0], 1e-7, 'square_avg')
+
+
+def test_clip_adadelta_skips_on_nan_and_honours_grad_scale():
+    from ss_asr_amd import ops
+    n = 5000
+    p, g = rnd(n, seed=63).float().to(dev()), rnd(n, seed=64).float().to(dev())
+    sq, ad = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    ws, stats = ops.clip_adadelta_ws(n, dev()), torch.zeros(2, device=dev())
+    bad = g.clone()
+    bad[17] = float('nan')
+    before = p.clone()
+    ops.clip_adadelta_(p, bad, sq, ad, ws, stats)
+    assert stats[1].item() == 1.0 and torch.equal(p, before) and float(sq.abs().sum()) == 0
+    # grad_scale = 1/4 must equal pre-dividing the gradient (DDP mean)
+    p2, sq2, ad2 = before.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    ops.clip_adadelta_(p, g, sq, ad, ws, stats, grad_scale=0.25)
+    ops.clip_adadelta_(p2, g * 0.25, sq2, ad2, ws, stats)
+    close(p, p2, 1e-7, 'grad_scale')
+
+
+def test_frame_lengths():
+    from ss_asr_amd import ops
+    x = rnd(6, 50, 80, seed=71).float()
+    lens = [50, 44, 30, 17, 2, 1]
+    for i, l in enumerate(lens):
+        x[i, l:] = 0
+    assert ops.frame_lengths(x.to(dev())).cpu().tolist() == lens
