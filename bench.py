@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Benchmark of the ASR training hot path (BASELINE.json: train-step
+utterances/sec on 80-dim mel).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = forward (Listener -> Attention -> Speller) + masked CE + backward +
+gradient all-reduce (N > 1) + clip + Adadelta on one synthetic batch that is
+already resident in HBM.  Workload: BASELINE.json configs[1], the ~10 h
+Malromur-shaped corpus (8,000 utterances, <= 800 frames of 80-dim fbank,
+batch 32 per GPU, bucketed by length), fp32 arithmetic, tf_rate 0.9 as in
+conf/default.yaml.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA dense peak
+
+DIMS = dict(output_dim=50, encoder_state_size=256, decoder_state_size=256, mlp_out_size=128,
+            feature_dim=80, tf_rate=0.9)
+
+
+def attention_roofline(device, B=32, T=100, A=128, E=512, D=256, iters=400):
+    """Times the attention energy + masked softmax + context kernel alone with
+    HIP events on the launching stream, at the workload's decode-step shape.
+    Algorithmic bytes per launch: comp + feat + mask/alpha +
+    state/ctx + W_phi, fp32."""
+    from ss_asr_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(5)
+    feat = torch.randn(B, T, E, generator=g).to(device)
+    comp = torch.tanh(torch.randn(B, T, A, generator=g)).to(device)
+    state = torch.randn(B, D, generator=g).to(device)
+    w_phi = (torch.randn(A, D, generator=g) / 16).to(device)
+    lens = torch.full((B,), T, dtype=torch.int32, device=device)
+    for _ in range(20):
+        ops.attn_step(state, w_phi, comp, feat, lens)
+    import ctypes as C
+    from ss_asr_amd import _lib
+    lib = _lib.load()
+    w_t = w_phi.t().contiguous()
+    q = torch.empty(B, A, device=device)
+    att = torch.empty(B, T, device=device)
+    ctx = torch.empty(B, E, device=device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = [C.c_void_p(t.data_ptr()) for t in (state, w_t, comp, feat, lens)]
+    outs = [C.c_void_p(t.data_ptr()) for t in (q, att, ctx)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        lib.ssasr_attn_step_fwd(*args, B, T, A, E, D, *outs, st)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    s = 4
+    nbytes = B * T * (A + E) * s + B * T * (s + 1) + B * (D + E) * s + D * A * s
+    achieved = nbytes / (us * 1e-6) / 1e9
+    return dict(kernel='attn_step_fwd_kernel', bound='hbm', achieved=round(achieved, 1),
+                peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=None, bytes_per_launch=nbytes, us_per_launch=round(us, 3),
+                shape=dict(B=B, T=T, A=A, E=E))
+
+
+def lstm_step_roofline(device, N=32, H=256, iters=400):
+    """The recurrent step kernel (dominant by time): h[N,H] x W_hh^T[H,4H] plus
+    the gate math, per direction.  Priced against the fp32 MFMA peak although
+    it is latency bound (1 launch = 2 directions = 2 * 2*N*H*4H flops)."""
+    import ctypes as C
+    from ss_asr_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(6)
+    S, I = 64, 80
+    x = torch.randn(S, N, I, generator=g).to(device)
+    w = [(torch.randn(4 * H, I, generator=g) / 9).to(device), (torch.randn(4 * H, H, generator=g) / 16).to(device),
+         torch.zeros(4 * H, device=device), torch.zeros(4 * H, device=device)] * 2
+    y = torch.empty(S, N, 2 * H, device=device)
+    gates = torch.empty(2, S * N, 4 * H, device=device)
+    cs = torch.empty(2, S * N, H, device=device)
+    hs = torch.empty(2, S * N, H, device=device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def run():
+        lib.ssasr_bilstm_fwd(p(x), N * I, I, S, N, I, H, None, *[p(t) for t in w], p(y), N * 2 * H, 2 * H,
+                             p(gates), p(cs), p(hs), st)
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(1, iters // S)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * S)       # includes 1/S of the i2h GEMM
+    flops = 2 * (2.0 * N * H * 4 * H)
+    tf = flops / (us * 1e-6) / 1e12
+    return dict(kernel='lstm_cell_fwd_kernel', bound='mfma', achieved=round(tf, 3), peak=MFMA_F32_PEAK_TF,
+                unit='TFLOP/s', frac=round(tf / MFMA_F32_PEAK_TF, 5), traffic=None,
+                flops_per_launch=flops, us_per_launch=round(us, 3),
+                note='latency bound: one launch per time step; floor = kernel boundary ~1.45 us')
+
+
+def cpu_baseline(batch):
+    """The oracle (a CPU restatement of the reference, pinned to its golden
+    vectors) timed on the host cores for ONE train step on one bench batch."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import las_oracle as lo
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    model = lo.OracleASR(**DIMS)
+    optim = lo.make_optimizer(model)
+    x, y, _ = batch
+    x, y = x.cpu(), y.cpu()
+    lo.train_step(model, optim, x[:2, :32].contiguous(), y[:2])          # thread-pool warm-up
+    t0 = time.perf_counter()
+    loss, _ = lo.train_step(model, optim, x, y)
+    dt = time.perf_counter() - t0
+    return dict(value=round(x.shape[0] / dt, 4), unit='utterances/sec', cores=cores, kind='port',
+                sample='1 train step on one bench batch: %d utterances, %d frames max, fp32, torch %s'
+                       % (x.shape[0], x.shape[1], torch.__version__),
+                seconds=round(dt, 2), loss=round(loss, 5))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--max-frames', type=int, default=800)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from ss_asr_amd import dist as sdist
+    rank, world, local = sdist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE is %d' % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print('bench.py needs an MI355X (no CPU path)', file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.engine import ASRTrainStep, label_geometry
+    from ss_asr_amd.synthetic import config2_batches
+
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    model = ASR(**DIMS).to(device)
+    model.train()
+    stepper = ASRTrainStep(model, lr=1.0, eps=1e-8, grad_clip=5.0)
+
+    nb = 8
+    host_batches = config2_batches(nb, batch_size=args.batch, feat_dim=DIMS['feature_dim'], seed=1, rank=rank,
+                                   hi=args.max_frames)
+    batches = []
+    for x, y, lens in host_batches:
+        _, ans_len = label_geometry(y)
+        batches.append((x.to(device), y.to(device), lens, ans_len))
+
+    def run(i):
+        x, y, lens, ans_len = batches[i % nb]
+        return stepper(x, y, lens, ans_len)
+
+    for i in range(args.warmup):
+        run(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = run(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    last_loss = float(loss) if loss is not None else float('nan')
+
+    if rank != 0:
+        return
+    utts = world * args.batch * args.steps
+    frames = sum(sum(batches[(args.warmup + i) % nb][2]) for i in range(args.steps))
+    out = {
+        'metric': 'train-step utterances/sec on 80-dim mel', 'value': round(utts / dt, 2),
+        'unit': 'utterances/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[1]: ASRTrainer step, ~10h synthetic Malromur-shape '
+                               'fbanks (8000 utts, <=%d frames, 80-dim), batch %d per GPU, bucketed by length, '
+                               'LAS 256/256/128, tf_rate 0.9, Adadelta' % (args.max_frames, args.batch),
+                   'global_batch': world * args.batch, 'max_frames': args.max_frames,
+                   'parallelism': 'dp%d' % world, 'mean_frames_per_utt': round(frames / (args.batch * args.steps), 1)},
+        'final_loss': round(last_loss, 5),
+    }
+    if not args.no_roofline:
+        att = attention_roofline(device)
+        rec = lstm_step_roofline(device)
+        out['roofline'] = att
+        out['roofline_recurrent_step'] = rec
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(host_batches[nb // 2])
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

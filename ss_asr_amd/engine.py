@@ -1,0 +1,42 @@
+"""One ASR train step (the body of ASRTrainer.exec, src/trainer.py:415-438) as a
+reusable object: forward, masked CE, backward, gradient all-reduce across
+ranks, clip + NaN guard + Adadelta.  Used by trainer.py, bench.py and the
+tests so that all of them time and check the same code."""
+import torch
+
+from . import dist as sdist
+from . import ops
+from .optim import FlatParameters, FusedAdadelta
+
+
+class ASRTrainStep:
+    def __init__(self, model, lr=1.0, eps=1e-8, rho=0.9, grad_clip=5.0):
+        if not next(model.parameters()).is_cuda:
+            raise RuntimeError('ASRTrainStep needs the model on the GPU (no CPU path)')
+        self.model = model
+        self.flat = FlatParameters(model)
+        sdist.broadcast_flat(self.flat.data)
+        self.optim = FusedAdadelta(self.flat, lr=lr, rho=rho, eps=eps)
+        self.grad_clip = grad_clip
+
+    def forward_loss(self, x, y, x_lens, ans_len):
+        _, logits, att = self.model(x, ans_len, teacher=y, state_len=x_lens)
+        return ops.masked_ce_loss(logits, y, ans_len), logits, att
+
+    def __call__(self, x, y, x_lens, ans_len):
+        """x [B,T,F] float32, y [B,L] int64 (both on the GPU), x_lens host list
+        (descending), ans_len = max label length - 1.  Returns the loss tensor
+        (on the device; reading it synchronises)."""
+        self.optim.zero_grad()
+        loss, _, _ = self.forward_loss(x, y, x_lens, ans_len)
+        loss.backward()
+        scale = sdist.allreduce_grad(self.flat.grad)
+        self.optim.clip_and_step(self.grad_clip, grad_scale=scale)
+        return loss
+
+
+def label_geometry(y_cpu):
+    """prepare_y's lengths on the host (src/ASRDataset.py:338): returns
+    (y_lens, ans_len)."""
+    y_lens = [int(v) + 1 for v in (y_cpu != 0).sum(-1)]
+    return y_lens, max(y_lens) - 1

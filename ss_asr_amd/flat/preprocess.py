@@ -1,0 +1,14 @@
+"""Flat-import shim: the reference's scripts do `import preprocess` with src/ on
+sys.path (src/trainer.py:20-31).  Put this directory first on PYTHONPATH to run
+the reference's src/train.py unchanged against the MI355X implementation."""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from ss_asr_amd.preprocess import *  # noqa: E402,F401,F403
+from ss_asr_amd import preprocess as _impl  # noqa: E402
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith('__')})

@@ -1,0 +1,269 @@
+"""Solver / ASRTrainer with the surface of the reference's src/trainer.py
+(Solver :33-195, ASRTrainer :374-545) so that ``src/train.py`` drives it
+unchanged: ``getattr(trainer, 'ASRTrainer')(config, paras)`` then
+``load_data()``, ``set_model()``, ``exec()``.
+
+Differences, all inside the same call surface:
+  * the model computes through libssasr_hip.so (MI355X only);
+  * parameters and gradients live in flat buffers and Solver.step runs the
+    fused clip + NaN-guard + Adadelta kernel (optim.py) for Adadelta, the
+    reference's clip_grad_norm_ + optim.step() for any other optimizer type;
+  * launched under torchrun (WORLD_SIZE > 1) every rank takes the batches
+    ``index % world == rank`` and gradients are averaged with one RCCL
+    all-reduce per step (dist.py); rank 0 alone logs and checkpoints;
+  * valid() no longer dies on the undefined names of src/trainer.py:531.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dist as sdist
+from . import ops
+from .ASRDataset import load_asr_dataset, prepare_x, prepare_y
+from .LogHandler import LogHandler
+from .TrackerHandler import TrackerHandler
+from .asr import ASR
+from .optim import FlatParameters, FusedAdadelta
+from .postprocess import calc_acc, calc_err, draw_att
+
+
+class Solver:
+    def __init__(self, config, paras, module_id):
+        self.config = config
+        self.paras = paras
+        self.module_id = module_id
+        self.rank, self.world, local = sdist.init_from_env()
+
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            self.device = torch.device('cuda', local)
+            self.verbose("A cuda device is available and will be used.")
+            self.paras.gpu = True
+        else:
+            # Kept for the plumbing tests; the model's forward refuses CPU tensors.
+            self.device = torch.device('cpu')
+            self.verbose("No cuda device available.")
+            self.paras.gpu = False
+
+        os.makedirs(paras.ckpdir, exist_ok=True)
+        self.ckpdir = os.path.join(self.paras.ckpdir, self.paras.name)
+        os.makedirs(self.ckpdir, exist_ok=True)
+        suffix = '' if self.rank == 0 else '.rank%d' % self.rank
+        self.tr = TrackerHandler(os.path.join(self.ckpdir, 'tracker%s.json' % suffix),
+                                 self.module_id)
+        self.lg = LogHandler(os.path.join(self.paras.logdir, self.paras.name,
+                                          self.module_id + suffix), self.module_id)
+        self.ckppath = os.path.join(self.ckpdir, self.module_id + '.cpt')
+        self.best_ckppath = os.path.join(self.ckpdir, self.module_id + '_best.cpt')
+
+        self.valid_step = self.set_if_exists('valid_step', 500)
+        self.logging_step = self.set_if_exists('logging_step', 250)
+        self.save_step = self.set_if_exists('save_step', 1000)
+        self.n_epochs = self.set_if_exists('n_epochs', 5)
+        self.train_batch_size = self.set_if_exists('train_batch_size', 32)
+        self.valid_batch_size = self.set_if_exists('valid_batch_size', 32)
+        self.test_batch_size = self.set_if_exists('test_batch_size', 1)
+        self.verbose_summary()
+
+    def verbose_summary(self):
+        self.verbose("-------SUMMARY-------")
+        self.verbose("Current step : {}".format(self.tr.step))
+        self.verbose("Best metric value : {}".format(self.tr.get_best()))
+        self.verbose("Number of epochs: {}".format(self.n_epochs))
+        self.verbose("Steps: [Logging {}], [Saving {}], [Validation {}]".format(
+            self.logging_step, self.save_step, self.valid_step))
+        self.verbose("Batch sizes: [Train {}], [Validation{}], [Testing {}]".format(
+            self.train_batch_size, self.valid_batch_size, self.test_batch_size))
+        self.verbose("---------------------")
+
+    def set_if_exists(self, key, default):
+        return self.config[self.module_id].get(key, default)
+
+    def verbose(self, msg, progress=False):
+        end = '\r' if progress else '\n'
+        if progress:
+            msg += '                              '
+        else:
+            msg = '[INFO ({} / {})] '.format(self.module_id, self.paras.name) + str(msg)
+        if self.paras.verbose and getattr(self, 'rank', 0) == 0:
+            print(msg, end=end)
+
+    def step(self, params, optim, grad_clip=5):
+        """src/trainer.py:131-148: clip the global gradient norm, skip the update
+        (with a message) when the norm is NaN, otherwise step the optimizer.
+        With FusedAdadelta everything happens on the device; the NaN message of
+        a step is printed when its flag has reached the host (at the latest on
+        the next call)."""
+        if isinstance(optim, FusedAdadelta):
+            done = optim.poll()
+            if done is not None and done[1]:
+                self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+            scale = sdist.allreduce_grad(optim.flat.grad)
+            optim.clip_and_step(max_norm=float(grad_clip), grad_scale=scale)
+            return
+        params = list(params)
+        if sdist.is_active():
+            for p in params:
+                if p.grad is not None:
+                    torch.distributed.all_reduce(p.grad)
+                    p.grad.div_(sdist.world_size())
+        grad_norm = nn.utils.clip_grad_norm_(params, grad_clip)
+        if math.isnan(grad_norm):
+            self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step))
+        else:
+            optim.step()
+
+    def setup_module(self, module, ckp_path, *para, **model_para):
+        model = module(*para, **model_para)
+        if os.path.isfile(ckp_path):
+            self.verbose('Loading a pretrained model from {}'.format(ckp_path))
+            model.load_state_dict(torch.load(ckp_path, map_location='cpu'))
+        else:
+            self.verbose('No model found at {}. A new model will be created'.format(ckp_path))
+        return model.to(self.device)
+
+    def genpath(self, p, module_id):
+        if p is None:
+            path = os.path.join(self.ckpdir, '{}.cpt'.format(module_id))
+            return (path, path)
+        if isinstance(p, str):
+            return (p, p)
+        assert len(p) == 2
+        return p
+
+    def close(self):
+        return None
+
+
+class ASRTrainer(Solver):
+    def __init__(self, config, paras):
+        super().__init__(config, paras, 'asr')
+
+    def load_data(self):
+        """Index files must be sorted so that every batch is in decreasing
+        frame-length order (conf/README.md:16)."""
+        n_jobs = self.set_if_exists('loader_jobs', 8)
+        (self.mapper, _, self.train_set) = load_asr_dataset(
+            self.config['asr']['train_index'], batch_size=self.train_batch_size,
+            n_jobs=n_jobs, use_gpu=self.paras.gpu)
+        (_, _, self.valid_set) = load_asr_dataset(
+            self.config['asr']['valid_index'], batch_size=self.valid_batch_size,
+            n_jobs=n_jobs, use_gpu=self.paras.gpu)
+        self.wer_step = self.config['asr']['wer_step']
+
+    def set_model(self):
+        self.asr_model = self.setup_module(ASR, self.ckppath, self.mapper.get_dim(),
+                                           **self.config['asr']['mdl'])
+        opt = self.config['asr']['opt']
+        if opt['type'] == 'Adadelta' and self.device.type == 'cuda':
+            self.flat = FlatParameters(self.asr_model)
+            sdist.broadcast_flat(self.flat.data)
+            self.optim = FusedAdadelta(self.flat, lr=opt['learning_rate'], eps=1e-8)
+        else:
+            self.optim = getattr(torch.optim, opt['type'])(
+                self.asr_model.parameters(), lr=opt['learning_rate'], eps=1e-8)
+
+    def _loss(self, prediction, y, ans_len):
+        """src/trainer.py:426-434."""
+        if prediction.is_cuda:
+            return ops.masked_ce_loss(prediction, y, ans_len)
+        raise RuntimeError('ss_asr_amd computes on the GPU only')
+
+    def exec(self):
+        self.verbose('Training set total {} batches'.format(len(self.train_set)))
+        epoch = 0
+        while epoch < self.n_epochs:
+            self.verbose("Starting epoch {} out of {}".format(epoch + 1, self.n_epochs))
+            for b_ind, (x, y) in enumerate(self.train_set):
+                if b_ind % self.world != self.rank:
+                    continue
+                self.verbose('Batch: {}/{}, global step: {}'.format(
+                    b_ind, len(self.train_set), self.tr.step), progress=True)
+                (x, x_lens) = prepare_x(x, device=self.device)
+                (y, y_lens) = prepare_y(y, device=self.device)
+                state_len = x_lens
+                ans_len = max(y_lens) - 1
+
+                self.optim.zero_grad()
+                _, prediction, _ = self.asr_model(x, ans_len, teacher=y, state_len=state_len)
+                label = y[:, 1:ans_len + 1].contiguous()
+                loss = self._loss(prediction, y, ans_len)
+                loss.backward()
+                self.step(self.asr_model.parameters(), self.optim)
+
+                if self.rank == 0:
+                    if self.tr.step % self.logging_step == 0:
+                        self.lg.scalar('train_loss', loss.item(), self.tr.step)
+                        self.lg.scalar('train_acc', calc_acc(prediction, label), self.tr.step)
+                    if self.tr.step % self.wer_step == 0:
+                        self.lg.scalar('train_error',
+                                       calc_err(prediction, label, mapper=self.mapper),
+                                       self.tr.step)
+                    if self.tr.step % self.save_step == 0:
+                        self.verbose("Model saved at step {}".format(self.tr.step))
+                        torch.save(self.asr_model.state_dict(), self.ckppath)
+                if self.tr.step % self.valid_step == 0:
+                    self.optim.zero_grad()
+                    self.valid()
+                self.tr.do_step()
+            epoch += 1
+
+    def valid(self):
+        """Greedy decoding for ans_len + 30 steps without a teacher, loss on the
+        first ans_len outputs (src/trainer.py:460-537)."""
+        self.asr_model.eval()
+        total_loss, total_acc, total_err, num_batches = 0.0, 0.0, 0.0, 0
+        prediction = label = att_map = None
+        with torch.no_grad():
+            for b_idx, (x, y) in enumerate(self.valid_set):
+                self.verbose('Validation step - ( {} / {} )'.format(b_idx, len(self.valid_set)),
+                             progress=True)
+                (x, x_lens) = prepare_x(x, device=self.device)
+                (y, y_lens) = prepare_y(y, device=self.device)
+                ans_len = max(y_lens) - 1
+                _, prediction, att_map = self.asr_model(x, ans_len + 30, state_len=x_lens)
+                label = y[:, 1:ans_len + 1].contiguous()
+                loss = self._loss(prediction, y, ans_len)
+                total_loss += float(loss)
+                total_acc += calc_acc(prediction, label)
+                total_err += calc_err(prediction, label, mapper=self.mapper)
+                num_batches += 1
+        if num_batches == 0:
+            self.asr_model.train()
+            return
+        avg_loss = total_loss / num_batches
+        avg_err = total_err / num_batches
+        avg_acc = total_acc / num_batches
+        if self.rank == 0:
+            self.lg.scalar('eval_loss', avg_loss, self.tr.step)
+            self.lg.scalar('eval_error', avg_err, self.tr.step)
+            self.lg.scalar('eval_acc', avg_acc, self.tr.step)
+            hyp_idx = np.argmax(prediction.cpu().numpy(), axis=-1)
+            val_hyp = [self.mapper.translate(p) for p in hyp_idx]
+            val_txt = [self.mapper.translate(l) for l in label.cpu()]
+            for idx, attmap in enumerate(draw_att(att_map, hyp_idx)):
+                self.lg.image('eval_att_' + str(idx), attmap, self.tr.step)
+                self.lg.text('eval_hyp_' + str(idx), "{} |predict vs. real| {}".format(
+                    val_hyp[idx], val_txt[idx]), self.tr.step)
+            if avg_loss < self.tr.get_best():
+                self.tr.set_best(avg_loss)
+                self.verbose('Best validation loss for ASR : {:.4f} @ global step {}'.format(
+                    self.tr.get_best(), self.tr.step))
+                self.verbose('Saving best model.')
+                torch.save(self.asr_model.state_dict(), self.best_ckppath)
+                with open(os.path.join(self.ckpdir, 'best_hyp.txt'), 'w') as f:
+                    for hyp, txt in zip(val_hyp, val_txt):
+                        f.write(hyp + ',' + txt + '\n')
+            else:
+                self.verbose("Validation metric worse : ({:.4f} vs. {:.4f})".format(
+                    avg_loss, self.tr.get_best()))
+        self.asr_model.train()
+
+    def close(self):
+        self.verbose("Finished training! The most recent model will" +
+                     "be saved at step {}".format(self.tr.step))
+        if self.rank == 0:
+            torch.save(self.asr_model.state_dict(), self.ckppath)
