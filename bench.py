@@ -31,6 +31,30 @@ DIMS = dict(output_dim=50, encoder_state_size=256, decoder_state_size=256, mlp_o
             feature_dim=80, tf_rate=0.9)
 
 
+def note(msg):
+    print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU share of this process: affinity mask, capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith('cpu.max'):
+                if parts[0] != 'max':
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                        n = min(n, max(1, quota // int(f.read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 32))
+
+
 def attention_roofline(device, B=32, T=100, A=128, E=512, D=256, iters=400):
     """Times the attention energy + masked softmax + context kernel alone with
     HIP events on the launching stream, at the workload's decode-step shape.
@@ -117,8 +141,9 @@ def cpu_baseline(batch):
     vectors) timed on the host cores for ONE train step on one bench batch."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import las_oracle as lo
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    cores = host_cores()
     torch.set_num_threads(cores)
+    note('cpu baseline: 1 oracle train step on %d cores ...' % cores)
     torch.manual_seed(1)
     model = lo.OracleASR(**DIMS)
     optim = lo.make_optimizer(model)
@@ -197,7 +222,9 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    last_loss = float(loss) if loss is not None else float('nan')
+    last_loss = float(loss.detach()) if loss is not None else float('nan')
+    if rank == 0:
+        note('gpu: %d steps in %.3f s -> %.1f utt/s (loss %.4f)' % (args.steps, dt, world * args.batch * args.steps / dt, last_loss))
 
     if rank != 0:
         return
@@ -217,7 +244,9 @@ def main():
     }
     if not args.no_roofline:
         att = attention_roofline(device)
+        note('attention kernel: %s' % att)
         rec = lstm_step_roofline(device)
+        note('recurrent step kernel: %s' % rec)
         out['roofline'] = att
         out['roofline_recurrent_step'] = rec
     if world == 1 and not args.no_cpu_baseline:

@@ -226,7 +226,7 @@ def train_step(model, optim, x, y):
     loss = masked_ce_loss(logits, y, ans_len)
     loss.backward()
     norm, _ = solver_step(list(model.parameters()), optim)
-    return float(loss), norm
+    return float(loss.detach()), norm
 
 
 def make_optimizer(model):

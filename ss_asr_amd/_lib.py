@@ -70,6 +70,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7 / HSA runtime.  It must be the copy
+    # this process binds: loading ours first would pull in /opt/rocm's runtime
+    # and the two stacks then disagree about the device (hipErrorNoDevice).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             'ss_asr_amd: %s not found. Build it with `python -m ss_asr_amd.build` '

@@ -41,6 +41,18 @@ static inline RowMap rm_dense(int64_t ld) { return RowMap{ld, 0, 0, 0}; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32,
+// about 1 ulp each).  Absolute error < 2e-7, which is what matters for values
+// that feed sums; used inside the latency-critical recurrent kernels where
+// the library tanhf / division sequences cost ~1 us per step.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  // 1 - 2 / (1 + e^{2x}); saturates cleanly: e^{2x} -> inf gives 1, -> 0 gives -1
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 // 64-lane butterfly reductions (wave64).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -141,7 +141,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   SSASR_LAUNCH_CHECK();
 
   const int nch = attn_pick_nch((int)E);
-  dim3 cgrid((unsigned)(D / 4), 1, (unsigned)((B + 31) / 32)), cblock(256);
+  dim3 cgrid = cell_fwd_grid(D, 1, B), cblock(256);
   for (int64_t t = 0; t < U; ++t) {
     AttnFwd p{};
     p.s = t ? d.h1 + (t - 1) * B * D : nullptr; p.lds = D;
@@ -261,7 +261,7 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   if ((rc = ssasr_launch_transpose(d.w_ih2, g.ws_t_ih2, (int)(4 * D), (int)D, st))) return rc;
   if ((rc = ssasr_launch_transpose(d.w_hh2, g.ws_t_hh2, (int)(4 * D), (int)D, st))) return rc;
 
-  dim3 cgrid((unsigned)(D / 16), 1, (unsigned)((B + 31) / 32)), cblock(256);
+  dim3 cgrid = cell_bwd_grid(D, 1, B), cblock(256);
   float* dc1 = g.ws_dc;               // [2][B][D]
   float* dc2 = g.ws_dc + 2 * B * D;   // [2][B][D]
   for (int64_t t = U - 1; t >= 0; --t) {
@@ -311,7 +311,7 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     pm.sl.nseg = 1;
     seg_set(pm.sl, 0, d.gates1 + t * B * 4 * D, 4 * D, g.ws_t_ih1 + D * 4 * D, 4 * D, (int)(4 * D));
     pm.out = g.ws_dctx + t * B * E; pm.ldo = E; pm.N = (int)B; pm.R = (int)E;
-    hipLaunchKernelGGL(seg_matmul_plain_kernel, dim3((unsigned)((E + 15) / 16), 1, (unsigned)((B + 31) / 32)),
+    hipLaunchKernelGGL(seg_matmul_plain_kernel, plain_mm_grid(E, B),
                        dim3(256), 0, st, pm);
 
     // attention step backward (step 0 has q = 0 and s = 0: only the context

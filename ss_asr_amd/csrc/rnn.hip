@@ -51,32 +51,15 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   }
 
   // (2) the recurrence, one launch per step, both directions per launch
-  dim3 grid((unsigned)(H / 4), 2, (unsigned)((N + 31) / 32)), block(256);
-  for (int64_t i = 0; i < S; ++i) {
-    CellFwdPair pr;
-    CellFwd* a = pr.d;
-    for (int d = 0; d < 2; ++d) {
-      const int64_t s = d ? S - 1 - i : i;
-      const int64_t sp = d ? s + 1 : s - 1;
-      CellFwd& c = a[d];
-      c = CellFwd{};
-      float* gd = gates + (d * rows + s * N) * 4 * H;
-      float* cd = cs + d * rows * H;
-      float* hd = hs + d * rows * H;
-      c.sl.nseg = 0;
-      if (i > 0) {
-        c.sl.nseg = 1;
-        seg_set(c.sl, 0, hd + sp * N * H, H, whh[d], H, (int)H);
-        c.c_prev = cd + sp * N * H;
-      }
-      c.pre = gd; c.gates = gd;
-      c.c_out = cd + s * N * H;
-      c.h_out = hd + s * N * H;
-      c.y = y + s * ys_s + d * H; c.ys_n = ys_n;
-      c.lens = lens; c.s = (int)s; c.N = (int)N; c.H = (int)H;
-    }
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, grid, block, 0, st, pr);
-  }
+  if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31) || rows * 4 * H >= (1ll << 40)) return SSASR_EARG;
+  if (!aligned16(w_hh_f) || !aligned16(w_hh_r) || !aligned16(hs)) return SSASR_EARG;   // 16-byte loads
+  EncFwd e{};
+  e.whh[0] = w_hh_f; e.whh[1] = w_hh_r;
+  e.gates = gates; e.cs = cs; e.hs = hs; e.y = y; e.lens = lens;
+  e.ys_s = (int)ys_s; e.ys_n = (int)ys_n; e.S = (int)S; e.N = (int)N; e.H = (int)H;
+  dim3 grid = cell_fwd_grid(H, 2, N), block(256);
+  for (int64_t i = 0; i < S; ++i)
+    hipLaunchKernelGGL(lstm_enc_fwd_kernel, grid, block, 0, st, e, (int)i);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
@@ -94,6 +77,9 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
                                 void* stream) {
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
   if (!dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
+  // the gate epilogue of the backward kernel uses 16-byte accesses
+  if (!aligned16(dy) || !aligned16(gates) || !aligned16(cs) || !aligned16(ws_dc) || ys_s % 4 || ys_n % 4)
+    return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = S * N;
   const float* wih[2] = {w_ih_f, w_ih_r};
@@ -109,35 +95,13 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
   }
 
   // BPTT: one launch per step, both directions per launch.
-  dim3 grid((unsigned)(H / 16), 2, (unsigned)((N + 31) / 32)), block(256);
-  for (int64_t i = 0; i < S; ++i) {
-    CellBwdPair pr;
-    CellBwd* a = pr.d;
-    for (int d = 0; d < 2; ++d) {
-      const int64_t s = d ? i : S - 1 - i;        // reverse of the forward order
-      const int64_t sn = d ? s - 1 : s + 1;       // step handled by the previous launch
-      const int64_t sp = d ? s + 1 : s - 1;       // forward-order predecessor
-      const bool has_prev = d ? (s < S - 1) : (s > 0);
-      CellBwd& c = a[d];
-      c = CellBwd{};
-      float* gd = gates + d * rows * 4 * H;
-      const float* cd = cs + d * rows * H;
-      float* dcb = ws_dc + d * 2 * N * H;
-      c.sl.nseg = 0;
-      if (i > 0) {
-        c.sl.nseg = 1;
-        seg_set(c.sl, 0, gd + sn * N * 4 * H, 4 * H, ws_whhT + d * 4 * H * H, 4 * H, (int)(4 * H));
-        c.dc_in = dcb + (i & 1) * N * H;
-      }
-      c.add1 = dy + s * ys_s + d * H; c.ld1 = ys_n;
-      c.gates = gd + s * N * 4 * H; c.dgates = gd + s * N * 4 * H;
-      c.c_prev = has_prev ? cd + sp * N * H : nullptr;
-      c.c = cd + s * N * H;
-      c.dc_out = dcb + ((i + 1) & 1) * N * H;
-      c.lens = lens; c.s = (int)s; c.N = (int)N; c.H = (int)H;
-    }
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, grid, block, 0, st, pr);
-  }
+  if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31)) return SSASR_EARG;
+  EncBwd e{};
+  e.whhT = ws_whhT; e.gates = gates; e.cs = cs; e.dy = dy; e.dc = ws_dc; e.lens = lens;
+  e.ys_s = (int)ys_s; e.ys_n = (int)ys_n; e.S = (int)S; e.N = (int)N; e.H = (int)H;
+  dim3 grid = cell_bwd_grid(H, 2, N), block(256);
+  for (int64_t i = 0; i < S; ++i)
+    hipLaunchKernelGGL(lstm_enc_bwd_kernel, grid, block, 0, st, e, (int)i);
   SSASR_LAUNCH_CHECK();
 
   // Dense contractions over all time steps.
@@ -214,7 +178,7 @@ extern "C" int ssasr_lstm_cell_fwd(const float* x1, int64_t ldx1, int64_t k1, co
   c.sl.nseg = ns;
   c.b1 = b_ih; c.b2 = b_hh; c.gates = gates; c.c_prev = c_prev; c.c_out = c_out; c.h_out = h_out;
   c.N = (int)N; c.H = (int)H;
-  dim3 grid((unsigned)(H / 4), 1, (unsigned)((N + 31) / 32)), block(256);
+  dim3 grid = cell_fwd_grid(H, 1, N), block(256);
   hipLaunchKernelGGL(lstm_cell_fwd_kernel, grid, block, 0, (hipStream_t)stream, pr);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
@@ -227,12 +191,15 @@ extern "C" int ssasr_lstm_cell_bwd(const float* dh, const float* dc, const float
                                    const float* c_prev, const float* c, int64_t N, int64_t H,
                                    float* dgates, float* dc_prev, void* stream) {
   if (N <= 0 || H <= 0 || H % 16 != 0 || !dh || !gates || !c || !dgates || !dc_prev) return SSASR_EARG;
+  if (!aligned16(dh) || !aligned16(gates) || !aligned16(c) || !aligned16(dgates) || !aligned16(dc_prev) ||
+      !aligned16(dc) || !aligned16(c_prev))
+    return SSASR_EARG;
   CellBwdPair pr{};
   CellBwd& b = pr.d[0];
   b.sl.nseg = 0;
   b.add1 = dh; b.ld1 = H; b.dc_in = dc; b.gates = gates; b.c_prev = c_prev; b.c = c;
   b.dgates = dgates; b.dc_out = dc_prev; b.N = (int)N; b.H = (int)H;
-  dim3 grid((unsigned)(H / 16), 1, (unsigned)((N + 31) / 32)), block(256);
+  dim3 grid = cell_bwd_grid(H, 1, N), block(256);
   hipLaunchKernelGGL(lstm_cell_bwd_kernel, grid, block, 0, (hipStream_t)stream, pr);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;

@@ -11,12 +11,15 @@
 //  * one launch per time step, both directions in the same grid.  The kernel
 //    boundary is the only inter-workgroup synchronisation (about 1.5 us on
 //    MI355X, cheaper than an in-kernel all-gather over 8 XCDs);
+//  * inside a launch there is exactly ONE round trip to memory: every operand
+//    of the step (weights, previous state, and everything the gate epilogue
+//    needs) is requested up front with 16-byte loads, then consumed;
 //  * forward: a workgroup owns 4 hidden units = 16 gate rows = one MFMA row
 //    tile, for a chunk of 32 batch columns.  Its 4 waves split K and combine
 //    through LDS; the MFMA output layout puts the four gates of one (unit,
 //    column) pair in the four accumulator registers of one lane, so the cell
 //    update needs no cross-lane traffic;
-//  * backward: a workgroup owns 16 hidden units and computes
+//  * backward: a workgroup owns 16 hidden units x 16 batch columns and computes
 //    dh_t = dy_t + dG_{t+1} x W_hh (K = 4H, weights pre-transposed so that K
 //    is contiguous), then the gate derivatives for its own units.  "matmul
 //    first, pointwise second" keeps everything a step needs inside the
@@ -29,82 +32,156 @@
 #pragma once
 #include "common.h"
 
+#ifndef SSASR_STAMP          // diagnostic builds (tools/stepbench.hip) define this
+#define SSASR_STAMP(i)
+#define SSASR_STAMP_DRAIN()
+#else
+#define SSASR_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 namespace {
 
 constexpr int MAXSEG = 3;
 
-// acc[bt] += W[row, :] . X[n(bt), :]^T for this wave's share of K.
-// A operand lane (r, q): W[row r][k]; B operand lane (n = r, q): X[n][k].
-__device__ __forceinline__ void seg_mma(f32x4 (&acc)[2], const float* wrow, const float* x0,
-                                        const float* x1, int K, bool vec, int wave, int q) {
-  if (vec) {
-    // K % 16 == 0 and all rows 16-byte aligned: one float4 feeds four MFMAs.
-    const int nkb = K >> 4;
-#pragma unroll 4
-    for (int kb = wave; kb < nkb; kb += 4) {
-      const int k = (kb << 4) + 4 * q;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 a = wrow ? *reinterpret_cast<const float4*>(wrow + k) : z;
-      const float4 b0 = x0 ? *reinterpret_cast<const float4*>(x0 + k) : z;
-      const float4 b1 = x1 ? *reinterpret_cast<const float4*>(x1 + k) : z;
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc[1], 0, 0, 0);
-    }
-  } else {
-    const int ng = (K + 3) >> 2;
-    for (int g = wave; g < ng; g += 4) {
-      const int k = 4 * g + q;
-      const bool in = k < K;
-      const float a = (wrow && in) ? wrow[k] : 0.f;
-      const float b0 = (x0 && in) ? x0[k] : 0.f;
-      const float b1 = (x1 && in) ? x1[k] : 0.f;
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
-    }
-  }
-}
-
+// Descriptors are copied from the kernel-argument segment into registers in
+// ONE round of scalar loads at kernel entry (every later `if (ptr)` would
+// otherwise cost its own dependent ~0.2 us scalar-memory round trip), so they
+// are kept small and free of padding.
 struct SegList {
-  int nseg;
   const float* X[MAXSEG];   // [N][K] activations, row stride ldx
-  int64_t ldx[MAXSEG];
   const float* W[MAXSEG];   // [rows][K] weights, row stride ldw
-  int64_t ldw[MAXSEG];
+  int ldx[MAXSEG];
+  int ldw[MAXSEG];
   int K[MAXSEG];
-  int vec[MAXSEG];
+  int nseg;
+  int allvec;               // every segment: K % 16 == 0 and all rows 16-byte aligned
 };
 
-// Runs all segments for one 16-row weight tile and 32 batch columns, combines
-// the four waves' partial sums through LDS.  On return red[bt][lane] holds the
-// complete D fragments (row = 4 * (lane >> 4) + reg, column = lane & 15).
+#define SSASR_MFMA4(ACC, A, B)                                                  \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, ACC, 0, 0, 0);       \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, ACC, 0, 0, 0);       \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, ACC, 0, 0, 0);       \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, ACC, 0, 0, 0)
+
+// D[16 x 16*NB] = sum over segments of W[row, :] . X[n, :]^T for one 16-row
+// weight tile and NB tiles of 16 batch columns.  The four waves split K in
+// interleaved 16-deep blocks and combine through LDS.  On return
+// red[(w*NB + bt)*64 + lane] holds wave w's partial D fragments (row =
+// 4 * (lane >> 4) + reg, column = lane & 15); use red_sum().
+//
+// Fast path (all segments `vec`): per segment, this wave's k-blocks are
+// consumed UN at a time, all 16-byte loads of a group issued before its MFMAs.
+// Inside a 16-deep block MFMA j reads k = 4 * (lane >> 4) + j from both
+// operands, so one float4 feeds four MFMAs.  Rows / columns outside the matrix
+// are read from row 0 instead (their products land in D rows / columns that
+// are never stored).  Operand matrices must be smaller than 4 GiB.
+template <int NB, int UN>
 __device__ __forceinline__ void seg_matmul_tile(const SegList& sl, int64_t wrow_index, bool wrow_ok,
-                                                int n0, int N, f32x4* red /* [4][2][64] */) {
+                                                int n0, int N, f32x4* red) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  const int na = n0 + r, nb = n0 + 16 + r;
-  for (int sgi = 0; sgi < sl.nseg; ++sgi) {
-    const float* wrow = wrow_ok ? sl.W[sgi] + wrow_index * sl.ldw[sgi] : nullptr;
-    const float* x0 = na < N ? sl.X[sgi] + (int64_t)na * sl.ldx[sgi] : nullptr;
-    const float* x1 = nb < N ? sl.X[sgi] + (int64_t)nb * sl.ldx[sgi] : nullptr;
-    seg_mma(acc, wrow, x0, x1, sl.K[sgi], sl.vec[sgi] != 0, wave, q);
+  f32x4 acc[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (sl.allvec) {
+    // Addressing is kept off the vector ALU: a wave-uniform base pointer per
+    // segment (SGPRs), one 32-bit byte offset per lane and operand, and an
+    // immediate per k-block.  A lone wave issues about one instruction per
+    // 4-8 cycles, so every VALU instruction ahead of the loads is latency.
+    const unsigned wr = wrow_ok ? (unsigned)wrow_index : 0u;
+    unsigned nrow[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int n = n0 + 16 * t + r;
+      nrow[t] = (unsigned)(n < N ? n : 0);
+    }
+#pragma unroll
+    for (int s = 0; s < MAXSEG; ++s) {
+      if (s >= sl.nseg) continue;                       // uniform
+      const int nkb = sl.K[s] >> 4;
+      const int cnt = nkb > wave ? (nkb - wave + 3) >> 2 : 0;   // this wave's k-blocks
+      const char* wb = reinterpret_cast<const char*>(sl.W[s]) + wave * 64;
+      const char* xb = reinterpret_cast<const char*>(sl.X[s]) + wave * 64;
+      const unsigned wo = (wr * (unsigned)sl.ldw[s] + 4u * q) * 4u;
+      unsigned xo[NB];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) xo[t] = (nrow[t] * (unsigned)sl.ldx[s] + 4u * q) * 4u;
+      int j0 = 0;
+      for (; j0 + UN <= cnt; j0 += UN) {                // full groups: immediates only
+        float4 a[UN], b[UN][NB];
+        const char* wg = wb + j0 * 256;
+        const char* xg = xb + j0 * 256;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          a[u] = *reinterpret_cast<const float4*>(wg + wo + u * 256);
+#pragma unroll
+          for (int t = 0; t < NB; ++t) b[u][t] = *reinterpret_cast<const float4*>(xg + xo[t] + u * 256);
+        }
+        SSASR_STAMP(1);
+        SSASR_STAMP_DRAIN();
+        SSASR_STAMP(2);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+          for (int t = 0; t < NB; ++t) { SSASR_MFMA4(acc[t], a[u], b[u][t]); }
+        }
+      }
+      if (j0 < cnt) {                                   // tail group (uniform guards)
+        float4 a[UN], b[UN][NB];
+        const char* wg = wb + j0 * 256;
+        const char* xg = xb + j0 * 256;
+        const int rem = cnt - j0;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          if (u < rem) {
+            a[u] = *reinterpret_cast<const float4*>(wg + wo + u * 256);
+#pragma unroll
+            for (int t = 0; t < NB; ++t) b[u][t] = *reinterpret_cast<const float4*>(xg + xo[t] + u * 256);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          if (u < rem) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t) { SSASR_MFMA4(acc[t], a[u], b[u][t]); }
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < MAXSEG; ++s) {
+      if (s >= sl.nseg) continue;
+      const float* w = wrow_ok ? sl.W[s] + wrow_index * (int64_t)sl.ldw[s] : nullptr;
+      const int K = sl.K[s];
+      const int ng = (K + 3) >> 2;
+      for (int g = wave; g < ng; g += 4) {
+        const int k = 4 * g + q;
+        const bool in = k < K;
+        const float a = (w && in) ? w[k] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const int n = n0 + 16 * t + r;
+          const float b = (n < N && in) ? sl.X[s][(int64_t)n * sl.ldx[s] + k] : 0.f;
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
   }
-  red[(wave * 2 + 0) * 64 + lane] = acc[0];
-  red[(wave * 2 + 1) * 64 + lane] = acc[1];
+  SSASR_STAMP(3);
+#pragma unroll
+  for (int t = 0; t < NB; ++t) red[(wave * NB + t) * 64 + lane] = acc[t];
   __syncthreads();
+  SSASR_STAMP(4);
 }
 
+template <int NB>
 __device__ __forceinline__ f32x4 red_sum(const f32x4* red, int bt, int lane) {
-  f32x4 v = red[(0 * 2 + bt) * 64 + lane];
+  f32x4 v = red[(0 * NB + bt) * 64 + lane];
 #pragma unroll
-  for (int w = 1; w < 4; ++w) v += red[(w * 2 + bt) * 64 + lane];
+  for (int w = 1; w < 4; ++w) v += red[(w * NB + bt) * 64 + lane];
   return v;
 }
 
@@ -119,46 +196,55 @@ struct CellFwd {
   float* c_out;          // [N][H]
   float* h_out;          // [N][H]
   float* y;              // optional strided copy of h: y[n * ys_n + u]
-  int64_t ys_n;
   const int32_t* lens;   // [N] or null
+  int ys_n;
   int s;
   int N, H;
 };
 
 struct CellFwdPair { CellFwd d[2]; };   // one entry per direction (blockIdx.y)
 
-__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwdPair pr) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 2 * 64];
-  const CellFwd& a = pr.d[blockIdx.y];
+constexpr int FWD_NB = 2;    // batch tiles per workgroup (32 columns)
+constexpr int FWD_UN = 4;
+
+__device__ __forceinline__ void cell_fwd_body(const CellFwd& a, f32x4* red) {
   const int H = a.H, N = a.N;
   const int tile = blockIdx.x;            // 4 hidden units
-  const int n0 = blockIdx.z * 32;
+  const int n0 = blockIdx.z * (16 * FWD_NB);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
-  // tile row r <-> (unit 4*tile + (r >> 2), gate r & 3); PyTorch row = gate*H + unit
-  const int urow = 4 * tile + (r >> 2);
-  seg_matmul_tile(a.sl, (int64_t)(r & 3) * H + urow, urow < H, n0, N, red);
 
-  if (threadIdx.x >= 128) return;
+  // Epilogue role of the first FWD_NB waves: lane (q, r) of wave bt owns the
+  // four gates of unit u for column n.  Its operands are requested first.
   const int bt = threadIdx.x >> 6;
   const int u = 4 * tile + q;
   const int n = n0 + 16 * bt + r;
-  if (u >= H || n >= N) return;
-  f32x4 p = red_sum(red, bt, lane);
+  const bool epi = bt < FWD_NB && u < H && n < N;
   const int64_t g0 = (int64_t)n * 4 * H + u;
+  float add[4] = {0.f, 0.f, 0.f, 0.f};
+  float cp = 0.f;
+  bool live = true;
+  if (epi) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float v = p[g];
-    if (a.pre) v += a.pre[g0 + (int64_t)g * H];
-    if (a.b1) v += a.b1[g * H + u];
-    if (a.b2) v += a.b2[g * H + u];
-    p[g] = v;
+    for (int g = 0; g < 4; ++g) {
+      if (a.pre) add[g] = a.pre[g0 + (int64_t)g * H];
+      if (a.b1) add[g] += a.b1[g * H + u];
+      if (a.b2) add[g] += a.b2[g * H + u];
+    }
+    if (a.c_prev) cp = a.c_prev[(int64_t)n * H + u];
+    if (a.lens) live = a.s < a.lens[n];
   }
-  const bool live = !a.lens || a.s < a.lens[n];
-  float gi = sigmoidf_(p[0]), gf = sigmoidf_(p[1]), gg = tanhf(p[2]), go = sigmoidf_(p[3]);
-  const float cp = a.c_prev ? a.c_prev[(int64_t)n * H + u] : 0.f;
+
+  // tile row r <-> (unit 4*tile + (r >> 2), gate r & 3); PyTorch row = gate*H + unit
+  const int urow = 4 * tile + (r >> 2);
+  seg_matmul_tile<FWD_NB, FWD_UN>(a.sl, (int64_t)(r & 3) * H + urow, urow < H, n0, N, red);
+  if (!epi) return;
+
+  const f32x4 p = red_sum<FWD_NB>(red, bt, lane);
+  float gi = fast_sigmoid(p[0] + add[0]), gf = fast_sigmoid(p[1] + add[1]);
+  float gg = fast_tanh(p[2] + add[2]), go = fast_sigmoid(p[3] + add[3]);
   float c = gf * cp + gi * gg;
-  float h = go * tanhf(c);
+  float h = go * fast_tanh(c);
   if (!live) { gi = gf = gg = go = 0.f; c = 0.f; h = 0.f; }
   a.gates[g0] = gi;
   a.gates[g0 + H] = gf;
@@ -167,80 +253,200 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwdPair pr) {
   a.c_out[(int64_t)n * H + u] = c;
   a.h_out[(int64_t)n * H + u] = h;
   if (a.y) a.y[(int64_t)n * a.ys_n + u] = h;
+  SSASR_STAMP(5);
+}
+
+// Generic form (Speller cells): grid (H/4, directions, ceil(N/32)), 256 threads
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwdPair pr) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * FWD_NB * 64];
+  SSASR_STAMP(0);
+  const CellFwd a = pr.d[blockIdx.y];     // whole descriptor -> registers, one round
+  cell_fwd_body(a, red);
+}
+
+// Encoder layers launch this once per time step.  The arguments are a compact
+// layer descriptor plus the step index (host launch cost grows with argument
+// bytes: ~2.5 us at 12 B, ~4 us at 700 B); each direction derives its own
+// pointers on the scalar unit.
+struct EncFwd {
+  const float* whh[2];   // [4H][H] per direction
+  float* gates;          // [2][S*N][4H]: pre-activations in, activated gates out
+  float* cs;             // [2][S*N][H]
+  float* hs;             // [2][S*N][H]
+  float* y;              // y[s * ys_s + n * ys_n + d * H + u]
+  const int32_t* lens;
+  int ys_s, ys_n;
+  int S, N, H;
+};
+
+__global__ __launch_bounds__(256) void lstm_enc_fwd_kernel(EncFwd e, int i) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * FWD_NB * 64];
+  SSASR_STAMP(0);
+  const int d = blockIdx.y;
+  const int64_t S = e.S, N = e.N, H = e.H;
+  const int64_t s = d ? S - 1 - i : i;
+  const int64_t sp = d ? s + 1 : s - 1;
+  const int64_t rows = S * N;
+  CellFwd a;
+  a.sl = SegList{};
+  float* gd = e.gates + (d * rows + s * N) * 4 * H;
+  float* cd = e.cs + d * rows * H;
+  float* hd = e.hs + d * rows * H;
+  a.c_prev = nullptr;
+  if (i > 0) {
+    a.sl.X[0] = hd + sp * N * H; a.sl.ldx[0] = (int)H;
+    a.sl.W[0] = e.whh[d]; a.sl.ldw[0] = (int)H;
+    a.sl.K[0] = (int)H; a.sl.nseg = 1; a.sl.allvec = (H % 16 == 0);
+    a.c_prev = cd + sp * N * H;
+  }
+  a.pre = gd; a.b1 = nullptr; a.b2 = nullptr; a.gates = gd;
+  a.c_out = cd + s * N * H;
+  a.h_out = hd + s * N * H;
+  a.y = e.y + s * e.ys_s + d * H; a.ys_n = e.ys_n;
+  a.lens = e.lens; a.s = (int)s; a.N = e.N; a.H = e.H;
+  cell_fwd_body(a, red);
 }
 
 // ------------------------------- backward --------------------------------
 struct CellBwd {
   SegList sl;            // X = gate derivatives of the consumers, W = transposed weights [H][K]
   const float* add1;     // optional addend rows: add1[n * ld1 + u]
-  int64_t ld1;
   const float* add2;
-  int64_t ld2;
   const float* dc_in;    // [N][H] or null
   const float* gates;    // [N][4H] activated gates saved by the forward pass
   const float* c_prev;   // [N][H] or null
   const float* c;        // [N][H]
   float* dgates;         // [N][4H] derivative w.r.t. gate pre-activations (may alias gates)
   float* dc_out;         // [N][H] or null
-  float* dh_out;         // optional [N][H]: the total dh of this step (debug / taps)
   const int32_t* lens;
+  int ld1, ld2;
   int s;
   int N, H;
 };
 
 struct CellBwdPair { CellBwd d[2]; };
 
-__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwdPair pr) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 2 * 64];
-  const CellBwd& a = pr.d[blockIdx.y];
+constexpr int BWD_NB = 1;    // 16 batch columns per workgroup
+constexpr int BWD_UN = 16;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// grid (H/16, directions, ceil(N/16)), 256 threads.  All row pointers must be
+// 16-byte aligned and H % 4 == 0 (checked by the host entry points).
+__device__ __forceinline__ void cell_bwd_body(const CellBwd& a, f32x4* red) {
   const int H = a.H, N = a.N;
   const int tile = blockIdx.x;            // 16 hidden units
-  const int n0 = blockIdx.z * 32;
+  const int n0 = blockIdx.z * (16 * BWD_NB);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
-  const int urow = 16 * tile + r;
-  seg_matmul_tile(a.sl, urow, urow < H, n0, N, red);
 
-  if (threadIdx.x >= 128) return;
+  // Epilogue role of wave 0: lane (q, r) owns units u0 .. u0+3 of column n.
   const int bt = threadIdx.x >> 6;
+  const int u0 = 16 * tile + 4 * q;
   const int n = n0 + 16 * bt + r;
-  if (n >= N) return;
-  const f32x4 dhv = red_sum(red, bt, lane);
-  const bool live = !a.lens || a.s < a.lens[n];
+  const bool epi = bt < BWD_NB && u0 < H && n < N;
+  const int64_t hu = (int64_t)n * H + u0;
+  const int64_t g0 = (int64_t)n * 4 * H + u0;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gi = z4, gf = z4, gg = z4, go = z4, cpv = z4, cv = z4, dcv = z4, ad1 = z4, ad2 = z4;
+  bool live = true;
+  if (epi) {
+    gi = ld4(a.gates + g0);
+    gf = ld4(a.gates + g0 + H);
+    gg = ld4(a.gates + g0 + 2 * (int64_t)H);
+    go = ld4(a.gates + g0 + 3 * (int64_t)H);
+    cv = ld4(a.c + hu);
+    if (a.c_prev) cpv = ld4(a.c_prev + hu);
+    if (a.dc_in) dcv = ld4(a.dc_in + hu);
+    if (a.add1) ad1 = ld4(a.add1 + (int64_t)n * a.ld1 + u0);
+    if (a.add2) ad2 = ld4(a.add2 + (int64_t)n * a.ld2 + u0);
+    if (a.lens) live = a.s < a.lens[n];
+  }
+
+  const int urow = 16 * tile + r;
+  seg_matmul_tile<BWD_NB, BWD_UN>(a.sl, urow, urow < H, n0, N, red);
+  if (!epi) return;
+
+  const f32x4 dhv = red_sum<BWD_NB>(red, bt, lane);
+  float di[4], df[4], dg[4], dov[4], dcp[4];
+  const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
+  const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
+  const float cp_[4] = {cpv.x, cpv.y, cpv.z, cpv.w}, c_[4] = {cv.x, cv.y, cv.z, cv.w};
+  const float dc_[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
+  const float a1_[4] = {ad1.x, ad1.y, ad1.z, ad1.w}, a2_[4] = {ad2.x, ad2.y, ad2.z, ad2.w};
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int u = 16 * tile + 4 * q + e;
-    if (u >= H) continue;
-    const int64_t hu = (int64_t)n * H + u;
-    const int64_t g0 = (int64_t)n * 4 * H + u;
-    float dh = dhv[e];
-    if (a.add1) dh += a.add1[(int64_t)n * a.ld1 + u];
-    if (a.add2) dh += a.add2[(int64_t)n * a.ld2 + u];
-    float di = 0.f, df = 0.f, dg = 0.f, dov = 0.f, dcp = 0.f;
-    if (live) {
-      const float gi = a.gates[g0], gf = a.gates[g0 + H];
-      const float gg = a.gates[g0 + 2 * (int64_t)H], go = a.gates[g0 + 3 * (int64_t)H];
-      const float cp = a.c_prev ? a.c_prev[hu] : 0.f;
-      const float tc = tanhf(a.c[hu]);
-      float dc = a.dc_in ? a.dc_in[hu] : 0.f;
-      dc += dh * go * (1.f - tc * tc);
-      dov = dh * tc * go * (1.f - go);
-      di = dc * gg * gi * (1.f - gi);
-      dg = dc * gi * (1.f - gg * gg);
-      df = dc * cp * gf * (1.f - gf);
-      dcp = dc * gf;
-    }
-    a.dgates[g0] = di;
-    a.dgates[g0 + H] = df;
-    a.dgates[g0 + 2 * (int64_t)H] = dg;
-    a.dgates[g0 + 3 * (int64_t)H] = dov;
-    if (a.dc_out) a.dc_out[hu] = dcp;
-    if (a.dh_out) a.dh_out[hu] = live ? dh : 0.f;
+    const float dh = dhv[e] + a1_[e] + a2_[e];
+    const float tc = fast_tanh(c_[e]);
+    const float dc = dc_[e] + dh * go_[e] * (1.f - tc * tc);
+    dov[e] = live ? dh * tc * go_[e] * (1.f - go_[e]) : 0.f;
+    di[e] = live ? dc * gg_[e] * gi_[e] * (1.f - gi_[e]) : 0.f;
+    dg[e] = live ? dc * gi_[e] * (1.f - gg_[e] * gg_[e]) : 0.f;
+    df[e] = live ? dc * cp_[e] * gf_[e] * (1.f - gf_[e]) : 0.f;
+    dcp[e] = live ? dc * gf_[e] : 0.f;
   }
+  st4(a.dgates + g0, make_float4(di[0], di[1], di[2], di[3]));
+  st4(a.dgates + g0 + H, make_float4(df[0], df[1], df[2], df[3]));
+  st4(a.dgates + g0 + 2 * (int64_t)H, make_float4(dg[0], dg[1], dg[2], dg[3]));
+  st4(a.dgates + g0 + 3 * (int64_t)H, make_float4(dov[0], dov[1], dov[2], dov[3]));
+  if (a.dc_out) st4(a.dc_out + hu, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+  SSASR_STAMP(5);
 }
 
-// out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:]  (+ add), plain store.  Used for
-// the context gradient of the speller's first cell.
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwdPair pr) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * BWD_NB * 64];
+  SSASR_STAMP(0);
+  const CellBwd a = pr.d[blockIdx.y];     // whole descriptor -> registers, one round
+  cell_bwd_body(a, red);
+}
+
+// Encoder BPTT step: compact layer descriptor + launch index (see EncFwd).
+struct EncBwd {
+  const float* whhT;     // [2][H][4H] transposed recurrent weights
+  float* gates;          // [2][S*N][4H]: activated gates in, gate derivatives out
+  const float* cs;       // [2][S*N][H]
+  const float* dy;       // dy[s * ys_s + n * ys_n + d * H + u]
+  float* dc;             // [2][2][N][H] ping-pong cell-state derivative
+  const int32_t* lens;
+  int ys_s, ys_n;
+  int S, N, H;
+};
+
+__global__ __launch_bounds__(256) void lstm_enc_bwd_kernel(EncBwd e, int i) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * BWD_NB * 64];
+  SSASR_STAMP(0);
+  const int d = blockIdx.y;
+  const int64_t S = e.S, N = e.N, H = e.H;
+  const int64_t s = d ? i : S - 1 - i;          // reverse of the forward order
+  const int64_t sn = d ? s - 1 : s + 1;         // step handled by the previous launch
+  const int64_t sp = d ? s + 1 : s - 1;         // forward-order predecessor
+  const bool has_prev = d ? (s < S - 1) : (s > 0);
+  const int64_t rows = S * N;
+  CellBwd a;
+  a.sl = SegList{};
+  float* gd = e.gates + d * rows * 4 * H;
+  const float* cd = e.cs + d * rows * H;
+  float* dcb = e.dc + d * 2 * N * H;
+  a.dc_in = nullptr;
+  if (i > 0) {
+    a.sl.X[0] = gd + sn * N * 4 * H; a.sl.ldx[0] = (int)(4 * H);
+    a.sl.W[0] = e.whhT + d * 4 * H * H; a.sl.ldw[0] = (int)(4 * H);
+    a.sl.K[0] = (int)(4 * H); a.sl.nseg = 1; a.sl.allvec = 1;
+    a.dc_in = dcb + (i & 1) * N * H;
+  }
+  a.add1 = e.dy + s * e.ys_s + d * H; a.ld1 = e.ys_n;
+  a.add2 = nullptr; a.ld2 = 0;
+  a.gates = gd + s * N * 4 * H; a.dgates = gd + s * N * 4 * H;
+  a.c_prev = has_prev ? cd + sp * N * H : nullptr;
+  a.c = cd + s * N * H;
+  a.dc_out = dcb + ((i + 1) & 1) * N * H;
+  a.lens = e.lens; a.s = (int)s; a.N = e.N; a.H = e.H;
+  cell_bwd_body(a, red);
+}
+
+// out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:], plain store.  Used for the
+// context gradient of the speller's first cell.
 struct PlainMm {
   SegList sl;
   float* out;
@@ -248,19 +454,21 @@ struct PlainMm {
   int N, R;   // R = number of output columns (weight rows)
 };
 
-__global__ __launch_bounds__(256) void seg_matmul_plain_kernel(PlainMm a) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 2 * 64];
+// grid (ceil(R/16), 1, ceil(N/16)), 256 threads
+__global__ __launch_bounds__(256) void seg_matmul_plain_kernel(PlainMm pa) {
+  const PlainMm a = pa;
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * BWD_NB * 64];
   const int tile = blockIdx.x;
-  const int n0 = blockIdx.z * 32;
+  const int n0 = blockIdx.z * (16 * BWD_NB);
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int urow = 16 * tile + r;
-  seg_matmul_tile(a.sl, urow, urow < a.R, n0, a.N, red);
-  if (threadIdx.x >= 128) return;
+  seg_matmul_tile<BWD_NB, BWD_UN>(a.sl, urow, urow < a.R, n0, a.N, red);
   const int bt = threadIdx.x >> 6;
+  if (bt >= BWD_NB) return;
   const int n = n0 + 16 * bt + r;
   if (n >= a.N) return;
-  const f32x4 v = red_sum(red, bt, lane);
+  const f32x4 v = red_sum<BWD_NB>(red, bt, lane);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int u = 16 * tile + 4 * q + e;
@@ -307,9 +515,24 @@ bool vec_ok(const void* p, int64_t ld, int K) {
   return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0 && K % 16 == 0;
 }
 
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Appends a segment; call in order i = 0, 1, ... (sets nseg = i + 1).
 void seg_set(SegList& sl, int i, const float* X, int64_t ldx, const float* W, int64_t ldw, int K) {
-  sl.X[i] = X; sl.ldx[i] = ldx; sl.W[i] = W; sl.ldw[i] = ldw; sl.K[i] = K;
-  sl.vec[i] = vec_ok(X, ldx, K) && vec_ok(W, ldw, K);
+  sl.X[i] = X; sl.ldx[i] = (int)ldx; sl.W[i] = W; sl.ldw[i] = (int)ldw; sl.K[i] = K;
+  const int ok = vec_ok(X, ldx, K) && vec_ok(W, ldw, K);
+  sl.allvec = (i == 0) ? ok : (sl.allvec && ok);
+  sl.nseg = i + 1;
+}
+
+inline dim3 cell_fwd_grid(int64_t H, int dirs, int64_t N) {
+  return dim3((unsigned)(H / 4), (unsigned)dirs, (unsigned)((N + 16 * FWD_NB - 1) / (16 * FWD_NB)));
+}
+inline dim3 cell_bwd_grid(int64_t H, int dirs, int64_t N) {
+  return dim3((unsigned)(H / 16), (unsigned)dirs, (unsigned)((N + 16 * BWD_NB - 1) / (16 * BWD_NB)));
+}
+inline dim3 plain_mm_grid(int64_t R, int64_t N) {
+  return dim3((unsigned)((R + 15) / 16), 1, (unsigned)((N + 16 * BWD_NB - 1) / (16 * BWD_NB)));
 }
 
 }  // namespace
