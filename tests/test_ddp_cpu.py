@@ -1,0 +1,63 @@
+"""World-size-2 checks of the data-parallel host logic on the gloo backend (CPU).
+The arithmetic under test is the collective contract of ss_asr_amd/dist.py:
+SUM all-reduce of the flat gradient, averaging folded into the optimizer as
+grad_scale = 1/world, parameters broadcast from rank 0."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from ss_asr_amd import dist as sdist
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.optim import FlatParameters
+    r, w, _ = sdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world) and sdist.is_active() and sdist.world_size() == world
+
+    torch.manual_seed(100 + rank)                      # ranks start from different weights
+    model = ASR(50, 32, 32, 16, 12, 1.0)
+    flat = FlatParameters(model)
+    sdist.broadcast_flat(flat.data)
+    ref = [torch.empty_like(flat.data) for _ in range(world)]
+    dist.all_gather(ref, flat.data)
+    assert all(torch.equal(ref[0], t) for t in ref)    # everyone holds rank 0's parameters
+
+    g = torch.Generator().manual_seed(7 + rank)
+    local = torch.randn(flat.numel, generator=g)
+    flat.grad.copy_(local)
+    scale = sdist.allreduce_grad(flat.grad)
+    assert scale == 1.0 / world
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    mean = sum(gathered) / world
+    assert torch.allclose(flat.grad * scale, mean, atol=1e-6)
+    # the clip norm every rank would compute is identical (same branch of the NaN guard)
+    norms = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(norms, (flat.grad * scale).norm().reshape(1))
+    assert all(torch.equal(norms[0], n) for n in norms)
+    # parameter views still alias the flat buffer after the collective
+    p = next(model.parameters())
+    assert p.grad.data_ptr() == flat.grad.data_ptr()
+    if rank == 0:
+        with open(out, 'w') as f:
+            f.write('ok')
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gloo_world_size_two(tmp_path):
+    out = os.path.join(str(tmp_path), 'done')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == 'ok'

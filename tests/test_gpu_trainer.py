@@ -1,0 +1,77 @@
+"""BASELINE.json configs[0] end to end on the GPU: ASRTrainer over a 16-utterance
+synthetic 80-dim fbank index (train_batch_size 16, the yaml's model sizes),
+driven exactly as src/train.py drives it: load_data -> set_model -> exec.
+Checks the loss of the first step against the CPU oracle started from the same
+checkpoint, validation (greedy decoding), checkpoints and tracker resume."""
+import json
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import las_oracle as lo
+from test_host_cpu import make_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def config_for(index):
+    return {'asr': {'opt': {'type': 'Adadelta', 'learning_rate': 1.0},
+                    'mdl': {'encoder_state_size': 256, 'mlp_out_size': 128,
+                            'decoder_state_size': 256, 'tf_rate': 1.0, 'feature_dim': 80},
+                    'train_index': index, 'valid_index': index, 'wer_step': 1,
+                    'train_batch_size': 16, 'valid_batch_size': 16, 'n_epochs': 2,
+                    'logging_step': 1, 'save_step': 1, 'valid_step': 2, 'loader_jobs': 0}}
+
+
+def test_asr_trainer_config1_end_to_end(tmp_path):
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_x, prepare_y
+    from ss_asr_amd.trainer import ASRTrainer
+    root = str(tmp_path)
+    index, lens = make_corpus(root, n=16, t_max=96, feat=80, seed=3)
+    paras = types.SimpleNamespace(name='cfg1', logdir=os.path.join(root, 'runs'),
+                                  ckpdir=os.path.join(root, 'result'), verbose=False, seed=1)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = ASRTrainer(config_for(index), paras)
+    tr.load_data()
+    tr.set_model()
+    start = {k: v.detach().cpu().clone() for k, v in tr.asr_model.state_dict().items()}
+    tr.exec()
+    tr.close()
+    torch.cuda.synchronize()
+
+    ckpdir = os.path.join(root, 'result', 'cfg1')
+    assert json.load(open(os.path.join(ckpdir, 'tracker.json')))['asr']['step'] == 2
+    assert os.path.isfile(os.path.join(ckpdir, 'asr.cpt'))
+    assert os.path.isfile(os.path.join(ckpdir, 'asr_best.cpt'))       # valid() ran at step 0
+    assert os.path.isfile(os.path.join(ckpdir, 'best_hyp.txt'))
+    events = [json.loads(l) for l in open(os.path.join(root, 'runs', 'cfg1', 'asr', 'events.jsonl'))]
+    losses = [e['value'] for e in events if e['key'] == 'asr_train_loss']
+    assert len(losses) == 2 and all(np.isfinite(losses))
+    assert any(e['key'] == 'asr_eval_loss' for e in events)
+
+    # first-step loss equals the CPU oracle's from the same weights and batch
+    _, _, loader = load_asr_dataset(index, batch_size=16, n_jobs=0)
+    x, y = next(iter(loader))
+    x, x_lens = prepare_x(x)
+    y, y_lens = prepare_y(y)
+    assert x_lens == lens
+    ref = lo.OracleASR(50, 256, 256, 128, 80, 1.0)
+    ref.load_state_dict(start)
+    ans_len = max(y_lens) - 1
+    _, logits, _ = ref(x[:, :max(x_lens)], ans_len, teacher=y, state_len=x_lens)
+    want = float(lo.masked_ce_loss(logits, y, ans_len))
+    assert abs(losses[0] - want) < 1e-4, (losses[0], want)
+    assert losses[1] < losses[0] + 0.5            # the update did not blow the model up
+
+    # resume: a new trainer picks up the checkpoint and the step counter
+    tr2 = ASRTrainer(config_for(index), paras)
+    assert tr2.tr.step == 2
+    tr2.load_data()
+    tr2.set_model()
+    saved = torch.load(os.path.join(ckpdir, 'asr.cpt'), map_location='cpu')
+    for k, v in tr2.asr_model.state_dict().items():
+        assert torch.equal(v.cpu(), saved[k]), k

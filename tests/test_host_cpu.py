@@ -1,0 +1,202 @@
+"""CPU-only checks (no GPU in the build container): the C-ABI library loads and
+exports every symbol include/ssasr.h declares, the host-side mirrors of the
+reference's data / trainer surface behave like the reference, and the product
+path refuses to compute without a GPU instead of falling back."""
+import ctypes
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ss_asr_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'ssasr.h')).read()
+    declared = set(re.findall(r'\b(?:int|int64_t)\s+(ssasr_\w+)\s*\(', header))
+    assert len(declared) >= 17
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.ssasr_abi_version() == _lib.ABI_VERSION
+    # struct layouts bound by ctypes must match the C declarations field for field
+    for cname, cls in (('ssasr_decoder', _lib.Decoder), ('ssasr_decoder_grads', _lib.DecoderGrads)):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), header, re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        fields = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if decl:
+                fields += [f.strip().lstrip('*').strip() for f in
+                           re.sub(r'^(const\s+)?\w+\s*\**', '', decl, count=1).split(',')]
+        assert fields == [f[0] for f in cls._fields_], cname
+
+
+def test_argument_errors_are_negative_and_need_no_gpu():
+    from ss_asr_amd import _lib
+    lib = _lib.load()
+    assert lib.ssasr_bilstm_fwd(None, 0, 0, 0, 0, 0, 0, None, *([None] * 8), None, 0, 0, None,
+                                None, None, None) < 0
+    assert lib.ssasr_decoder_fwd(None, None) < 0
+    assert lib.ssasr_clip_adadelta_ws(10269874) == 1 + (10269874 + 4095) // 4096
+
+
+def test_ops_refuse_cpu_tensors():
+    from ss_asr_amd import ops
+    from ss_asr_amd.asr import ASR
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+    model = ASR(50, 32, 32, 16, 12, 1.0)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        model(torch.randn(2, 8, 12), 3, teacher=torch.zeros(2, 5, dtype=torch.long),
+              state_len=[8, 8])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'ss_asr_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f), encoding='utf-8').read()
+                assert 'las_oracle' not in text and 'oracle/' not in text, f
+
+
+def test_state_dict_and_seeded_init_match_the_oracle_model():
+    """Same constructor-time RNG consumption and key set as the reference layout."""
+    import las_oracle as lo
+    from ss_asr_amd.asr import ASR
+    torch.manual_seed(7)
+    a = ASR(50, 32, 32, 16, 12, 0.9)
+    torch.manual_seed(7)
+    b = lo.OracleASR(50, 32, 32, 16, 12, 0.9)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    n = sum(p.numel() for p in ASR(50, 256, 256, 128, 80, 0.9).parameters())
+    assert n == 10269874
+
+
+def test_packed_sequence_contract_errors():
+    from ss_asr_amd.asr import _check_lengths
+    _check_lengths([5, 5, 3], 5)
+    with pytest.raises(RuntimeError, match='decreasing'):
+        _check_lengths([3, 5], 5)
+    with pytest.raises(RuntimeError, match='greater than 0'):
+        _check_lengths([3, 0], 5)
+
+
+def test_flat_parameters_keep_values_and_alias_grads():
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.optim import FlatParameters
+    model = ASR(50, 32, 32, 16, 12, 1.0)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    flat = FlatParameters(model)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k])
+    p = next(model.parameters())
+    p.grad.add_(1.0)
+    assert float(flat.grad.sum()) == p.numel()
+    flat.zero_grad()
+    assert float(p.grad.abs().sum()) == 0.0
+    assert all(o % 4 == 0 for o in flat.offsets)
+
+
+# ----------------------------------------------------------------- data ----
+def make_corpus(tmp_path, n=16, t_max=40, feat=80, seed=1):
+    """BASELINE.json configs[0] in miniature: .npy fbanks padded to the corpus
+    maximum (float64, like src/preprocess.py:267) and the 6-column index."""
+    from ss_asr_amd.preprocess import ALL_CHARS
+    rng = np.random.default_rng(seed)
+    lens = sorted(rng.integers(t_max // 2, t_max + 1, size=n).tolist(), reverse=True)
+    lens[0] = t_max
+    rows = []
+    for i, l in enumerate(lens):
+        fb = np.zeros((t_max, feat))
+        fb[:l] = rng.standard_normal((l, feat)).astype(np.float32)
+        path = os.path.join(tmp_path, 'u%03d.npy' % i)
+        np.save(path, fb)
+        text = '<' + ''.join(rng.choice(list(ALL_CHARS), size=int(rng.integers(3, 9)))) + '>'
+        rows.append('\t'.join([text, path, str(len(text)), str(l), 'na', 'u%03d.wav' % i]))
+    index = os.path.join(tmp_path, 'index.tsv')
+    with open(index, 'w', encoding='utf-8') as f:
+        f.write('\n'.join(rows) + '\n')
+    return index, lens
+
+
+def test_dataset_batches_lengths_and_mapper(tmp_path):
+    from ss_asr_amd.ASRDataset import Mapper, load_asr_dataset, prepare_x, prepare_y
+    index, lens = make_corpus(str(tmp_path), n=18)
+    mapper, ds, loader = load_asr_dataset(index, batch_size=8, n_jobs=0)
+    assert mapper.get_dim() == 50 and ds.get_feature_dim() == 80
+    assert len(ds) == 2                      # 18 // 8, remainder dropped (src/ASRDataset.py:63)
+    x, y = next(iter(loader))
+    assert x.shape[:2] == (1, 8) and x.dtype == torch.float64
+    xs, x_lens = prepare_x(x)
+    assert xs.dtype == torch.float32 and x_lens == lens[:8]
+    ys, y_lens = prepare_y(y)
+    assert ys.dtype == torch.long and ys[:, 0].eq(0).all()
+    assert y_lens == [int((row != 0).sum()) + 1 for row in ys]
+    text = ds.get_text(0)
+    assert Mapper().translate(ds.encode(text)) == text[1:-1]
+
+
+def test_postprocess_metrics():
+    from ss_asr_amd.ASRDataset import Mapper
+    from ss_asr_amd.postprocess import calc_acc, calc_err, edit_distance, trim_eos
+    assert edit_distance('kitten', 'sitting') == 3 and edit_distance([], ['a']) == 1
+    assert trim_eos([5, 6, 1, 7]) == [5, 6, 1]
+    label = torch.tensor([[4, 5, 6, 1, 0], [7, 8, 1, 0, 0]])
+    logits = torch.nn.functional.one_hot(torch.tensor([[4, 5, 9, 1, 3], [7, 8, 1, 2, 2]]), 50).float()
+    assert abs(calc_acc(logits, label) - (3 / 4 + 1.0) / 2) < 1e-9
+    assert calc_err(logits, label, Mapper()) == pytest.approx((1.0 + 0.0) / 2)
+
+
+def test_tracker_format_and_resume(tmp_path):
+    from ss_asr_amd.TrackerHandler import TrackerHandler
+    path = os.path.join(str(tmp_path), 'tracker.json')
+    tr = TrackerHandler(path, 'asr')
+    tr.do_step(); tr.do_step(); tr.set_best(3.5)
+    assert json.load(open(path)) == {'asr': {'best': 3.5, 'step': 2}}
+    assert TrackerHandler(path, 'asr').step == 2
+
+
+def test_trainer_plumbing_without_gpu(tmp_path):
+    """Config 1 (16 utterances, batch 16, feature_dim 80) through ASRTrainer up to
+    the first forward, which must refuse to run on the CPU."""
+    from ss_asr_amd.trainer import ASRTrainer
+    if torch.cuda.is_available():
+        pytest.skip('covered by the gpu test')
+    index, _ = make_corpus(str(tmp_path), n=16)
+    config = {'asr': {'opt': {'type': 'Adadelta', 'learning_rate': 1.0},
+                      'mdl': {'encoder_state_size': 32, 'mlp_out_size': 16,
+                              'decoder_state_size': 32, 'tf_rate': 0.9, 'feature_dim': 80},
+                      'train_index': index, 'valid_index': index, 'wer_step': 50,
+                      'train_batch_size': 16, 'valid_batch_size': 16, 'n_epochs': 1,
+                      'loader_jobs': 0}}
+    paras = types.SimpleNamespace(name='t', logdir=os.path.join(str(tmp_path), 'runs'),
+                                  ckpdir=os.path.join(str(tmp_path), 'result'), verbose=False,
+                                  seed=1)
+    tr = ASRTrainer(config, paras)
+    tr.load_data()
+    tr.set_model()
+    assert len(tr.train_set) == 1 and tr.mapper.get_dim() == 50
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        tr.exec()
+
+
+def test_flat_shims_serve_the_reference_entry_point():
+    """src/train.py does `import trainer` and getattr(trainer, 'ASRTrainer')."""
+    flat = os.path.join(ROOT, 'ss_asr_amd', 'flat')
+    code = ("import sys; sys.path.insert(0, %r); import trainer, asr, ASRDataset, preprocess;"
+            "assert trainer.ASRTrainer.__module__ == 'ss_asr_amd.trainer';"
+            "assert asr.ASR and ASRDataset.load_asr_dataset and preprocess.TOKENS == '<>$'" % flat)
+    import subprocess
+    subprocess.run([sys.executable, '-c', code], check=True, cwd=ROOT)
