@@ -91,10 +91,11 @@ int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const float* feat
                               float* dw_psi, float* db_psi, void* stream);
 
 /* One Attention.forward call after the cache exists (src/asr.py:383-390).
- * state [B][D] (NULL = zeros), w_phi_t [D][A] (phi.weight transposed),
- * comp [B][T][A], feat [B][T][E], enc_len int32[B].
- * Outputs: q [B][A] = tanh(phi(state)), att [B][T], ctx [B][E]. */
-int ssasr_attn_step_fwd(const float* state, const float* w_phi_t, const float* comp,
+ * state [B][D], w_phi [A][D] (phi.weight), comp [B][T][A], feat [B][T][E],
+ * enc_len int32[B].  Two launches: q [B][A] = tanh(phi(state)) (small MFMA
+ * kernel), then energies + masked softmax + context: att [B][T], ctx [B][E].
+ * state == NULL skips the first launch and takes q as an input. */
+int ssasr_attn_step_fwd(const float* state, const float* w_phi, const float* comp,
                         const float* feat, const int32_t* enc_len, int64_t B, int64_t T, int64_t A,
                         int64_t E, int64_t D, float* q, float* att, float* ctx, void* stream);
 

@@ -13,25 +13,25 @@
 // the grid is B x nch workgroups; every workgroup re-derives q and the
 // softmax of its utterance (comp is small next to h) and no inter-workgroup
 // exchange is needed.  All global reads are 16-byte per lane and contiguous
-// per half-wave; reductions are wave shuffles plus one LDS hop.
+// per half-wave; reductions are wave shuffles plus one LDS hop.  The phi
+// projection q = tanh(W_phi s) runs as its own small MFMA launch
+// (seg_matmul_plain_kernel with a tanh epilogue): inside this kernel it would
+// re-read the 128 KB weight per workgroup, more than the step's real payload.
 #pragma once
 #include "common.h"
 
 namespace {
 
 struct AttnFwd {
-  const float* s;        // [B][lds] decoder state rows (speller layer-1 h), null => zeros
-  int64_t lds;
-  const float* wphiT;    // [D][A]  phi weight, transposed
+  const float* q;        // [B][A] tanh(phi(state)) from the phi kernel; null => zeros (step 0)
   const float* comp;     // [B][T][A]
   const float* feat;     // [B][T][E]
   const int32_t* lens;   // [B]
-  float* q;              // [B][A] out (saved for backward)
   float* att;            // out: att[b * att_sb + t]
   int64_t att_sb;
   float* ctx;            // out: ctx[b * ctx_ld + e]
   int64_t ctx_ld;
-  int B, T, A, E, D, nch;
+  int B, T, A, E, nch;
 };
 
 __device__ __forceinline__ float block_reduce_sum(float v, float* sm, int nw) {
@@ -55,43 +55,227 @@ __device__ __forceinline__ float block_reduce_max(float v, float* sm, int nw) {
   return t;
 }
 
-// grid (B, nch), 256 threads, dynamic LDS: D + A + T + 1024 + 16 floats
+__device__ __forceinline__ float4 aload4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Fast path: A == 128, E / nch == 128, T <= 128 * NP.  grid (B, nch), 256
+// threads = 8 half-waves; half-wave hw owns rows t = hw + 8 i.  A lane holds 4
+// of the 128 columns of its rows of comp AND of this workgroup's feat slice.
+// Rows are handled in NP passes of 16 per half-wave; for NP == 1 (T <= 128,
+// the training shapes) every global load of the step is issued before any
+// arithmetic, i.e. one memory round trip.  The masked softmax needs one
+// barrier (per-half-wave max / sum pairs combined by every thread), the
+// context one more.  Workgroups of one utterance differ by a multiple of 8 in
+// linear block id, so they tend to share an XCD (and its L2 copy of comp);
+// nothing depends on that.
+template <int NP>
+__global__ __launch_bounds__(256) void attn_step_fwd_fast_kernel(AttnFwd p) {
+  constexpr int RPT = 16;
+  __shared__ __attribute__((aligned(16))) float sRed[8 * 128];
+  __shared__ float sM[8], sS[8];
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const int tid = threadIdx.x, hw = tid >> 5, l32 = tid & 31;
+  const int T = p.T, E = p.E;
+  int len = p.lens ? p.lens[b] : T;
+  len = len < T ? len : T;
+  const float* cb = p.comp + (int64_t)b * T * 128 + 4 * l32;
+  const float* fb = p.feat + (int64_t)b * T * E + chunk * 128 + 4 * l32;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 c[RPT], f[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = hw + 8 * i;
+    c[i] = t < len ? aload4(cb + (int64_t)t * 128) : z4;
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int t = hw + 8 * i;
+    f[i] = t < len ? aload4(fb + (int64_t)t * E) : z4;
+  }
+  const float4 q4 = p.q ? aload4(p.q + (int64_t)b * 128 + 4 * l32) : z4;
+
+  // energies: dot over the 32 lanes of the half-wave
+  float e[RPT * NP];
+  float m = -INFINITY;
+#pragma unroll
+  for (int pz = 0; pz < NP; ++pz) {
+    if (pz > 0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int t = hw + 8 * (i + RPT * pz);
+        c[i] = t < len ? aload4(cb + (int64_t)t * 128) : z4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      float v = c[i].x * q4.x;
+      v = fmaf(c[i].y, q4.y, v);
+      v = fmaf(c[i].z, q4.z, v);
+      v = fmaf(c[i].w, q4.w, v);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      e[pz * RPT + i] = v;
+      if (hw + 8 * (i + RPT * pz) < len) m = fmaxf(m, v);
+    }
+  }
+  float ssum = 0.f;
+#pragma unroll
+  for (int i = 0; i < RPT * NP; ++i) {
+    const float pv = (hw + 8 * i < len) ? __builtin_amdgcn_exp2f((e[i] - m) * 1.4426950408889634f) : 0.f;
+    e[i] = pv;
+    ssum += pv;
+  }
+  if (l32 == 0) { sM[hw] = m; sS[hw] = ssum; }
+  __syncthreads();
+  float gm = sM[0];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) gm = fmaxf(gm, sM[g]);
+  float gs = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+    gs += sS[g] > 0.f ? sS[g] * __builtin_amdgcn_exp2f((sM[g] - gm) * 1.4426950408889634f) : 0.f;
+  // this half-wave's rescale: exp(m - gm) / gs   (m = -inf only when it owns no valid row)
+  const float scale = ssum > 0.f
+      ? __builtin_amdgcn_exp2f((m - gm) * 1.4426950408889634f) * __builtin_amdgcn_rcpf(gs) : 0.f;
+
+  float4 acc = z4;
+#pragma unroll
+  for (int pz = 0; pz < NP; ++pz) {
+    if (pz > 0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int t = hw + 8 * (i + RPT * pz);
+        f[i] = t < len ? aload4(fb + (int64_t)t * E) : z4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const float w = e[pz * RPT + i] * scale;
+      e[pz * RPT + i] = w;
+      acc.x = fmaf(w, f[i].x, acc.x);
+      acc.y = fmaf(w, f[i].y, acc.y);
+      acc.z = fmaf(w, f[i].z, acc.z);
+      acc.w = fmaf(w, f[i].w, acc.w);
+    }
+  }
+  if (chunk == 0 && l32 == 0) {
+#pragma unroll
+    for (int i = 0; i < RPT * NP; ++i) {
+      const int t = hw + 8 * i;
+      if (t < T) p.att[(int64_t)b * p.att_sb + t] = e[i];
+    }
+  }
+  *reinterpret_cast<float4*>(sRed + hw * 128 + 4 * l32) = acc;
+  __syncthreads();
+  if (tid < 128) {
+    float v = sRed[tid];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) v += sRed[g * 128 + tid];
+    p.ctx[(int64_t)b * p.ctx_ld + chunk * 128 + tid] = v;
+  }
+}
+
+// Long encoder outputs (T > 256) with the same lane mapping: rows go through
+// in runtime passes of 128 with the energies / alphas parked in LDS, which
+// keeps the kernel below 256 VGPRs.  (Fully unrolled register variants for
+// NP >= 3 make hipcc spill into AGPRs, and those builds returned wrong
+// alphas on gfx950 / ROCm 7.2; see DESIGN.md.)
+// grid (B, nch), 256 threads, dynamic LDS: T + 1024 + 16 floats
+__global__ __launch_bounds__(256) void attn_step_fwd_long_kernel(AttnFwd p) {
+  constexpr int RPT = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sE = smem;                        // [T]
+  float* sRed = sE + ((p.T + 3) & ~3);     // [1024]
+  float* sW = sRed + 1024;                 // [16]
+  const int b = blockIdx.x, chunk = blockIdx.y;
+  const int tid = threadIdx.x, hw = tid >> 5, l32 = tid & 31;
+  const int T = p.T, E = p.E;
+  int len = p.lens ? p.lens[b] : T;
+  len = len < T ? len : T;
+  const float* cb = p.comp + (int64_t)b * T * 128 + 4 * l32;
+  const float* fb = p.feat + (int64_t)b * T * E + chunk * 128 + 4 * l32;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 q4 = p.q ? aload4(p.q + (int64_t)b * 128 + 4 * l32) : z4;
+#pragma unroll 1
+  for (int t0 = 0; t0 < len; t0 += 8 * RPT) {
+    float4 c[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int t = t0 + hw + 8 * i;
+      c[i] = t < len ? aload4(cb + (int64_t)t * 128) : z4;
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      float v = c[i].x * q4.x;
+      v = fmaf(c[i].y, q4.y, v);
+      v = fmaf(c[i].z, q4.z, v);
+      v = fmaf(c[i].w, q4.w, v);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const int t = t0 + hw + 8 * i;
+      if (l32 == 0 && t < len) sE[t] = v;
+    }
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int t = tid; t < len; t += 256) m = fmaxf(m, sE[t]);
+  m = block_reduce_max(m, sW, 4);
+  float sum = 0.f;
+  for (int t = tid; t < len; t += 256) {
+    const float ev = __builtin_amdgcn_exp2f((sE[t] - m) * 1.4426950408889634f);
+    sE[t] = ev;
+    sum += ev;
+  }
+  sum = block_reduce_sum(sum, sW, 4);
+  const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;
+  for (int t = tid; t < len; t += 256) sE[t] *= inv;
+  __syncthreads();
+  if (chunk == 0)
+    for (int t = tid; t < T; t += 256) p.att[(int64_t)b * p.att_sb + t] = t < len ? sE[t] : 0.f;
+
+  float4 acc = z4;
+#pragma unroll 1
+  for (int t0 = 0; t0 < len; t0 += 8 * RPT) {
+    float4 f[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int t = t0 + hw + 8 * i;
+      f[i] = t < len ? aload4(fb + (int64_t)t * E) : z4;
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int t = t0 + hw + 8 * i;
+      const float w = t < len ? sE[t] : 0.f;
+      acc.x = fmaf(w, f[i].x, acc.x);
+      acc.y = fmaf(w, f[i].y, acc.y);
+      acc.z = fmaf(w, f[i].z, acc.z);
+      acc.w = fmaf(w, f[i].w, acc.w);
+    }
+  }
+  *reinterpret_cast<float4*>(sRed + hw * 128 + 4 * l32) = acc;
+  __syncthreads();
+  if (tid < 128) {
+    float v = sRed[tid];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) v += sRed[g * 128 + tid];
+    p.ctx[(int64_t)b * p.ctx_ld + chunk * 128 + tid] = v;
+  }
+}
+
+// General shapes.  grid (B, nch), 256 threads, dynamic LDS: A + T + 1024 + 16 floats
 __global__ __launch_bounds__(256) void attn_step_fwd_kernel(AttnFwd p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sS = smem;                 // [D]
-  float* sQ = sS + p.D;             // [A]
+  float* sQ = smem;                 // [A]
   float* sE = sQ + p.A;             // [T]
   float* sR = sE + ((p.T + 3) & ~3);  // [1024]
   float* sW = sR + 1024;            // [16]
   const int b = blockIdx.x, chunk = blockIdx.y;
   const int tid = threadIdx.x;
-  const int T = p.T, A = p.A, E = p.E, D = p.D;
+  const int T = p.T, A = p.A, E = p.E;
   int len = p.lens ? p.lens[b] : T;
   len = len < T ? len : T;
 
-  // q = tanh(W_phi s)
-  if (p.s) {
-    for (int k = tid; k < D; k += 256) sS[k] = p.s[(int64_t)b * p.lds + k];
-    __syncthreads();
-    for (int a = tid; a < A; a += 256) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      const float* w = p.wphiT + a;
-      int k = 0;
-      for (; k + 3 < D; k += 4) {
-        a0 = fmaf(w[(int64_t)k * A], sS[k], a0);
-        a1 = fmaf(w[(int64_t)(k + 1) * A], sS[k + 1], a1);
-        a2 = fmaf(w[(int64_t)(k + 2) * A], sS[k + 2], a2);
-        a3 = fmaf(w[(int64_t)(k + 3) * A], sS[k + 3], a3);
-      }
-      for (; k < D; ++k) a0 = fmaf(w[(int64_t)k * A], sS[k], a0);
-      sQ[a] = tanhf((a0 + a1) + (a2 + a3));
-    }
-  } else {
-    for (int a = tid; a < A; a += 256) sQ[a] = 0.f;
-  }
+  for (int a = tid; a < A; a += 256) sQ[a] = p.q ? p.q[(int64_t)b * A + a] : 0.f;
   __syncthreads();
-  if (chunk == 0)
-    for (int a = tid; a < A; a += 256) p.q[(int64_t)b * A + a] = sQ[a];
 
   // energies: half a wave per row of comp
   {
@@ -338,7 +522,8 @@ __global__ void tanh_bwd_kernel(float* dcomp, const float* comp, int64_t n) {
   }
 }
 
-inline size_t attn_fwd_lds(int D, int A, int T) { return sizeof(float) * (size_t)(D + A + ((T + 3) & ~3) + 1024 + 16); }
+inline size_t attn_fwd_long_lds(int T) { return sizeof(float) * (size_t)(((T + 3) & ~3) + 1024 + 16); }
+inline size_t attn_fwd_lds(int A, int T) { return sizeof(float) * (size_t)(A + ((T + 3) & ~3) + 1024 + 16); }
 inline size_t attn_bwd_lds(int E, int T) { return sizeof(float) * (size_t)(E + ((T + 3) & ~3) + 2048 + 16); }
 
 inline int attn_pick_nch(int E) {

@@ -65,8 +65,23 @@ bool attn_dims_ok(int64_t B, int64_t T, int64_t A, int64_t E, int64_t D) {
 }
 
 int launch_attn_fwd(const AttnFwd& p, hipStream_t st) {
-  hipLaunchKernelGGL(attn_step_fwd_kernel, dim3((unsigned)p.B, (unsigned)p.nch), dim3(256),
-                     attn_fwd_lds(p.D, p.A, p.T), st, p);
+  const dim3 grid((unsigned)p.B, (unsigned)p.nch), block(256);
+  const bool fast = p.A == 128 && p.E == 128 * p.nch && aligned16(p.comp) && aligned16(p.feat) &&
+                    (!p.q || aligned16(p.q));
+  if (fast && p.T <= 128) hipLaunchKernelGGL(attn_step_fwd_fast_kernel<1>, grid, block, 0, st, p);
+  else if (fast && p.T <= 256) hipLaunchKernelGGL(attn_step_fwd_fast_kernel<2>, grid, block, 0, st, p);
+  else if (fast) hipLaunchKernelGGL(attn_step_fwd_long_kernel, grid, block, attn_fwd_long_lds(p.T), st, p);
+  else hipLaunchKernelGGL(attn_step_fwd_kernel, grid, block, attn_fwd_lds(p.A, p.T), st, p);
+  return SSASR_OK;
+}
+
+// q[B][A] = tanh(state[B][D] . w_phi[A][D]^T)   (src/asr.py:383)
+int launch_phi(const float* state, const float* w_phi, float* q, int64_t B, int64_t A, int64_t D,
+               hipStream_t st) {
+  PlainMm pm{};
+  seg_set(pm.sl, 0, state, D, w_phi, D, (int)D);
+  pm.out = q; pm.ldo = (int)A; pm.N = (int)B; pm.R = (int)A; pm.act = 1;
+  hipLaunchKernelGGL(seg_matmul_plain_kernel, plain_mm_grid(A, B), dim3(256), 0, st, pm);
   return SSASR_OK;
 }
 
@@ -77,16 +92,18 @@ int launch_attn_bwd(const AttnBwd& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int ssasr_attn_step_fwd(const float* state, const float* w_phi_t, const float* comp,
+extern "C" int ssasr_attn_step_fwd(const float* state, const float* w_phi, const float* comp,
                                    const float* feat, const int32_t* enc_len, int64_t B, int64_t T,
                                    int64_t A, int64_t E, int64_t D, float* q, float* att,
                                    float* ctx, void* stream) {
-  if (!w_phi_t || !comp || !feat || !q || !att || !ctx || !attn_dims_ok(B, T, A, E, D)) return SSASR_EARG;
+  if (!w_phi || !comp || !feat || !q || !att || !ctx || !attn_dims_ok(B, T, A, E, D)) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (state) launch_phi(state, w_phi, q, B, A, D, st);   // state == NULL: q is an input
   AttnFwd p{};
-  p.s = state; p.lds = D; p.wphiT = w_phi_t; p.comp = comp; p.feat = feat; p.lens = enc_len;
-  p.q = q; p.att = att; p.att_sb = T; p.ctx = ctx; p.ctx_ld = E;
-  p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.D = (int)D; p.nch = attn_pick_nch((int)E);
-  launch_attn_fwd(p, (hipStream_t)stream);
+  p.q = q; p.comp = comp; p.feat = feat; p.lens = enc_len;
+  p.att = att; p.att_sb = T; p.ctx = ctx; p.ctx_ld = E;
+  p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.nch = attn_pick_nch((int)E);
+  launch_attn_fwd(p, st);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
@@ -125,7 +142,8 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   if (any_teacher && (!d.teacher || d.teacher_ld < U + 1)) return SSASR_EARG;
   if (any_sample && !d.uniforms) return SSASR_EARG;
 
-  if ((rc = ssasr_launch_transpose(d.w_phi, d.w_phi_t, (int)A, (int)D, st))) return rc;
+  if ((rc = ssasr_launch_transpose(d.w_phi, d.w_phi_t, (int)A, (int)D, st))) return rc;   // for backward
+  SSASR_HIP(hipMemsetAsync(d.q, 0, sizeof(float) * B * A, st));                            // q_0 = 0
 
   // chars[0] = <sos> = 0 (src/asr.py:73); chars[t] = teacher[:, t] (src/asr.py:95).
   // Steps that are not teacher forced overwrite their successor's entry in the loop.
@@ -143,12 +161,14 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   const int nch = attn_pick_nch((int)E);
   dim3 cgrid = cell_fwd_grid(D, 1, B), cblock(256);
   for (int64_t t = 0; t < U; ++t) {
+    // q_t = tanh(phi(h1_{t-1})); the state is zero at t = 0 and phi has no bias
+    if (t) launch_phi(d.h1 + (t - 1) * B * D, d.w_phi, d.q + t * B * A, B, A, D, st);
     AttnFwd p{};
-    p.s = t ? d.h1 + (t - 1) * B * D : nullptr; p.lds = D;
-    p.wphiT = d.w_phi_t; p.comp = d.comp; p.feat = d.feat; p.lens = d.enc_len;
-    p.q = d.q + t * B * A; p.att = d.att + t * T; p.att_sb = U * T;
+    p.q = t ? d.q + t * B * A : nullptr;
+    p.comp = d.comp; p.feat = d.feat; p.lens = d.enc_len;
+    p.att = d.att + t * T; p.att_sb = U * T;
     p.ctx = d.ctx + t * B * E; p.ctx_ld = E;
-    p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.D = (int)D; p.nch = nch;
+    p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.nch = nch;
     launch_attn_fwd(p, st);
 
     CellFwdPair c1{};
@@ -310,7 +330,7 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     PlainMm pm{};
     pm.sl.nseg = 1;
     seg_set(pm.sl, 0, d.gates1 + t * B * 4 * D, 4 * D, g.ws_t_ih1 + D * 4 * D, 4 * D, (int)(4 * D));
-    pm.out = g.ws_dctx + t * B * E; pm.ldo = E; pm.N = (int)B; pm.R = (int)E;
+    pm.out = g.ws_dctx + t * B * E; pm.ldo = (int)E; pm.N = (int)B; pm.R = (int)E; pm.act = 0;
     hipLaunchKernelGGL(seg_matmul_plain_kernel, plain_mm_grid(E, B),
                        dim3(256), 0, st, pm);
 

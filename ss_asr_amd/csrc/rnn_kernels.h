@@ -450,8 +450,9 @@ __global__ __launch_bounds__(256) void lstm_enc_bwd_kernel(EncBwd e, int i) {
 struct PlainMm {
   SegList sl;
   float* out;
-  int64_t ldo;
+  int ldo;
   int N, R;   // R = number of output columns (weight rows)
+  int act;    // 0 none, 1 tanh
 };
 
 // grid (ceil(R/16), 1, ceil(N/16)), 256 threads
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(256) void seg_matmul_plain_kernel(PlainMm pa) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int u = 16 * tile + 4 * q + e;
-    if (u < a.R) a.out[(int64_t)n * a.ldo + u] = v[e];
+    if (u < a.R) a.out[(int64_t)n * a.ldo + u] = a.act ? tanhf(v[e]) : v[e];
   }
 }
 

@@ -173,11 +173,10 @@ class _AttnStep(torch.autograd.Function):
         state, w_phi, comp, feat = _f32c(state), _f32c(w_phi), _f32c(comp), _f32c(feat)
         B, T, E = feat.shape
         A, D = w_phi.shape
-        w_phi_t = w_phi.t().contiguous()
         q = torch.empty(B, A, device=feat.device)
         att = torch.empty(B, T, device=feat.device)
         cx = torch.empty(B, E, device=feat.device)
-        check(lib.ssasr_attn_step_fwd(_p(state), _p(w_phi_t), _p(comp), _p(feat), _p(enc_len), B, T,
+        check(lib.ssasr_attn_step_fwd(_p(state), _p(w_phi), _p(comp), _p(feat), _p(enc_len), B, T,
                                       A, E, D, _p(q), _p(att), _p(cx), _stream()),
               'ssasr_attn_step_fwd')
         ctx.save_for_backward(state, w_phi, comp, feat, enc_len, q, att)

@@ -23,7 +23,8 @@ def close(got, want, atol, what=''):
     want = want.detach().double().cpu()
     assert got.shape == want.shape, (what, got.shape, want.shape)
     err = (got - want).abs().max().item()
-    assert err <= atol, '%s: max abs err %.3e > %.1e' % (what, err, atol)
+    tol = atol * max(1.0, want.abs().max().item())     # absolute for O(1) data, relative above
+    assert err <= tol, '%s: max abs err %.3e > %.1e' % (what, err, tol)
 
 
 # ----------------------------------------------------------------- GEMM ----
