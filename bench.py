@@ -132,7 +132,7 @@ def lstm_step_roofline(device, N=32, H=256, iters=400):
 
     def run():
         lib.ssasr_bilstm_fwd(p(x), N * I, I, S, N, I, H, None, *[p(t) for t in w], p(y), N * 2 * H, 2 * H,
-                             p(gates), p(cs), p(hs), st)
+                             p(gates), p(cs), p(hs), None, None, st)
     run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = max(1, iters // S)

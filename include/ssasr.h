@@ -48,12 +48,17 @@ int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
  * produce zeros in y (pad_packed_sequence, src/asr.py:417).
  * y element (s, n, d * H + u) at y[s * ys_s + n * ys_n + d * H + u].
  * Saved for backward: gates [2][S*N][4H], cs [2][S*N][H], hs [2][S*N][H].
+ * Optional workspaces that enable the single-launch persistent recurrence
+ * (taken when H % 64 == 0 and N <= 64): hx [2][S][H/4][roundup(N,8)][4] floats
+ * and sync_ws int32[8] (sync_ws[4] != 0 afterwards reports an exchange
+ * timeout); pass NULL for one launch per step.
  * Replaces: pBLSTM.forward / nn.LSTM, src/asr.py:406-427, :262. */
 int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
                      int64_t H, const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
                      const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,
                      const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* y,
-                     int64_t ys_s, int64_t ys_n, float* gates, float* cs, float* hs, void* stream);
+                     int64_t ys_s, int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
+                     int32_t* sync_ws, void* stream);
 
 /* Backward of ssasr_bilstm_fwd.  `gates` is consumed (overwritten with the
  * gate pre-activation derivatives).  dx may be NULL.  db_* is the derivative

@@ -8,7 +8,7 @@
 // input gradient of those layers and of the speller cells.
 //
 // Tiling: 256 threads = 4 waves in a 2x2 grid; block tile BM x BN (128x128 or
-// 64x64), K step 16.  Tiles are staged global -> registers -> LDS with one
+// 64x64), K step 32 per barrier.  Tiles are staged global -> registers -> LDS with one
 // barrier per K step (two LDS buffers); the next tile's global loads are in
 // flight while the current one feeds the MFMAs.  Either operand may be stored
 // with K contiguous or with its M/N index contiguous; the LDS image keeps the
@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;        // K depth per barrier: two 16-deep MFMA sub-steps
 constexpr int LDK = BK + 4;   // K-contiguous LDS image: [rows][LDK]
 
 template <int BMN, bool T>
@@ -46,8 +46,8 @@ __device__ __forceinline__ void load_tile(const Operand& op, int mn0, int k0, in
     const int f = tid + i * 256;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (!T) {
-      const int row = mn0 + (f >> 2);
-      const int k = k0 + (f & 3) * 4;
+      const int row = mn0 + f / (BK / 4);
+      const int k = k0 + (f % (BK / 4)) * 4;
       if (row < op.extent && k < kend) {
         const float* src = op.p + rm_off(op.m, row) + k;
         if (op.vec && k + 3 < kend) {
@@ -86,7 +86,7 @@ __device__ __forceinline__ void store_tile(float* lds, int tid,
   for (int i = 0; i < TileGeom<BMN, T>::NV; ++i) {
     const int f = tid + i * 256;
     if constexpr (!T) {
-      *reinterpret_cast<float4*>(lds + (f >> 2) * LDK + (f & 3) * 4) = v[i];
+      *reinterpret_cast<float4*>(lds + (f / (BK / 4)) * LDK + (f % (BK / 4)) * 4) = v[i];
     } else {
       constexpr int PER_ROW = BMN / 4;
       *reinterpret_cast<float4*>(lds + (f / PER_ROW) * TileGeom<BMN, T>::LDM + (f % PER_ROW) * 4) = v[i];
@@ -94,14 +94,14 @@ __device__ __forceinline__ void store_tile(float* lds, int tid,
   }
 }
 
-// Fragment of one 16-wide slice for the four MFMAs of a K step.
+// Fragment of one 16-wide slice for the four MFMAs of 16-deep sub-step ks.
 template <int BMN, bool T>
-__device__ __forceinline__ float4 read_frag(const float* lds, int base, int r, int q) {
+__device__ __forceinline__ float4 read_frag(const float* lds, int base, int r, int q, int ks) {
   if constexpr (!T) {
-    return *reinterpret_cast<const float4*>(lds + (base + r) * LDK + 4 * q);
+    return *reinterpret_cast<const float4*>(lds + (base + r) * LDK + 16 * ks + 4 * q);
   } else {
     constexpr int LDM = TileGeom<BMN, T>::LDM;
-    const float* p = lds + (4 * q) * LDM + base + r;
+    const float* p = lds + (16 * ks + 4 * q) * LDM + base + r;
     return make_float4(p[0], p[LDM], p[2 * LDM], p[3 * LDM]);
   }
 }
@@ -156,25 +156,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
     }
     const float* curA = lds + buf * STAGE;
     const float* curB = curA + GA::FLOATS;
-    float4 fa[TM], fb[TN];
+    // Both sub-steps' fragments are read up front (one LDS wait per K step) and
+    // the next tile goes to the other LDS stage between the two MFMA blocks, so
+    // that only the barrier itself separates consecutive K steps.
+    float4 fa[BK / 16][TM], fb[BK / 16][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[i] = read_frag<BM, TA>(curA, wm * WM + i * 16, r, q);
+    for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = read_frag<BN, TB>(curB, wn * WN + j * 16, r, q);
+      for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<BM, TA>(curA, wm * WM + i * 16, r, q, ks);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-      }
+      for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<BN, TB>(curB, wn * WN + j * 16, r, q, ks);
+    }
+#define SSASR_GEMM_STEP(KS, C)                                                          \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[KS][i].C, fb[KS][j].C, acc[i][j], 0, 0, 0)
+    SSASR_GEMM_STEP(0, x);
+    SSASR_GEMM_STEP(0, y);
+    SSASR_GEMM_STEP(0, z);
+    SSASR_GEMM_STEP(0, w);
     if (more) {
       float* nxt = lds + (buf ^ 1) * STAGE;
       store_tile<BM, TA>(nxt, tid, ra);
       store_tile<BN, TB>(nxt + GA::FLOATS, tid, rb);
     }
+    SSASR_GEMM_STEP(1, x);
+    SSASR_GEMM_STEP(1, y);
+    SSASR_GEMM_STEP(1, z);
+    SSASR_GEMM_STEP(1, w);
+#undef SSASR_GEMM_STEP
     __syncthreads();
     buf ^= 1;
   }

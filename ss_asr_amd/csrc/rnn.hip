@@ -1,5 +1,6 @@
 // Host entry points for the BiLSTM layers and the single LSTM cell step.
 // Kernels: rnn_kernels.h.
+#include <cstdlib>
 #include "rnn_kernels.h"
 
 int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st) {
@@ -27,7 +28,8 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
                                 const float* w_ih_f, const float* w_hh_f, const float* b_ih_f,
                                 const float* b_hh_f, const float* w_ih_r, const float* w_hh_r,
                                 const float* b_ih_r, const float* b_hh_r, float* y, int64_t ys_s,
-                                int64_t ys_n, float* gates, float* cs, float* hs, void* stream) {
+                                int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
+                                int32_t* sync_ws, void* stream) {
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
   if (!x || !y || !gates || !cs || !hs) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
@@ -53,6 +55,38 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   // (2) the recurrence, one launch per step, both directions per launch
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31) || rows * 4 * H >= (1ll << 40)) return SSASR_EARG;
   if (!aligned16(w_hh_f) || !aligned16(w_hh_r) || !aligned16(hs)) return SSASR_EARG;   // 16-byte loads
+  // One persistent launch when the whole grid is certain to be resident
+  // (rnn_kernels.h, "persistent forward recurrence"); else one launch per step.
+  {
+    const int64_t chunks = (N + 31) / 32, Np = (N + 7) & ~(int64_t)7;
+    const int kpw = (int)(H / 64);
+    const bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
+                      chunks <= 2 && (H / 4) * 2 * chunks <= 256 && S * Np * H * 4 < (1ll << 31) &&
+                      aligned16(hx) && !getenv("SSASR_NO_PERSISTENT");
+    if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
+    if (fits) {
+      EncPersist p{};
+      p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
+      p.gates = gates; p.cs = cs; p.hs = hs; p.hx = hx; p.y = y; p.lens = lens;
+      p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
+      p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
+      dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(256);
+      const bool fenced = getenv("SSASR_PERSISTENT_FENCED") != nullptr;   // diagnostic: release/acquire form
+      if (fenced) {
+        if (kpw == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<1, true>), pgrid, pblock, 0, st, p);
+        else if (kpw == 2) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<2, true>), pgrid, pblock, 0, st, p);
+        else if (kpw == 4) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
+        else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<8, true>), pgrid, pblock, 0, st, p);
+      } else {
+        if (kpw == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<1, false>), pgrid, pblock, 0, st, p);
+        else if (kpw == 2) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<2, false>), pgrid, pblock, 0, st, p);
+        else if (kpw == 4) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, false>), pgrid, pblock, 0, st, p);
+        else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<8, false>), pgrid, pblock, 0, st, p);
+      }
+      SSASR_LAUNCH_CHECK();
+      return SSASR_OK;
+    }
+  }
   EncFwd e{};
   e.whh[0] = w_hh_f; e.whh[1] = w_hh_r;
   e.gates = gates; e.cs = cs; e.hs = hs; e.y = y; e.lens = lens;

@@ -63,6 +63,28 @@ struct SegList {
   ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, ACC, 0, 0, 0);       \
   ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, ACC, 0, 0, 0)
 
+// MFMAs of one group of k-blocks.  A dependent 16x16x4 f32 MFMA needs 40 cycles,
+// an independent one 32, so consecutive instructions alternate between the
+// accumulator chains (2 * NB of them) instead of running x,y,z,w on one.
+template <int NB, int UN>
+__device__ __forceinline__ void seg_group_mma(f32x4 (&acc)[NB], f32x4 (&acc2)[NB], const float4 (&a)[UN],
+                                              const float4 (&b)[UN][NB], int n) {
+#define SSASR_GROUP_STEP(C)                                                                        \
+  _Pragma("unroll") for (int u = 0; u < UN; u += 2) {                                              \
+    _Pragma("unroll") for (int t = 0; t < NB; ++t) {                                               \
+      if (u < n) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].C, b[u][t].C, acc[t], 0, 0, 0); \
+      if (u + 1 < UN && u + 1 < n)                                                                 \
+        acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u + 1 < UN ? u + 1 : u].C,                \
+                                                       b[u + 1 < UN ? u + 1 : u][t].C, acc2[t], 0, 0, 0); \
+    }                                                                                              \
+  }
+  SSASR_GROUP_STEP(x)
+  SSASR_GROUP_STEP(y)
+  SSASR_GROUP_STEP(z)
+  SSASR_GROUP_STEP(w)
+#undef SSASR_GROUP_STEP
+}
+
 // D[16 x 16*NB] = sum over segments of W[row, :] . X[n, :]^T for one 16-row
 // weight tile and NB tiles of 16 batch columns.  The four waves split K in
 // interleaved 16-deep blocks and combine through LDS.  On return
@@ -81,9 +103,9 @@ __device__ __forceinline__ void seg_matmul_tile(const SegList& sl, int64_t wrow_
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
-  f32x4 acc[NB];
+  f32x4 acc[NB], acc2[NB];      // two chains per tile: even / odd k-blocks
 #pragma unroll
-  for (int t = 0; t < NB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NB; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   if (sl.allvec) {
     // Addressing is kept off the vector ALU: a wave-uniform base pointer per
@@ -122,11 +144,7 @@ __device__ __forceinline__ void seg_matmul_tile(const SegList& sl, int64_t wrow_
         SSASR_STAMP(1);
         SSASR_STAMP_DRAIN();
         SSASR_STAMP(2);
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-#pragma unroll
-          for (int t = 0; t < NB; ++t) { SSASR_MFMA4(acc[t], a[u], b[u][t]); }
-        }
+        seg_group_mma<NB, UN>(acc, acc2, a, b, UN);
       }
       if (j0 < cnt) {                                   // tail group (uniform guards)
         float4 a[UN], b[UN][NB];
@@ -141,13 +159,7 @@ __device__ __forceinline__ void seg_matmul_tile(const SegList& sl, int64_t wrow_
             for (int t = 0; t < NB; ++t) b[u][t] = *reinterpret_cast<const float4*>(xg + xo[t] + u * 256);
           }
         }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          if (u < rem) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t) { SSASR_MFMA4(acc[t], a[u], b[u][t]); }
-          }
-        }
+        seg_group_mma<NB, UN>(acc, acc2, a, b, rem);
       }
     }
   } else {
@@ -172,7 +184,7 @@ __device__ __forceinline__ void seg_matmul_tile(const SegList& sl, int64_t wrow_
   }
   SSASR_STAMP(3);
 #pragma unroll
-  for (int t = 0; t < NB; ++t) red[(wave * NB + t) * 64 + lane] = acc[t];
+  for (int t = 0; t < NB; ++t) red[(wave * NB + t) * 64 + lane] = acc[t] + acc2[t];
   __syncthreads();
   SSASR_STAMP(4);
 }
@@ -235,6 +247,7 @@ __device__ __forceinline__ void cell_fwd_body(const CellFwd& a, f32x4* red) {
     if (a.lens) live = a.s < a.lens[n];
   }
 
+  SSASR_STAMP(7);
   // tile row r <-> (unit 4*tile + (r >> 2), gate r & 3); PyTorch row = gate*H + unit
   const int urow = 4 * tile + (r >> 2);
   seg_matmul_tile<FWD_NB, FWD_UN>(a.sl, (int64_t)(r & 3) * H + urow, urow < H, n0, N, red);
@@ -304,7 +317,183 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_kernel(EncFwd e, int i) {
   a.h_out = hd + s * N * H;
   a.y = e.y + s * e.ys_s + d * H; a.ys_n = e.ys_n;
   a.lens = e.lens; a.s = (int)s; a.N = e.N; a.H = e.H;
+  SSASR_STAMP(6);
   cell_fwd_body(a, red);
+}
+
+// ---------------------- persistent forward recurrence ----------------------
+// One launch for all S steps of a layer (both directions).  What the per-step
+// launches pay every step and this kernel pays once: the kernel boundary
+// (~1.5 us GPU side), the descriptor fetch, and above all re-reading the W_hh
+// slice (in-kernel stamps: ~1.9K cycles to issue and ~2.7K to receive 48 KB per
+// workgroup per step).  Here the slice lives in registers; per step a
+// workgroup reads only h_{s-1}.
+//
+// Exchange of h between the H/4 workgroups of one (direction, column chunk)
+// group follows MI355X_MICROARCH.md "Valid forms" (third table row) and
+// cdna_hip_programming.md Guideline 16: the payload is stored write-through
+// (sc1 buffer stores, every 128-byte line written whole by one store
+// instruction of one wave: the exchange image is [step][unit tile][column][4]),
+// the storing wave drains its stores (s_waitcnt vmcnt(0)) and then one lane
+// adds 1 to the group's monotonic arrival counter (agent-scope atomic); a
+// consumer polls that counter with relaxed agent-scope loads until it reaches
+// (H/4) * step, passes a workgroup barrier, and reads the payload with sc1
+// buffer loads only (L1 is bypassed; no acquire fence needed).  Every step
+// uses fresh addresses; counters are zeroed by a memset node before launch.
+// Correctness does not depend on placement; progress needs every workgroup
+// of a group resident, which the host guarantees by only taking this path for
+// grids of at most 256 workgroups of 256 threads (<= 256 VGPRs: two such
+// workgroups fit one CU, so 128 free CUs suffice).  Spins are bounded; a
+// timeout sets *status and the kernel still terminates.
+struct EncPersist {
+  const float* whh[2];   // [4H][H] per direction
+  float* gates;          // [2][S*N][4H]
+  float* cs;             // [2][S*N][H]
+  float* hs;             // [2][S*N][H]   row-major copy (operand of dW_hh)
+  float* hx;             // [2][S][H/4][Np][4] exchange image, Np = N rounded up to 8
+  float* y;
+  const int32_t* lens;
+  unsigned* cnt;         // [2][chunks] arrival counters, zero at launch
+  int* status;           // set to 1 if a spin timed out
+  int ys_s, ys_n;
+  int S, N, H;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned PERSIST_MAX_SPINS = 1u << 20;   // ~ a second of polling, then give up for good
+
+template <int KPW, bool FENCED>   // k-blocks per wave = H / 64; FENCED: release/acquire form
+__global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * FWD_NB * 64];
+  __shared__ __attribute__((aligned(16))) float sH[32 * 4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
+  const int S = e.S, N = e.N, H = e.H;
+  const int n0 = chunk * 32;
+  const int Np = (N + 7) & ~7;                 // image columns: 128-byte lines never shared by two tiles
+  const unsigned ntile = gridDim.x;
+  const int64_t rows = (int64_t)S * N;
+  unsigned* cnt = e.cnt + d * gridDim.z + chunk;
+
+  // this wave's share of the weight tile, resident for the whole layer
+  float4 wreg[KPW];
+  {
+    const int wrow = (r & 3) * H + 4 * tile + (r >> 2);     // gate-major PyTorch row
+    const float* wp = e.whh[d] + (int64_t)wrow * H + 4 * q;
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) wreg[j] = *reinterpret_cast<const float4*>(wp + (wave + 4 * j) * 16);
+  }
+
+  const int bt = wave;                          // epilogue role of waves 0 and 1
+  const int u = 4 * tile + q;
+  const int n = n0 + 16 * bt + r;
+  const bool epi = bt < FWD_NB && n < N;
+  float cstate = 0.f;
+  bool broken = false;       // a timed-out workgroup stops waiting (results are then invalid)
+  const int len = (epi && e.lens) ? e.lens[n] : 0x7fffffff;
+
+  float* gbase = e.gates + (int64_t)d * rows * 4 * H;
+  float* cbase = e.cs + (int64_t)d * rows * H;
+  float* hbase = e.hs + (int64_t)d * rows * H;
+  const size_t xbytes = (size_t)S * Np * H * sizeof(float);
+  float* xbase = e.hx + (int64_t)d * S * Np * H;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)xbytes, 0x00020000);
+  unsigned xo[FWD_NB];                           // lane part of the h_{s-1} operand address
+#pragma unroll
+  for (int t = 0; t < FWD_NB; ++t) {
+    const int nn = n0 + 16 * t + r;
+    xo[t] = (unsigned)((q * Np + (nn < N ? nn : 0)) * 16);
+  }
+
+  for (int i = 0; i < S; ++i) {
+    const int s = d ? S - 1 - i : i;
+    const int sp = d ? s + 1 : s - 1;
+    const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u;
+    float add[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) add[g] = gbase[g0 + (int64_t)g * H];
+    }
+    f32x4 acc[FWD_NB], acc2[FWD_NB];
+#pragma unroll
+    for (int t = 0; t < FWD_NB; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (i > 0) {
+      if (tid == 0 && !broken) {
+        const unsigned target = ntile * (unsigned)i;
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; broken = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (FENCED) {
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      float4 b[KPW][FWD_NB];
+      u32x4 raw[KPW][FWD_NB];
+      const unsigned sbase = (unsigned)((int64_t)sp * Np * H * 4);   // step offset in bytes
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+        const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);  // 4 unit tiles per k-block
+#pragma unroll
+        for (int t = 0; t < FWD_NB; ++t)
+          raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, FENCED ? 0 : 16);
+      }
+      // NB: convert the whole vector at once; __builtin_bit_cast on a single
+      // ext-vector element (v.y) silently reads element 0 with this compiler.
+#pragma unroll
+      for (int j = 0; j < KPW; ++j) {
+#pragma unroll
+        for (int t = 0; t < FWD_NB; ++t) {
+          const f32x4 f = __builtin_bit_cast(f32x4, raw[j][t]);
+          b[j][t] = make_float4(f[0], f[1], f[2], f[3]);
+        }
+      }
+      seg_group_mma<FWD_NB, KPW>(acc, acc2, wreg, b, KPW);
+    }
+#pragma unroll
+    for (int t = 0; t < FWD_NB; ++t) red[(wave * FWD_NB + t) * 64 + lane] = acc[t] + acc2[t];
+    __syncthreads();
+    if (epi) {
+      const f32x4 p = red_sum<FWD_NB>(red, bt, lane);
+      float gi = fast_sigmoid(p[0] + add[0]), gf = fast_sigmoid(p[1] + add[1]);
+      float gg = fast_tanh(p[2] + add[2]), go = fast_sigmoid(p[3] + add[3]);
+      float c = gf * cstate + gi * gg;
+      float h = go * fast_tanh(c);
+      if (s >= len) { gi = gf = gg = go = 0.f; c = 0.f; h = 0.f; }
+      cstate = c;
+      sH[(16 * bt + r) * 4 + q] = h;
+      gbase[g0] = gi;
+      gbase[g0 + H] = gf;
+      gbase[g0 + 2 * (int64_t)H] = gg;
+      gbase[g0 + 3 * (int64_t)H] = go;
+      const int64_t hu = ((int64_t)s * N + n) * H + u;
+      cbase[hu] = c;
+      hbase[hu] = h;
+      e.y[(int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + u] = h;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      if (lane < 32 && n0 + lane < Np) {
+        const float4 hv = n0 + lane < N ? *reinterpret_cast<const float4*>(sH + lane * 4)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        u32x4 pv = {__builtin_bit_cast(unsigned, hv.x), __builtin_bit_cast(unsigned, hv.y),
+                    __builtin_bit_cast(unsigned, hv.z), __builtin_bit_cast(unsigned, hv.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
+                                               (int)((int64_t)s * Np * H * 4), FENCED ? 0 : 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (FENCED) {
+        if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ------------------------------- backward --------------------------------
@@ -442,6 +631,7 @@ __global__ __launch_bounds__(256) void lstm_enc_bwd_kernel(EncBwd e, int i) {
   a.c = cd + s * N * H;
   a.dc_out = dcb + ((i + 1) & 1) * N * H;
   a.lens = e.lens; a.s = (int)s; a.N = e.N; a.H = e.H;
+  SSASR_STAMP(6);
   cell_bwd_body(a, red);
 }
 

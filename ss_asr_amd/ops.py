@@ -12,6 +12,18 @@ from . import _lib
 from ._lib import check
 
 
+_persist_status = []     # int32[8] workspaces of persistent launches not yet checked
+
+
+def check_persistent_status():
+    """Raises if any persistent recurrence launched since the last call timed
+    out waiting for its peers (synchronises the device)."""
+    global _persist_status
+    pending, _persist_status = _persist_status, []
+    if pending and any(int(v) for v in torch.stack([t[4] for t in pending]).cpu()):
+        raise RuntimeError('ssasr_bilstm_fwd: persistent recurrence timed out')
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -86,9 +98,15 @@ class _BiLSTM(torch.autograd.Function):
         gates = torch.empty(2, S * N, 4 * H, device=x.device, dtype=torch.float32)
         cs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         hs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
+        # workspaces of the persistent recurrence (exchange image + counters)
+        hx = torch.empty(2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4, device=x.device,
+                         dtype=torch.float32) if N <= 64 and H % 64 == 0 else None
+        sync = torch.empty(8, device=x.device, dtype=torch.int32) if hx is not None else None
         check(lib.ssasr_bilstm_fwd(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
-                                   _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _stream()),
-              'ssasr_bilstm_fwd')
+                                   _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
+                                   _stream()), 'ssasr_bilstm_fwd')
+        if sync is not None:
+            _persist_status.append(sync)
         ctx.save_for_backward(x, lens, gates, cs, hs, *w)
         ctx.geom = (S, N, I, H, xs_s, xs_n, ys_s, ys_n, bool(batch_first))
         return y

@@ -15,7 +15,6 @@ __device__ unsigned long long g_stamp[8 * 4096];
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %d at %s:%d\n", e, __FILE__, __LINE__); return 1; } } while (0)
 
-__global__ void empty_kernel(CellFwdPair pr) { if (pr.d[0].N < 0) pr.d[0].c_out[0] = 1.f; }
 __global__ void tiny_kernel(int x, float* p) { if (x < 0) p[0] = 1.f; }
 
 int main(int argc, char** argv) {
@@ -39,70 +38,55 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int64_t ys_s = N * 2 * H, ys_n = 2 * H;
 
-  auto fwd_args = [&](int64_t i) {
-    CellFwdPair pr;
-    for (int d = 0; d < 2; ++d) {
-      const int64_t s = d ? S - 1 - i : i, sp = d ? s + 1 : s - 1;
-      CellFwd& c = pr.d[d]; c = CellFwd{};
-      float* gd = gates + (d * rows + s * N) * 4 * H; float* cd = cs + d * rows * H; float* hd = hs + d * rows * H;
-      if (i > 0) { c.sl.nseg = 1; seg_set(c.sl, 0, hd + sp * N * H, H, whh + d * 4 * H * H, H, (int)H); c.c_prev = cd + sp * N * H; }
-      c.pre = gd; c.gates = gd; c.c_out = cd + s * N * H; c.h_out = hd + s * N * H;
-      c.y = y + s * ys_s + d * H; c.ys_n = ys_n; c.s = (int)s; c.N = (int)N; c.H = (int)H;
-    }
-    return pr;
-  };
-  auto bwd_args = [&](int64_t i) {
-    CellBwdPair pr;
-    for (int d = 0; d < 2; ++d) {
-      const int64_t s = d ? i : S - 1 - i, sn = d ? s - 1 : s + 1, sp = d ? s + 1 : s - 1;
-      const bool has_prev = d ? (s < S - 1) : (s > 0);
-      CellBwd& c = pr.d[d]; c = CellBwd{};
-      float* gd = gates + d * rows * 4 * H; const float* cd = cs + d * rows * H; float* dcb = dc + d * 2 * N * H;
-      if (i > 0) { c.sl.nseg = 1; seg_set(c.sl, 0, gd + sn * N * 4 * H, 4 * H, whhT + d * 4 * H * H, 4 * H, (int)(4 * H)); c.dc_in = dcb + (i & 1) * N * H; }
-      c.add1 = dy + s * ys_s + d * H; c.ld1 = ys_n;
-      c.gates = gd + s * N * 4 * H; c.dgates = gd + s * N * 4 * H;
-      c.c_prev = has_prev ? cd + sp * N * H : nullptr; c.c = cd + s * N * H;
-      c.dc_out = dcb + ((i + 1) & 1) * N * H; c.s = (int)s; c.N = (int)N; c.H = (int)H;
-    }
-    return pr;
-  };
+  EncFwd ef{};
+  ef.whh[0] = whh; ef.whh[1] = whh + 4 * H * H; ef.gates = gates; ef.cs = cs; ef.hs = hs; ef.y = y; ef.lens = nullptr;
+  ef.ys_s = (int)ys_s; ef.ys_n = (int)ys_n; ef.S = (int)S; ef.N = (int)N; ef.H = (int)H;
+  EncBwd eb{};
+  eb.whhT = whhT; eb.gates = gates; eb.cs = cs; eb.dy = dy; eb.dc = dc; eb.lens = nullptr;
+  eb.ys_s = (int)ys_s; eb.ys_n = (int)ys_n; eb.S = (int)S; eb.N = (int)N; eb.H = (int)H;
+  auto run_fwd = [&]() { for (int64_t i = 0; i < S; ++i) hipLaunchKernelGGL(lstm_enc_fwd_kernel, cell_fwd_grid(H, 2, N), dim3(256), 0, st, ef, (int)i); };
+  auto run_bwd = [&]() { for (int64_t i = 0; i < S; ++i) hipLaunchKernelGGL(lstm_enc_bwd_kernel, cell_bwd_grid(H, 2, N), dim3(256), 0, st, eb, (int)i); };
+  auto run_empty = [&]() { for (int64_t i = 0; i < S; ++i) hipLaunchKernelGGL(tiny_kernel, cell_fwd_grid(H, 2, N), dim3(256), 0, st, 1, y); };
 
   float ms;
-  for (int rep = 0; rep < 3; ++rep) {
-    CK(hipEventRecord(e0, st));
-    for (int64_t i = 0; i < S; ++i) { auto pr = fwd_args(i); hipLaunchKernelGGL(lstm_cell_fwd_kernel, cell_fwd_grid(H, 2, N), dim3(256), 0, st, pr); }
-    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("fwd chain      : %.3f us / step\n", ms * 1e3 / S);
-    CK(hipEventRecord(e0, st));
-    for (int64_t i = 0; i < S; ++i) { auto pr = bwd_args(i); hipLaunchKernelGGL(lstm_cell_bwd_kernel, cell_bwd_grid(H, 2, N), dim3(256), 0, st, pr); }
-    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("bwd chain      : %.3f us / step\n", ms * 1e3 / S);
-    CK(hipEventRecord(e0, st));
-    for (int64_t i = 0; i < S; ++i) { auto pr = fwd_args(i); hipLaunchKernelGGL(empty_kernel, cell_fwd_grid(H, 2, N), dim3(256), 0, st, pr); }
-    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("empty, big args: %.3f us / step\n", ms * 1e3 / S);
-    CK(hipEventRecord(e0, st));
-    for (int64_t i = 0; i < S; ++i) { hipLaunchKernelGGL(tiny_kernel, cell_fwd_grid(H, 2, N), dim3(256), 0, st, 1, y); }
-    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("empty, 12B args: %.3f us / step\n", ms * 1e3 / S);
+  auto timeit = [&](const char* name, auto fn) {
+    fn(); CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st)); fn(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1)); printf("%-28s %.3f us / step\n", name, ms * 1e3 / S); return 0; };
+  auto graphit = [&](const char* name, auto fn) {
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal)); fn(); CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(ge, st)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1)); printf("%-28s %.3f us / step (graph replay)\n", name, ms * 1e3 / S); return 0; };
+  for (int rep = 0; rep < 2; ++rep) {
+    timeit("fwd chain", run_fwd); timeit("bwd chain", run_bwd); timeit("empty 12B args", run_empty);
+    graphit("fwd chain", run_fwd); graphit("bwd chain", run_bwd); graphit("empty 12B args", run_empty);
   }
 #ifdef STAMPS
   // stamp one fwd and one bwd launch in the middle of a chain
   for (int which = 0; which < 2; ++which) {
     for (int64_t i = 0; i < 50; ++i) {
-      if (which == 0) { auto pr = fwd_args(i); hipLaunchKernelGGL(lstm_cell_fwd_kernel, cell_fwd_grid(H, 2, N), dim3(256), 0, st, pr); }
-      else { auto pr = bwd_args(i); hipLaunchKernelGGL(lstm_cell_bwd_kernel, cell_bwd_grid(H, 2, N), dim3(256), 0, st, pr); }
+      if (which == 0) hipLaunchKernelGGL(lstm_enc_fwd_kernel, cell_fwd_grid(H, 2, N), dim3(256), 0, st, ef, (int)i);
+      else hipLaunchKernelGGL(lstm_enc_bwd_kernel, cell_bwd_grid(H, 2, N), dim3(256), 0, st, eb, (int)i);
     }
     CK(hipStreamSynchronize(st));
     std::vector<unsigned long long> hst(8 * 4096);
     CK(hipMemcpyFromSymbol(hst.data(), HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8 * 4096));
-    const int nwg = which == 0 ? 128 : 64;
+    const int nwg = which == 0 ? 128 : 64 * 2;
     printf("%s stamps (cycles, median over %d workgroups): ", which ? "bwd" : "fwd", nwg);
     for (int k = 1; k < 6; ++k) {
       std::vector<long long> d;
       for (int w = 0; w < nwg; ++w) d.push_back((long long)(hst[w * 8 + k] - hst[w * 8 + k - 1]));
       std::sort(d.begin(), d.end());
       printf(" seg%d=%lld", k, d[d.size() / 2]);
+    }
+    for (int k = 6; k < 8; ++k) {
+      std::vector<long long> d;
+      for (int w = 0; w < nwg; ++w) d.push_back((long long)(hst[w * 8 + k] - hst[w * 8 + 0]));
+      std::sort(d.begin(), d.end());
+      printf(" t%d-t0=%lld", k, d[d.size() / 2]);
     }
     unsigned long long mn = ~0ull, mx = 0;
     for (int w = 0; w < nwg; ++w) { mn = std::min(mn, hst[w * 8]); mx = std::max(mx, hst[w * 8 + 5]); }
