@@ -62,14 +62,17 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
 
 /* Backward of ssasr_bilstm_fwd.  `gates` is consumed (overwritten with the
  * gate pre-activation derivatives).  dx may be NULL.  db_* is the derivative
- * of b_ih and of b_hh alike.  Workspaces: ws_whhT [2][H][4H], ws_dc [2][2][N][H]. */
+ * of b_ih and of b_hh alike.  Workspaces: ws_whhT [2][H][4H], ws_dc [2][2][N][H].
+ * Optional, enabling the single-launch persistent BPTT (H in {64,128,256},
+ * N <= 32): gx [2][S][4H][roundup(N,16)] floats, sync_ws int32[8]; NULL = one
+ * launch per step. */
 int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
                      int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H, const int32_t* lens,
                      const float* w_ih_f, const float* w_hh_f, const float* w_ih_r,
                      const float* w_hh_r, float* gates, const float* cs, const float* hs, float* dx,
                      int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f, float* db_f,
                      float* dw_ih_r, float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc,
-                     void* stream);
+                     float* gx, int32_t* sync_ws, void* stream);
 
 /* One nn.LSTMCell step (src/asr.py:320-324); input given as column blocks
  * x1 | x2 (x2 may be NULL).  gates [N][4H] receives the activated i,f,g,o. */

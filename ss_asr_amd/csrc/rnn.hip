@@ -61,7 +61,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     const int64_t chunks = (N + 31) / 32, Np = (N + 7) & ~(int64_t)7;
     const int kpw = (int)(H / 64);
     const bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
-                      chunks <= 2 && (H / 4) * 2 * chunks <= 256 && S * Np * H * 4 < (1ll << 31) &&
+                      chunks == 1 && (H / 4) * 2 * chunks <= 256 && S * Np * H * 4 < (1ll << 31) &&
                       aligned16(hx) && !getenv("SSASR_NO_PERSISTENT");
     if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
     if (fits) {
@@ -108,7 +108,7 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
                                 int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f,
                                 float* db_f, float* dw_ih_r, float* dw_hh_r, float* db_r,
                                 float* ws_whhT /* [2][H][4H] */, float* ws_dc /* [2][2][N][H] */,
-                                void* stream) {
+                                float* gx, int32_t* sync_ws, void* stream) {
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
   if (!dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
   // the gate epilogue of the backward kernel uses 16-byte accesses
@@ -128,13 +128,33 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
     if (rc) return rc;
   }
 
-  // BPTT: one launch per step, both directions per launch.
+  // BPTT: one persistent launch when the grid is certain to be resident
+  // (rnn_kernels.h, "persistent backward recurrence"), else one launch per step.
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31)) return SSASR_EARG;
+  if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
+  bool persistent = false;
+  {
+    const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
+    const int kpw = (int)(H / 16);
+    persistent = gx && sync_ws && (kpw == 4 || kpw == 8 || kpw == 16) && chunks <= 2 &&
+                 S * 4 * H * Np * 4 < (1ll << 31) && aligned16(gx) && !getenv("SSASR_NO_PERSISTENT");
+    if (persistent) {
+      EncPersistBwd p{};
+      p.whhT = ws_whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens;
+      p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
+      p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
+      dim3 pgrid((unsigned)(H / 16), 2, (unsigned)chunks), pblock(256);
+      if (kpw == 4) hipLaunchKernelGGL(lstm_enc_bwd_persistent_kernel<4>, pgrid, pblock, 0, st, p);
+      else if (kpw == 8) hipLaunchKernelGGL(lstm_enc_bwd_persistent_kernel<8>, pgrid, pblock, 0, st, p);
+      else hipLaunchKernelGGL(lstm_enc_bwd_persistent_kernel<16>, pgrid, pblock, 0, st, p);
+      SSASR_LAUNCH_CHECK();
+    }
+  }
   EncBwd e{};
   e.whhT = ws_whhT; e.gates = gates; e.cs = cs; e.dy = dy; e.dc = ws_dc; e.lens = lens;
   e.ys_s = (int)ys_s; e.ys_n = (int)ys_n; e.S = (int)S; e.N = (int)N; e.H = (int)H;
   dim3 grid = cell_bwd_grid(H, 2, N), block(256);
-  for (int64_t i = 0; i < S; ++i)
+  for (int64_t i = 0; i < S && !persistent; ++i)
     hipLaunchKernelGGL(lstm_enc_bwd_kernel, grid, block, 0, st, e, (int)i);
   SSASR_LAUNCH_CHECK();
 

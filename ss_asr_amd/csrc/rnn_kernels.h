@@ -635,6 +635,168 @@ __global__ __launch_bounds__(256) void lstm_enc_bwd_kernel(EncBwd e, int i) {
   cell_bwd_body(a, red);
 }
 
+// --------------------- persistent backward recurrence ----------------------
+// BPTT of one layer in one launch, same hand-off protocol as the forward
+// kernel.  A workgroup owns 16 hidden units x 16 columns; its slice of W_hh^T
+// (16 rows x 4H, 64 KB at H = 256) stays in registers, the cell-state
+// derivative of its (unit, column) pairs stays in registers, and per step it
+// reads the 16 x 4H gate derivatives of its column chunk that the H/16
+// workgroups of its (direction, chunk) group published one step earlier.
+// Exchange image per step: [k-block = gate * H/16 + unit tile][q][Np][4]
+// floats, so that a consumer lane's 16-byte read (4 consecutive k) and a
+// producer wave's 16-byte-per-lane store are both contiguous over the 16
+// columns (256 bytes = two whole 128-byte lines per (k-block, q)).
+struct EncPersistBwd {
+  const float* whhT;     // [2][H][4H]
+  float* gates;          // [2][S*N][4H]: activated gates in, gate derivatives out (row-major)
+  const float* cs;       // [2][S*N][H]
+  const float* dy;
+  float* gx;             // [2][S][H/4][4][Np][4] exchange image
+  const int32_t* lens;
+  unsigned* cnt;         // [2][chunks]
+  int* status;
+  int ys_s, ys_n;
+  int S, N, H;
+};
+
+template <int KPW>   // k-blocks per wave = (4H / 16) / 4 = H / 16
+__global__ __launch_bounds__(256) void lstm_enc_bwd_persistent_kernel(EncPersistBwd e) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
+  const int S = e.S, N = e.N, H = e.H;
+  const int n0 = chunk * 16;
+  const int Np = (N + 15) & ~15;               // whole 128-byte lines per 16-column chunk
+  const unsigned ntile = gridDim.x;            // H / 16 producers per group
+  const int64_t rows = (int64_t)S * N;
+  unsigned* cnt = e.cnt + d * gridDim.z + chunk;
+
+  float4 wreg[KPW];
+  {
+    const float* wp = e.whhT + ((int64_t)d * H + 16 * tile + r) * 4 * H + 4 * q;
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) wreg[j] = *reinterpret_cast<const float4*>(wp + (wave + 4 * j) * 16);
+  }
+
+  const int u0 = 16 * tile + 4 * q;             // epilogue (wave 0): units u0..u0+3 of column n
+  const int n = n0 + r;
+  const bool epi = wave == 0 && n < N;
+  const int len = (epi && e.lens) ? e.lens[n] : 0x7fffffff;
+  float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps
+  bool broken = false;
+
+  float* gbase = e.gates + (int64_t)d * rows * 4 * H;
+  const float* cbase = e.cs + (int64_t)d * rows * H;
+  const size_t step_bytes = (size_t)4 * H * Np * sizeof(float);
+  float* xbase = e.gx + (int64_t)d * S * 4 * H * Np;
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)(step_bytes * S), 0x00020000);
+  const unsigned xo = (unsigned)((q * Np + (n < N ? n : n0)) * 16);
+
+  for (int i = 0; i < S; ++i) {
+    const int s = d ? i : S - 1 - i;            // reverse of the forward order
+    const int sn = d ? s - 1 : s + 1;           // step published by the previous iteration
+    const int sp = d ? s + 1 : s - 1;           // forward-order predecessor
+    const bool has_prev = d ? (s < S - 1) : (s > 0);
+    const int64_t hu = ((int64_t)s * N + n) * H + u0;
+    const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gi = z4, gf = z4, gg = z4, go = z4, cpv = z4, cv = z4, ad1 = z4;
+    if (epi) {
+      gi = ld4(gbase + g0);
+      gf = ld4(gbase + g0 + H);
+      gg = ld4(gbase + g0 + 2 * (int64_t)H);
+      go = ld4(gbase + g0 + 3 * (int64_t)H);
+      cv = ld4(cbase + hu);
+      if (has_prev) cpv = ld4(cbase + ((int64_t)sp * N + n) * H + u0);
+      ad1 = ld4(e.dy + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + u0);
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i > 0) {
+      if (tid == 0 && !broken) {
+        const unsigned target = ntile * (unsigned)i;
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; broken = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      u32x4 raw[KPW];
+      const unsigned sbase = (unsigned)((size_t)sn * step_bytes);
+#pragma unroll
+      for (int j = 0; j < KPW; ++j)
+        raw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo + (unsigned)((wave + 4 * j) * 4 * Np * 16)),
+                                                       (int)sbase, 16);
+#pragma unroll
+      for (int j = 0; j < KPW; j += 2) {
+        const f32x4 f0 = __builtin_bit_cast(f32x4, raw[j]);
+        const f32x4 f1 = __builtin_bit_cast(f32x4, raw[j + 1 < KPW ? j + 1 : j]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j].x, f0[0], acc, 0, 0, 0);
+        if (j + 1 < KPW) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j + 1 < KPW ? j + 1 : j].x, f1[0], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j].y, f0[1], acc, 0, 0, 0);
+        if (j + 1 < KPW) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j + 1 < KPW ? j + 1 : j].y, f1[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j].z, f0[2], acc, 0, 0, 0);
+        if (j + 1 < KPW) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j + 1 < KPW ? j + 1 : j].z, f1[2], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j].w, f0[3], acc, 0, 0, 0);
+        if (j + 1 < KPW) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j + 1 < KPW ? j + 1 : j].w, f1[3], acc2, 0, 0, 0);
+      }
+    }
+    red[wave * 64 + lane] = acc + acc2;
+    __syncthreads();
+    if (wave == 0) {
+      float4 di = z4, df = z4, dg = z4, dov = z4;
+      if (epi) {
+        f32x4 dhv = red[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) dhv += red[w * 64 + lane];
+        const bool live = s < len;
+        const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
+        const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
+        const float cp_[4] = {cpv.x, cpv.y, cpv.z, cpv.w}, c_[4] = {cv.x, cv.y, cv.z, cv.w};
+        const float dc_[4] = {dcv.x, dcv.y, dcv.z, dcv.w}, a1_[4] = {ad1.x, ad1.y, ad1.z, ad1.w};
+        float rdi[4], rdf[4], rdg[4], rdo[4], rdc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dh = dhv[k] + a1_[k];
+          const float tc = fast_tanh(c_[k]);
+          const float dc = dc_[k] + dh * go_[k] * (1.f - tc * tc);
+          rdo[k] = live ? dh * tc * go_[k] * (1.f - go_[k]) : 0.f;
+          rdi[k] = live ? dc * gg_[k] * gi_[k] * (1.f - gi_[k]) : 0.f;
+          rdg[k] = live ? dc * gi_[k] * (1.f - gg_[k] * gg_[k]) : 0.f;
+          rdf[k] = live ? dc * cp_[k] * gf_[k] * (1.f - gf_[k]) : 0.f;
+          rdc[k] = live ? dc * gf_[k] : 0.f;
+        }
+        di = make_float4(rdi[0], rdi[1], rdi[2], rdi[3]);
+        df = make_float4(rdf[0], rdf[1], rdf[2], rdf[3]);
+        dg = make_float4(rdg[0], rdg[1], rdg[2], rdg[3]);
+        dov = make_float4(rdo[0], rdo[1], rdo[2], rdo[3]);
+        dcv = make_float4(rdc[0], rdc[1], rdc[2], rdc[3]);
+      }
+      // exchange image first (write-through), then the row-major copy for the GEMMs
+      if (n0 + r < Np) {
+        const unsigned so = (unsigned)((size_t)s * step_bytes);
+        const unsigned lo = (unsigned)((q * Np + n0 + r) * 16);
+        const int kt = H / 16;                  // k-blocks per gate
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, di), xrs, (int)(lo + (unsigned)((0 * kt + tile) * 4 * Np * 16)), (int)so, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, df), xrs, (int)(lo + (unsigned)((1 * kt + tile) * 4 * Np * 16)), (int)so, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dg), xrs, (int)(lo + (unsigned)((2 * kt + tile) * 4 * Np * 16)), (int)so, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dov), xrs, (int)(lo + (unsigned)((3 * kt + tile) * 4 * Np * 16)), (int)so, 16);
+      }
+      if (epi) {
+        st4(gbase + g0, di);
+        st4(gbase + g0 + H, df);
+        st4(gbase + g0 + 2 * (int64_t)H, dg);
+        st4(gbase + g0 + 3 * (int64_t)H, dov);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();      // red is rewritten by the next iteration
+  }
+}
+
 // out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:], plain store.  Used for the
 // context gradient of the speller's first cell.
 struct PlainMm {

@@ -128,10 +128,16 @@ class _BiLSTM(torch.autograd.Function):
               torch.empty_like(w[4]), torch.empty_like(w[5]), torch.empty(4 * H, device=dev)]
         ws_t = torch.empty(2, H, 4 * H, device=dev)
         ws_dc = torch.empty(2, 2, N, H, device=dev)
+        # workspaces of the persistent BPTT (exchange image + counters)
+        gx = torch.empty(2 * S * 4 * H * ((N + 15) // 16 * 16), device=dev,
+                         dtype=torch.float32) if N <= 32 and H in (64, 128, 256) else None
+        sync = torch.empty(8, device=dev, dtype=torch.int32) if gx is not None else None
+        if sync is not None:
+            _persist_status.append(sync)
         check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
                                    _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
-                                   _p(ws_dc), _stream()), 'ssasr_bilstm_bwd')
+                                   _p(ws_dc), _p(gx), _p(sync), _stream()), 'ssasr_bilstm_bwd')
         # inputs: x, lens, steps, batch_first, then w_ih,w_hh,b_ih,b_hh per direction
         return (dx, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
                 dw[3], dw[4], dw[5], dw[5].clone())
