@@ -63,6 +63,7 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
 /* Backward of ssasr_bilstm_fwd.  `gates` is consumed (overwritten with the
  * gate pre-activation derivatives).  dx may be NULL.  db_* is the derivative
  * of b_ih and of b_hh alike.  Workspaces: ws_whhT [2][H][4H], ws_dc [2][2][N][H].
+ * dw_ih_f == NULL defers every weight gradient to ssasr_bilstm_wgrad.
  * Optional, enabling the single-launch persistent BPTT (H in {64,128,256},
  * N <= 32): gx [2][S][4H][roundup(N,16)] floats, sync_ws int32[8]; NULL = one
  * launch per step. */
@@ -73,6 +74,16 @@ int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x
                      int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f, float* db_f,
                      float* dw_ih_r, float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc,
                      float* gx, int32_t* sync_ws, void* stream);
+
+/* Weight gradients of a layer from the gate derivatives ssasr_bilstm_bwd left
+ * in `gates`: dW_ih = dG^T X, dW_hh = sum_s dG[s]^T h[s_prev], db = column sums.
+ * accumulate = 0 overwrites, 1 adds (e.g. straight into optimizer-zeroed
+ * gradient buffers).  db2_* (optional) gets a second copy of the bias
+ * gradient.  Not on the critical path of backward: may run on another stream. */
+int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t xs_s, int64_t xs_n,
+                       const float* hs, int64_t S, int64_t N, int64_t I, int64_t H, float* dw_ih_f,
+                       float* dw_hh_f, float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
+                       float* db_r, float* db2_r, int accumulate, void* stream);
 
 /* One nn.LSTMCell step (src/asr.py:320-324); input given as column blocks
  * x1 | x2 (x2 may be NULL).  gates [N][4H] receives the activated i,f,g,o. */

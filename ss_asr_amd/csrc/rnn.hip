@@ -98,6 +98,12 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   return SSASR_OK;
 }
 
+extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t xs_s, int64_t xs_n,
+                                  const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
+                                  float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
+                                  float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
+                                  int accumulate, void* stream);
+
 // Backward of the layer.  `gates` is consumed: on return it holds the gate
 // pre-activation derivatives.  dw_* / db_* are overwritten.
 extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
@@ -158,27 +164,54 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
     hipLaunchKernelGGL(lstm_enc_bwd_kernel, grid, block, 0, st, e, (int)i);
   SSASR_LAUNCH_CHECK();
 
-  // Dense contractions over all time steps.
-  for (int d = 0; d < 2; ++d) {
+  // Input gradient (critical path: the layer below needs it).
+  for (int d = 0; d < 2 && dx; ++d) {
     const float* dG = gates + d * rows * 4 * H;
-    if (dx) {   // dx += dG . W_ih
-      GemmDesc g{};
-      g.A = dG; g.ma = rm_dense(4 * H);
-      g.B = wih[d]; g.mb = rm_dense(I);
-      g.C = dx; g.mc = RowMap{0, N, dxs_s, dxs_n};
-      g.M = (int)rows; g.N = (int)I; g.K = (int)(4 * H);
-      g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = d ? 1.f : 0.f; g.splitk = 1; g.batch = 1;
-      rc = ssasr_launch_gemm(g, st);
-      if (rc) return rc;
-    }
+    GemmDesc g{};
+    g.A = dG; g.ma = rm_dense(4 * H);
+    g.B = wih[d]; g.mb = rm_dense(I);
+    g.C = dx; g.mc = RowMap{0, N, dxs_s, dxs_n};
+    g.M = (int)rows; g.N = (int)I; g.K = (int)(4 * H);
+    g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = d ? 1.f : 0.f; g.splitk = 1; g.batch = 1;
+    rc = ssasr_launch_gemm(g, st);
+    if (rc) return rc;
+  }
+  if (!dw_ih_f) return SSASR_OK;      // weight gradients deferred to ssasr_bilstm_wgrad
+  return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, nullptr, dw_ih_r,
+                            dw_hh_r, db_r, nullptr, 0, stream);
+}
+
+// Weight gradients of a layer from the gate derivatives left in `gates` by
+// ssasr_bilstm_bwd: dW_ih = dG^T X, dW_hh = sum_s dG[s]^T h[s_prev], db = column
+// sums.  accumulate = 0 overwrites the outputs, 1 adds to them (gradient
+// buffers that were zeroed by the optimizer).  db2_* optionally receives a
+// second copy of the bias gradient (b_ih and b_hh have the same derivative).
+// Off the critical path of the backward pass: callers may enqueue it on a
+// second stream.
+extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t xs_s, int64_t xs_n,
+                                  const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
+                                  float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
+                                  float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
+                                  int accumulate, void* stream) {
+  if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dgates || !x || !hs) return SSASR_EARG;
+  if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = S * N;
+  float* dwih[2] = {dw_ih_f, dw_ih_r};
+  float* dwhh[2] = {dw_hh_f, dw_hh_r};
+  float* db[2] = {db_f, db_r};
+  float* db2[2] = {db2_f, db2_r};
+  int rc;
+  for (int d = 0; d < 2; ++d) {
+    const float* dG = dgates + d * rows * 4 * H;
     {           // dW_ih = dG^T . X
-      SSASR_HIP(hipMemsetAsync(dwih[d], 0, sizeof(float) * 4 * H * I, st));
+      if (!accumulate) SSASR_HIP(hipMemsetAsync(dwih[d], 0, sizeof(float) * 4 * H * I, st));
       GemmDesc g{};
       g.A = dG; g.ma = rm_dense(4 * H);
       g.B = x; g.mb = RowMap{0, N, xs_s, xs_n};
       g.C = dwih[d]; g.mc = rm_dense(I);
       g.M = (int)(4 * H); g.N = (int)I; g.K = (int)rows;
-      g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 0.f; g.batch = 1;
+      g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
       const int64_t tiles = ((4 * H + 63) / 64) * ((I + 63) / 64);
       int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
       if (rows < 64 * sk) sk = 1;
@@ -187,14 +220,14 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
       if (rc) return rc;
     }
     {           // dW_hh = sum_s dG[s]^T . h[s_prev]
-      SSASR_HIP(hipMemsetAsync(dwhh[d], 0, sizeof(float) * 4 * H * H, st));
+      if (!accumulate) SSASR_HIP(hipMemsetAsync(dwhh[d], 0, sizeof(float) * 4 * H * H, st));
       if (S > 1) {
         GemmDesc g{};
         g.A = d ? dG : dG + N * 4 * H; g.ma = rm_dense(4 * H);
         g.B = d ? hs + d * rows * H + N * H : hs; g.mb = rm_dense(H);
         g.C = dwhh[d]; g.mc = rm_dense(H);
         g.M = (int)(4 * H); g.N = (int)H; g.K = (int)((S - 1) * N);
-        g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 0.f; g.batch = 1;
+        g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
         const int64_t tiles = ((4 * H + 63) / 64) * ((H + 63) / 64);
         int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
         if ((S - 1) * N < 64 * sk) sk = 1;
@@ -203,9 +236,14 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
         if (rc) return rc;
       }
     }
-    SSASR_HIP(hipMemsetAsync(db[d], 0, sizeof(float) * 4 * H, st));
+    if (!accumulate) SSASR_HIP(hipMemsetAsync(db[d], 0, sizeof(float) * 4 * H, st));
     rc = ssasr_launch_colsum(dG, rows, (int)(4 * H), 4 * H, db[d], st);
     if (rc) return rc;
+    if (db2[d]) {
+      if (!accumulate) SSASR_HIP(hipMemsetAsync(db2[d], 0, sizeof(float) * 4 * H, st));
+      rc = ssasr_launch_colsum(dG, rows, (int)(4 * H), 4 * H, db2[d], st);
+      if (rc) return rc;
+    }
   }
   return SSASR_OK;
 }

@@ -53,5 +53,8 @@ def allreduce_grad(flat_grad):
     optimizer kernel must apply."""
     if not is_active():
         return 1.0
+    if flat_grad.is_cuda:
+        from . import ops
+        ops.join_side_stream()       # deferred weight-gradient GEMMs must have landed
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / dist.get_world_size()

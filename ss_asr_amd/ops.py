@@ -24,6 +24,39 @@ def check_persistent_status():
         raise RuntimeError('ssasr_bilstm_fwd: persistent recurrence timed out')
 
 
+# ---- weight-gradient overlap ------------------------------------------------
+# Weight gradients are off the critical path of backward.  For parameters whose
+# .grad lives in an optimizer-owned flat buffer (optim.FlatParameters marks
+# them), the BiLSTM backward enqueues its weight-gradient GEMMs on a second
+# stream and accumulates straight into .grad, while the main stream goes on
+# with the next layer's recurrence.  join_side_stream() must run before
+# anything reads the gradients (FusedAdadelta.clip_and_step does).
+_side = None
+
+
+def side_stream():
+    global _side
+    if _side is None:
+        _side = torch.cuda.Stream()
+    return _side
+
+
+def join_side_stream():
+    if _side is not None:
+        torch.cuda.current_stream().wait_stream(_side)
+
+
+def _grad_sinks(params):
+    """The .grad tensors to accumulate into, or None if any parameter is not
+    managed by a flat gradient buffer."""
+    sinks = []
+    for p in params:
+        if not getattr(p, '_ssasr_flat_grad', False) or p.grad is None:
+            return None
+        sinks.append(p.grad)
+    return sinks
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -78,9 +111,10 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, act=0, alpha=1.0, beta=0
 # ---------------------------------------------------------------------------
 class _BiLSTM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, lens, steps, batch_first, *w):
+    def forward(ctx, x, lens, steps, batch_first, sinks, *w):
         lib = _lib.load()
         _need_gpu(x, *w)
+        ctx.sinks = sinks
         x = _f32c(x)
         w = [_f32c(t) for t in w]
         H = w[1].shape[1]
@@ -124,8 +158,12 @@ class _BiLSTM(torch.autograd.Function):
             # frames past `steps` of a batch-first input get no gradient
             full = (not batch_first) or x.shape[1] == S
             dx = (torch.empty_like if full else torch.zeros_like)(x)
-        dw = [torch.empty_like(w[0]), torch.empty_like(w[1]), torch.empty(4 * H, device=dev),
-              torch.empty_like(w[4]), torch.empty_like(w[5]), torch.empty(4 * H, device=dev)]
+        sinks = ctx.sinks
+        if sinks is None:
+            dw = [torch.empty_like(w[0]), torch.empty_like(w[1]), torch.empty(4 * H, device=dev),
+                  torch.empty_like(w[4]), torch.empty_like(w[5]), torch.empty(4 * H, device=dev)]
+        else:
+            dw = [None] * 6          # deferred: ssasr_bilstm_wgrad on the side stream
         ws_t = torch.empty(2, H, 4 * H, device=dev)
         ws_dc = torch.empty(2, 2, N, H, device=dev)
         # workspaces of the persistent BPTT (exchange image + counters)
@@ -138,8 +176,20 @@ class _BiLSTM(torch.autograd.Function):
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
                                    _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
                                    _p(ws_dc), _p(gx), _p(sync), _stream()), 'ssasr_bilstm_bwd')
-        # inputs: x, lens, steps, batch_first, then w_ih,w_hh,b_ih,b_hh per direction
-        return (dx, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
+        if sinks is not None:
+            main = torch.cuda.current_stream()
+            side = side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                check(lib.ssasr_bilstm_wgrad(_p(gates), _p(x), xs_s, xs_n, _p(hs), S, N, I, H,
+                                             _p(sinks[0]), _p(sinks[1]), _p(sinks[2]), _p(sinks[3]),
+                                             _p(sinks[4]), _p(sinks[5]), _p(sinks[6]), _p(sinks[7]),
+                                             1, C.c_void_p(side.cuda_stream)), 'ssasr_bilstm_wgrad')
+            for t in (gates, x, hs):
+                t.record_stream(side)
+            return (dx,) + (None,) * 12
+        # inputs: x, lens, steps, batch_first, sinks, then w_ih,w_hh,b_ih,b_hh per direction
+        return (dx, None, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
                 dw[3], dw[4], dw[5], dw[5].clone())
 
 
@@ -148,7 +198,7 @@ def bilstm(x, lens, steps, batch_first, weights):
     batch_first: x [N, T, I], the first ``steps`` frames are processed and the
     result is [N, steps, 2H]; otherwise x is [S, N, I] -> [S, N, 2H].
     lens: int32 device tensor [N] or None."""
-    return _BiLSTM.apply(x, lens, steps, batch_first, *weights)
+    return _BiLSTM.apply(x, lens, steps, batch_first, _grad_sinks(weights), *weights)
 
 
 # ---------------------------------------------------------------------------

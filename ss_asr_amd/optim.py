@@ -40,6 +40,7 @@ class FlatParameters:
                 self.data[o:o + n].copy_(p.data.reshape(-1))
                 p.data = self.data[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+                p._ssasr_flat_grad = True     # ops may accumulate into p.grad from a side stream
 
     def zero_grad(self):
         self.grad.zero_()
@@ -67,6 +68,7 @@ class FusedAdadelta(torch.optim.Optimizer):
         self.flat.zero_grad()
 
     def clip_and_step(self, max_norm=5.0, grad_scale=1.0):
+        ops.join_side_stream()       # weight gradients enqueued on the side stream
         g = self.param_groups[0]
         ops.clip_adadelta_(self.flat.data, self.flat.grad, self.square_avg, self.acc_delta,
                            self._ws, self.stats, grad_scale=grad_scale, max_norm=max_norm,

@@ -78,6 +78,7 @@ def test_backward_and_solver_step_match_reference(golden, name):
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
     _, _, _, loss = forward(fx, model)
     loss.backward()
+    torch.cuda.synchronize()          # weight-gradient GEMMs run on a side stream
     params = dict(model.named_parameters())
     got = np.array([params[n].grad.double().norm().item() for n in names])
     np.testing.assert_allclose(got, fx['grad_norms'], rtol=1e-3, atol=1e-6)
