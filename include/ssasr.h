@@ -209,6 +209,20 @@ int ssasr_clip_adadelta(float* param, const float* grad, float* square_avg, floa
 int ssasr_frame_lengths(const float* x, int64_t B, int64_t T, int64_t F, int32_t* lens,
                         void* stream);
 
+/* Log-mel filterbank of one waveform: log_fbank, src/preprocess.py:187-208
+ * (librosa 0.6.3 melspectrogram defaults: centred reflect-padded STFT with a
+ * periodic Hann window of n_fft samples, power 2, Slaney mel filters, then
+ * log(S + 2.22e-16)).  F = ssasr_logmel_frames(n_samples, hop) = 1 + n/hop.
+ * Constants (host-built, device-resident): window [n_fft]; dft_basis
+ * [2*nb][Kp] with nb = n_fft/2+1, Kp = roundup(n_fft,4), rows 0..nb-1 =
+ * cos(2 pi k n / n_fft), rows nb.. = sin; mel_basis [n_mels][nbp], nbp =
+ * roundup(nb,4).  Workspaces: ws_frames [F][Kp], ws_spec [F][2*nb], ws_power
+ * [F][nbp].  out [F][n_mels]. */
+int64_t ssasr_logmel_frames(int64_t n_samples, int64_t hop);
+int ssasr_logmel(const float* wav, int64_t n_samples, int64_t n_fft, int64_t hop, int64_t n_mels,
+                 const float* window, const float* dft_basis, const float* mel_basis,
+                 float* ws_frames, float* ws_spec, float* ws_power, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

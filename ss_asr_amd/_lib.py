@@ -61,6 +61,8 @@ SIGNATURES = {
     'ssasr_clip_adadelta_ws': (I64, [I64]),
     'ssasr_clip_adadelta': (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, P, P, P]),
     'ssasr_frame_lengths': (I32, [P, I64, I64, I64, P, P]),
+    'ssasr_logmel_frames': (I64, [I64, I64]),
+    'ssasr_logmel': (I32, [P, I64, I64, I64, I64, P, P, P, P, P, P, P, P]),
 }
 
 _lib = None

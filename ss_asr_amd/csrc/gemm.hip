@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
           atomicAdd(C + rowoff + n, v);
         } else {
           if (g.act == 1) v = tanhf(v);
+          else if (g.act == 2) v = logf(fmaxf(v, 0.f) + 2.220446049250313e-16f);   // np.log(x + eps)
           if (g.beta != 0.f) v += g.beta * C[rowoff + n];
           C[rowoff + n] = v;
         }
