@@ -156,6 +156,12 @@ typedef struct ssasr_decoder {
   int32_t* chars;           /* [U+1][B]    character fed to each step            */
   float* gates1; float* c1; float* h1;   /* [U][B][4D], [U][B][D], [U][B][D]     */
   float* gates2; float* c2; float* h2;
+  /* optional workspaces of the single-launch persistent loop (taken for
+   * A = 128, E = 512, D = 256, B <= 32, T <= 128, V <= 64; all five non-NULL) */
+  float* ws_hx1; float* ws_hx2;          /* [U][D/4][32][4] each                 */
+  float* ws_qx;                          /* [U][A/16][32][16]                    */
+  int32_t* ws_modes;                     /* device int32[U]                      */
+  int32_t* ws_sync;                      /* int32[8]; [5] != 0 reports a timeout */
 } ssasr_decoder;
 
 int ssasr_decoder_fwd(const ssasr_decoder* d, void* stream);

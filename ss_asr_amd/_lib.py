@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -28,7 +28,8 @@ class Decoder(C.Structure):
          ('embed', P), ('w_ct', P), ('b_ct', P),
          ('logits', P), ('att', P),
          ('w_phi_t', P), ('q', P), ('ctx', P), ('emb_in', P), ('chars', P),
-         ('gates1', P), ('c1', P), ('h1', P), ('gates2', P), ('c2', P), ('h2', P)])
+         ('gates1', P), ('c1', P), ('h1', P), ('gates2', P), ('c2', P), ('h2', P),
+         ('ws_hx1', P), ('ws_hx2', P), ('ws_qx', P), ('ws_modes', P), ('ws_sync', P)])
 
 
 class DecoderGrads(C.Structure):

@@ -4,8 +4,10 @@
 #include "../../include/ssasr.h"
 #include "attn_kernels.h"
 #include "rnn_kernels.h"
+#include "decoder_persistent.h"
+#include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 1; }
+extern "C" int ssasr_abi_version(void) { return 2; }
 
 // ------------------------------ attention ---------------------------------
 extern "C" int ssasr_attn_precompute_fwd(const float* feat, const float* w_psi, const float* b_psi,
@@ -158,9 +160,32 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
                      d.emb_in, (U + 1) * B, (int)D);
   SSASR_LAUNCH_CHECK();
 
+  // Single persistent launch for the production sizes (decoder_persistent.h).
+  const bool persistent = d.ws_hx1 && d.ws_hx2 && d.ws_qx && d.ws_modes && d.ws_sync && A == PD_A &&
+                          E == PD_E && D == PD_D && B <= 32 && T <= 128 && V <= 64 &&
+                          !getenv("SSASR_NO_PERSISTENT") && !getenv("SSASR_NO_PERSISTENT_DECODER");
+  if (d.ws_sync) SSASR_HIP(hipMemsetAsync(d.ws_sync, 0, 8 * sizeof(int32_t), st));
+  if (persistent) {
+    SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
+    DecPersist p{};
+    p.feat = d.feat; p.comp = d.comp; p.enc_len = d.enc_len; p.w_phi = d.w_phi;
+    p.w_ih1 = d.w_ih1; p.w_hh1 = d.w_hh1; p.b_ih1 = d.b_ih1; p.b_hh1 = d.b_hh1;
+    p.w_ih2 = d.w_ih2; p.w_hh2 = d.w_hh2; p.b_ih2 = d.b_ih2; p.b_hh2 = d.b_hh2;
+    p.embed = d.embed; p.w_ct = d.w_ct; p.b_ct = d.b_ct; p.uniforms = d.uniforms; p.modes = d.ws_modes;
+    p.att = d.att; p.q = d.q; p.ctx = d.ctx; p.emb_in = d.emb_in; p.chars = d.chars;
+    p.gates1 = d.gates1; p.c1 = d.c1; p.h1 = d.h1; p.gates2 = d.gates2; p.c2 = d.c2; p.h2 = d.h2;
+    p.hx1 = d.ws_hx1; p.hx2 = d.ws_hx2; p.qx = d.ws_qx;
+    p.cnt = reinterpret_cast<unsigned*>(d.ws_sync); p.status = d.ws_sync + 5;
+    p.B = (int)B; p.T = (int)T; p.U = (int)U; p.V = (int)V;
+    const size_t lds = decoder_persistent_lds((int)T);
+    SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_persistent_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(decoder_fwd_persistent_kernel, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
+    SSASR_LAUNCH_CHECK();
+  }
   const int nch = attn_pick_nch((int)E);
   dim3 cgrid = cell_fwd_grid(D, 1, B), cblock(256);
-  for (int64_t t = 0; t < U; ++t) {
+  for (int64_t t = 0; t < U && !persistent; ++t) {
     // q_t = tanh(phi(h1_{t-1})); the state is zero at t = 0 and phi has no bias
     if (t) launch_phi(d.h1 + (t - 1) * B * D, d.w_phi, d.q + t * B * A, B, A, D, st);
     AttnFwd p{};

@@ -1,0 +1,424 @@
+// Persistent decode loop: all U steps of ASR.forward's attention -> Speller
+// loop (src/asr.py:79-103) in ONE launch, for the production sizes
+// A = 128, E = 512, D = 256, B <= 32, T <= 128.
+//
+// Per step the multi-launch path pays four kernel boundaries and re-reads
+// 8.4 MB of listener features plus 6.5 MB of cell weights.  Here
+//   * 64 "attention" workgroups (utterance b, 256-column half of E) keep
+//     their slice of feat in LDS for the whole loop (102 KB at T = 100) and
+//     prefetch their rows of comp while they wait for the query;
+//   * 128 "compute" workgroups (4 hidden units x 16 utterances) keep their
+//     slices of W_phi, [W_ih1 | W_hh1] and [W_ih2 | W_hh2] in registers and
+//     time-share three roles per step: phi_t, cell 2 of step t-1 (off the
+//     critical path: it overlaps the attention workgroups' work) and cell 1
+//     of step t; the first 32 also draw the next character on steps that are
+//     not teacher forced.
+// Stage hand-offs (h1 -> q -> ctx -> h1, h1 -> h2, h2 -> char -> emb) use the
+// protocol of the persistent recurrences (rnn_kernels.h): write-through (sc1)
+// stores that cover whole 128-byte lines per store instruction, drain, one
+// agent-scope add to a monotonic per-stage counter; consumers poll, barrier,
+// and read with sc1 loads.  Every step uses fresh addresses.  All spins are
+// bounded; a timeout sets *status and the launch still terminates.
+#pragma once
+#include "attn_kernels.h"
+#include "rnn_kernels.h"
+
+namespace {
+
+constexpr int PD_A = 128, PD_E = 512, PD_D = 256, PD_BP = 32;   // BP: image columns
+constexpr int PD_NATT = 2;                                       // E / 256 slices per utterance
+constexpr int PD_NATTWG = 64;                                    // attention workgroups (32 utterances x 2)
+
+struct DecPersist {
+  const float* feat; const float* comp; const int32_t* enc_len;
+  const float* w_phi;
+  const float* w_ih1; const float* w_hh1; const float* b_ih1; const float* b_hh1;
+  const float* w_ih2; const float* w_hh2; const float* b_ih2; const float* b_hh2;
+  const float* embed; const float* w_ct; const float* b_ct; const float* uniforms;
+  const int32_t* modes;     // device int32[U]: 0 teacher, 1 sample, 2 argmax
+  float* att; float* q; float* ctx; float* emb_in; int32_t* chars;
+  float* gates1; float* c1; float* h1; float* gates2; float* c2; float* h2;
+  float* hx1; float* hx2;   // [U][D/4][BP][4] exchange images of h1 / h2
+  float* qx;                // [U][A/16][BP][16] exchange image of q
+  unsigned* cnt;            // [0] h1  [1] q  [2] ctx  [3] h2  [4] char
+  int* status;
+  int B, T, U, V;
+};
+
+enum { PC_H1 = 0, PC_Q = 1, PC_CTX = 2, PC_H2 = 3, PC_CHAR = 4 };
+
+struct PdWaiter {
+  bool broken;
+  int* status;
+  __device__ __forceinline__ void wait_ge(unsigned* c, unsigned target) {
+    if (threadIdx.x == 0 && !broken) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > PERSIST_MAX_SPINS) { *status = 1; broken = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+  }
+};
+
+__device__ __forceinline__ float4 pd_ld_sc1(const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+  const f32x4 f = __builtin_bit_cast(f32x4, v);
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void pd_st_sc1(const __amdgpu_buffer_rsrc_t& rs, unsigned off, float4 v) {
+  const f32x4 f = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), rs, (int)off, 0, 16);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pd_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int N>
+__device__ __forceinline__ void pd_mma(f32x4& acc, f32x4& acc2, const float4 (&w)[N], const float4 (&b)[N],
+                                       int lo, int hi) {
+#define PD_STEP(C)                                                                              \
+  _Pragma("unroll") for (int j = 0; j < N; j += 2) {                                            \
+    if (j >= lo && j < hi) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j].C, b[j].C, acc, 0, 0, 0); \
+    if (j + 1 < N && j + 1 >= lo && j + 1 < hi)                                                 \
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j + 1 < N ? j + 1 : j].C, b[j + 1 < N ? j + 1 : j].C, acc2, 0, 0, 0); \
+  }
+  PD_STEP(x) PD_STEP(y) PD_STEP(z) PD_STEP(w)
+#undef PD_STEP
+}
+
+// grid: 64 attention workgroups (blockIdx.x < 64: b = x >> 1, half = x & 1; only b < B work)
+//       then 128 compute workgroups (tile = c >> 1, 16-column chunk = c & 1): 192 in all.
+// The kernel needs ~256 VGPRs, i.e. one workgroup per CU: 192 leaves 64 CUs of slack.
+// dynamic LDS: T * 256 floats (feat slice) + 2176 floats scratch
+__global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int B = p.B, T = p.T, U = p.U;
+  PdWaiter wt{false, p.status};
+  const unsigned n_att = (unsigned)(B * PD_NATT);     // ctx publishers per step
+  const unsigned n_cmp = 128u, n_phi = 16u, n_chr = (unsigned)B;
+  const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4 * sizeof(float);      // bytes per step
+  const size_t img_q = (size_t)(PD_A / 16) * PD_BP * 16 * sizeof(float);
+
+  if (blockIdx.x < PD_NATTWG) {
+    // ------------------------------ attention role ------------------------------
+    const int b = blockIdx.x >> 1, chunk = blockIdx.x & 1;
+    if (b >= B) return;
+    float* sF = smem;                       // [T][256] feat slice
+    float* sRed = smem + (size_t)T * 256;   // [8][256]
+    float* sM = sRed + 2048;                // [8] + [8]
+    const int hw = tid >> 5, l32 = tid & 31;
+    int len = p.enc_len ? p.enc_len[b] : T;
+    len = len < T ? len : T;
+    const float* fb = p.feat + (int64_t)b * T * PD_E + chunk * 256;
+    for (int i = tid; i < T * 64; i += 256) {
+      const int t = i >> 6, c4 = i & 63;
+      *reinterpret_cast<float4*>(sF + t * 256 + 4 * c4) =
+          t < len ? aload4(fb + (int64_t)t * PD_E + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const float* cb = p.comp + (int64_t)b * T * PD_A + 4 * l32;
+    const __amdgpu_buffer_rsrc_t rq = pd_rsrc(p.qx, img_q * U);
+    const __amdgpu_buffer_rsrc_t rc = pd_rsrc(p.ctx, (size_t)U * B * PD_E * sizeof(float));
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < U; ++t) {
+      float4 c[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int tt = hw + 8 * i;
+        c[i] = tt < len ? aload4(cb + (int64_t)tt * PD_A) : z4;      // comp is read-only: plain loads
+      }
+      float4 q4 = z4;
+      if (t > 0) {
+        wt.wait_ge(p.cnt + PC_Q, n_phi * (unsigned)t);
+        q4 = pd_ld_sc1(rq, (unsigned)(t * img_q + (((l32 >> 2) * PD_BP + b) * 16 + (l32 & 3) * 4) * 4));
+      }
+      if (chunk == 0 && hw == 0) *reinterpret_cast<float4*>(p.q + ((int64_t)t * B + b) * PD_A + 4 * l32) = q4;
+      float e[16];
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = c[i].x * q4.x;
+        v = fmaf(c[i].y, q4.y, v);
+        v = fmaf(c[i].z, q4.z, v);
+        v = fmaf(c[i].w, q4.w, v);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        e[i] = v;
+        if (hw + 8 * i < len) m = fmaxf(m, v);
+      }
+      float ssum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = (hw + 8 * i < len) ? __builtin_amdgcn_exp2f((e[i] - m) * 1.4426950408889634f) : 0.f;
+        e[i] = pv;
+        ssum += pv;
+      }
+      if (l32 == 0) { sM[hw] = m; sM[8 + hw] = ssum; }
+      __syncthreads();
+      float gm = sM[0];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) gm = fmaxf(gm, sM[g]);
+      float gs = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        gs += sM[8 + g] > 0.f ? sM[8 + g] * __builtin_amdgcn_exp2f((sM[g] - gm) * 1.4426950408889634f) : 0.f;
+      const float scale = ssum > 0.f
+          ? __builtin_amdgcn_exp2f((m - gm) * 1.4426950408889634f) * __builtin_amdgcn_rcpf(gs) : 0.f;
+      float4 acc = z4, accb = z4;        // columns 4*l32.. and 128 + 4*l32.. of this half
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int tt = hw + 8 * i;
+        const float w = e[i] * scale;
+        e[i] = w;
+        if (tt < len) {
+          const float4 f = *reinterpret_cast<const float4*>(sF + tt * 256 + 4 * l32);
+          const float4 g = *reinterpret_cast<const float4*>(sF + tt * 256 + 128 + 4 * l32);
+          acc.x = fmaf(w, f.x, acc.x);
+          acc.y = fmaf(w, f.y, acc.y);
+          acc.z = fmaf(w, f.z, acc.z);
+          acc.w = fmaf(w, f.w, acc.w);
+          accb.x = fmaf(w, g.x, accb.x);
+          accb.y = fmaf(w, g.y, accb.y);
+          accb.z = fmaf(w, g.z, accb.z);
+          accb.w = fmaf(w, g.w, accb.w);
+        }
+      }
+      if (chunk == 0 && l32 == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int tt = hw + 8 * i;
+          if (tt < T) p.att[((int64_t)b * U + t) * T + tt] = e[i];
+        }
+      }
+      *reinterpret_cast<float4*>(sRed + hw * 256 + 4 * l32) = acc;
+      *reinterpret_cast<float4*>(sRed + hw * 256 + 128 + 4 * l32) = accb;
+      __syncthreads();
+      if (wave == 0) {
+        {     // 64 lanes x 16 bytes = the 1 KB half row of ctx: whole 128-byte lines
+          float4 v = *reinterpret_cast<const float4*>(sRed + 4 * lane);
+#pragma unroll
+          for (int g = 1; g < 8; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(sRed + g * 256 + 4 * lane);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+          pd_st_sc1(rc, (unsigned)((((int64_t)t * B + b) * PD_E + chunk * 256 + 4 * lane) * 4), v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CTX, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();     // sM / sRed are rewritten next step
+    }
+    return;
+  }
+
+  // -------------------------------- compute role --------------------------------
+  const int c = blockIdx.x - PD_NATTWG;
+  const int tile = c >> 1, chunk = c & 1;          // 4 hidden units, 16 utterances
+  const int r = lane & 15, q = lane >> 4;
+  const int n = 16 * chunk + r;                    // this lane's utterance (B operand / epilogue column)
+  const int nc = n < B ? n : 0;
+  f32x4* red = reinterpret_cast<f32x4*>(smem);     // [4][64]
+  float* sH = smem + 4 * 64 * 4;                   // [16][4] transpose buffer, then [256] for the char role
+  const int D = PD_D, E = PD_E;
+  const bool is_phi = c < 16, is_chr = c < B;
+  const int atile = c >> 1;                        // phi role: 16 rows of A, same 16-utterance chunk
+
+  // resident weight slices (this wave's k-blocks: kb = wave + 4 j)
+  float4 w1[16], w2[8], wp[4];
+  {
+    const int rowA = (r & 3) * D + 4 * tile + (r >> 2);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = 16 * (wave + 4 * j) + 4 * q;                 // 0 .. 1023 over [emb | ctx | h1]
+      w1[j] = k < D + E ? aload4(p.w_ih1 + (int64_t)rowA * (D + E) + k)
+                        : aload4(p.w_hh1 + (int64_t)rowA * D + (k - D - E));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * (wave + 4 * j) + 4 * q;                 // 0 .. 511 over [h1 | h2]
+      w2[j] = k < D ? aload4(p.w_ih2 + (int64_t)rowA * D + k) : aload4(p.w_hh2 + (int64_t)rowA * D + (k - D));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      wp[j] = is_phi ? aload4(p.w_phi + (int64_t)(16 * atile + r) * D + 16 * (wave + 4 * j) + 4 * q)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int u = 4 * tile + q;                      // epilogue (wave 0): unit u, utterance n
+  const bool epi = wave == 0 && n < B;
+  float bias1[4] = {0.f, 0.f, 0.f, 0.f}, bias2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (epi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bias1[g] = p.b_ih1[g * D + u] + p.b_hh1[g * D + u];
+      bias2[g] = p.b_ih2[g * D + u] + p.b_hh2[g * D + u];
+    }
+  }
+  float cst1 = 0.f, cst2 = 0.f;
+  const __amdgpu_buffer_rsrc_t rh1 = pd_rsrc(p.hx1, img_h * U);
+  const __amdgpu_buffer_rsrc_t rh2 = pd_rsrc(p.hx2, img_h * U);
+  const __amdgpu_buffer_rsrc_t rq = pd_rsrc(p.qx, img_q * U);
+  const __amdgpu_buffer_rsrc_t rc = pd_rsrc(p.ctx, (size_t)U * B * E * sizeof(float));
+  const __amdgpu_buffer_rsrc_t re = pd_rsrc(p.emb_in, (size_t)(U + 1) * B * D * sizeof(float));
+  const unsigned xoi = (unsigned)((q * PD_BP + nc) * 16);          // lane part of an image read
+  unsigned nsamp = 0;                                              // non-teacher steps so far
+
+  // cell epilogue shared by both cells: gates -> state, saves, image store, publish
+  auto cell_finish = [&](const f32x4& acc, const f32x4& acc2, const float (&bias)[4], float& cst, int t,
+                         float* gates, float* cs, float* hs, const __amdgpu_buffer_rsrc_t& rimg, int counter) {
+    red[wave * 64 + lane] = acc + acc2;
+    __syncthreads();
+    if (wave == 0) {
+      if (epi) {
+        f32x4 v = red[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += red[w * 64 + lane];
+        const float gi = fast_sigmoid(v[0] + bias[0]), gf = fast_sigmoid(v[1] + bias[1]);
+        const float gg = fast_tanh(v[2] + bias[2]), go = fast_sigmoid(v[3] + bias[3]);
+        const float cc = gf * cst + gi * gg;
+        const float h = go * fast_tanh(cc);
+        cst = cc;
+        sH[r * 4 + q] = h;
+        const int64_t g0 = ((int64_t)t * B + n) * 4 * D + u;
+        gates[g0] = gi; gates[g0 + D] = gf; gates[g0 + 2 * D] = gg; gates[g0 + 3 * D] = go;
+        cs[((int64_t)t * B + n) * D + u] = cc;
+        hs[((int64_t)t * B + n) * D + u] = h;
+      } else if (n >= B) {
+        sH[r * 4 + q] = 0.f;
+      }
+      // lanes of wave 0 exchange through sH without a workgroup barrier
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (lane < 16)
+        pd_st_sc1(rimg, (unsigned)(t * img_h + ((tile * PD_BP + 16 * chunk + lane) * 16)),
+                  *reinterpret_cast<const float4*>(sH + lane * 4));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(p.cnt + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  };
+
+  for (int t = 0; t <= U; ++t) {
+    // (A) h1_{t-1} from every compute workgroup
+    if (t > 0) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
+
+    // (B) phi_t: q_t = tanh(W_phi h1_{t-1})          (16 workgroups)
+    if (is_phi && t > 0 && t < U) {
+      float4 bq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bq[j] = pd_ld_sc1(rh1, (unsigned)((t - 1) * img_h + (wave + 4 * j) * 4 * PD_BP * 16 + xoi));
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      pd_mma<4>(acc, acc2, wp, bq, 0, 4);
+      red[wave * 64 + lane] = acc + acc2;
+      __syncthreads();
+      if (wave == 0) {
+        f32x4 v = red[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += red[w * 64 + lane];
+        // D fragment: rows 4q..4q+3 of this A tile, column = utterance 16*chunk + r
+        const float4 qv = make_float4(tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3]));
+        pd_st_sc1(rq, (unsigned)(t * img_q + ((atile * PD_BP + 16 * chunk + r) * 16 + 4 * q) * 4), qv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_Q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+    }
+
+    // (C) cell 2 of step t-1 (overlaps the attention workgroups' step t)
+    if (t > 0) {
+      const int s = t - 1;
+      if (s > 0) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)s);
+      float4 b2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kb = wave + 4 * j;                           // 0..15: h1_s, 16..31: h2_{s-1}
+        if (j < 4) b2[j] = pd_ld_sc1(rh1, (unsigned)(s * img_h + kb * 4 * PD_BP * 16 + xoi));
+        else b2[j] = s > 0 ? pd_ld_sc1(rh2, (unsigned)((s - 1) * img_h + (kb - 16) * 4 * PD_BP * 16 + xoi))
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      pd_mma<8>(acc, acc2, w2, b2, 0, s > 0 ? 8 : 4);
+      cell_finish(acc, acc2, bias2, cst2, s, p.gates2, p.c2, p.h2, rh2, PC_H2);
+
+      // (D) next character after step s when it is not teacher forced
+      const int mode = p.modes[s];
+      if (mode != 0) {
+        ++nsamp;
+        if (is_chr && s + 1 <= U) {
+          wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)(s + 1));
+          const int b = c;
+          float* sV = sH;                                       // [256] h2_s of utterance b
+          float* sL = sH + 256;                                 // [V] logits
+          if (tid < 64) {
+            const float4 hv = pd_ld_sc1(rh2, (unsigned)(s * img_h + ((tid * PD_BP + b) * 16)));
+            *reinterpret_cast<float4*>(sV + 4 * tid) = hv;
+          }
+          __syncthreads();
+          for (int v = wave; v < p.V; v += 4) {
+            const float* wr = p.w_ct + (int64_t)v * D;
+            float a = 0.f;
+            for (int k = lane; k < D; k += 64) a = fmaf(wr[k], sV[k], a);
+            a = wave_sum(a);
+            if (lane == 0) sL[v] = a + p.b_ct[v];
+          }
+          __syncthreads();
+          if (wave == 0) {
+            int best = 0;
+            if (lane == 0) {
+              float mx = sL[0];
+              for (int v = 1; v < p.V; ++v)
+                if (sL[v] > mx) { mx = sL[v]; best = v; }
+              if (mode == 1) {
+                float tot = 0.f;
+                for (int v = 0; v < p.V; ++v) tot += expf(sL[v] - mx);
+                const float target = p.uniforms[(int64_t)s * B + b] * tot;
+                float run = 0.f;
+                best = p.V - 1;
+                for (int v = 0; v < p.V; ++v) {
+                  run += expf(sL[v] - mx);
+                  if (run > target) { best = v; break; }
+                }
+              }
+              p.chars[(int64_t)(s + 1) * B + b] = best;
+            }
+            best = __shfl(best, 0, 64);
+            pd_st_sc1(re, (unsigned)((((int64_t)(s + 1) * B + b) * D + 4 * lane) * 4),
+                      aload4(p.embed + (int64_t)best * D + 4 * lane));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CHAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          __syncthreads();
+        }
+      }
+    }
+    if (t == U) break;
+
+    // (E) ctx_t from the attention workgroups, emb_t from the character role
+    wt.wait_ge(p.cnt + PC_CTX, n_att * (unsigned)(t + 1));
+    if (t > 0 && p.modes[t - 1] != 0) wt.wait_ge(p.cnt + PC_CHAR, n_chr * nsamp);
+
+    // (F) cell 1 of step t: [emb_t | ctx_t | h1_{t-1}]
+    {
+      float4 b1[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int kb = wave + 4 * j;                           // 0..15 emb, 16..47 ctx, 48..63 h1
+        if (j < 4) b1[j] = pd_ld_sc1(re, (unsigned)((((int64_t)t * B + nc) * D + 16 * kb + 4 * q) * 4));
+        else if (j < 12) b1[j] = pd_ld_sc1(rc, (unsigned)((((int64_t)t * B + nc) * E + 16 * (kb - 16) + 4 * q) * 4));
+        else b1[j] = t > 0 ? pd_ld_sc1(rh1, (unsigned)((t - 1) * img_h + (kb - 48) * 4 * PD_BP * 16 + xoi))
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      pd_mma<16>(acc, acc2, w1, b1, 0, t > 0 ? 16 : 12);
+      cell_finish(acc, acc2, bias1, cst1, t, p.gates1, p.c1, p.h1, rh1, PC_H1);
+    }
+  }
+}
+
+inline size_t decoder_persistent_lds(int T) { return sizeof(float) * ((size_t)T * 256 + 2176); }
+
+}  // namespace

@@ -20,7 +20,7 @@ def check_persistent_status():
     out waiting for its peers (synchronises the device)."""
     global _persist_status
     pending, _persist_status = _persist_status, []
-    if pending and any(int(v) for v in torch.stack([t[4] for t in pending]).cpu()):
+    if pending and any(int(v) for v in torch.stack([t[i] for t, i in pending]).cpu()):
         raise RuntimeError('ssasr_bilstm_fwd: persistent recurrence timed out')
 
 
@@ -140,7 +140,7 @@ class _BiLSTM(torch.autograd.Function):
                                    _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
                                    _stream()), 'ssasr_bilstm_fwd')
         if sync is not None:
-            _persist_status.append(sync)
+            _persist_status.append((sync, 4))
         ctx.save_for_backward(x, lens, gates, cs, hs, *w)
         ctx.geom = (S, N, I, H, xs_s, xs_n, ys_s, ys_n, bool(batch_first))
         return y
@@ -171,7 +171,7 @@ class _BiLSTM(torch.autograd.Function):
                          dtype=torch.float32) if N <= 32 and H in (64, 128, 256) else None
         sync = torch.empty(8, device=dev, dtype=torch.int32) if gx is not None else None
         if sync is not None:
-            _persist_status.append(sync)
+            _persist_status.append((sync, 4))
         check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
                                    _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
@@ -353,6 +353,12 @@ class _DecoderLoop(torch.autograd.Function):
                     chars=torch.empty(U + 1, B, device=dev, dtype=torch.int32),
                     gates1=f(U, B, 4 * D), c1=f(U, B, D), h1=f(U, B, D),
                     gates2=f(U, B, 4 * D), c2=f(U, B, D), h2=f(U, B, D))
+        if A == 128 and E == 512 and D == 256 and B <= 32 and T <= 128 and V <= 64:
+            # workspaces of the persistent decode loop
+            bufs.update(ws_hx1=f(U, D // 4, 32, 4), ws_hx2=f(U, D // 4, 32, 4), ws_qx=f(U, A // 16, 32, 16),
+                        ws_modes=torch.empty(U, device=dev, dtype=torch.int32),
+                        ws_sync=torch.empty(8, device=dev, dtype=torch.int32))
+            _persist_status.append((bufs['ws_sync'], 5))
         modes = (C.c_int32 * U)(*[int(m) for m in step_mode])
         d = _lib.Decoder()
         d.B, d.T, d.E, d.A, d.D, d.V, d.U = B, T, E, A, D, V, U

@@ -150,3 +150,45 @@ def test_sampled_steps_follow_the_categorical_law():
     top = int(torch.argmax(probs))
     rate = counts[top].item() / counts.sum().item()
     assert abs(rate - probs[top].item()) < 0.25
+
+
+def test_persistent_decode_loop_equals_multi_launch_loop():
+    """Production sizes take the single-launch persistent decode loop; with the
+    same coin flips and uniforms it must pick the same characters and give the
+    same logits / attention / gradients as the one-launch-per-stage loop
+    (also exercises in-kernel sampling and greedy steps)."""
+    import ctypes as C
+    from ss_asr_amd import _lib, ops
+    from ss_asr_amd.asr import ASR
+    torch.manual_seed(5)
+    model = ASR(50, 256, 256, 128, 80, 0.5).to('cuda:0')
+    B, T, U = 9, 96, 14
+    feat = torch.randn(B, T // 8, 512, device='cuda')
+    enc_len = torch.tensor([12, 12, 11, 9, 8, 8, 5, 3, 1], dtype=torch.int32, device='cuda')
+    teacher = torch.randint(3, 50, (B, U + 2), device='cuda').to(torch.int32)
+    modes = [0, 1, 0, 0, 2, 1, 1, 0, 0, 0, 1, 0, 2, 0]
+    uniforms = torch.rand(U, B, device='cuda')
+    results = []
+    for env in (None, '1'):
+        if env:
+            import os
+            os.environ['SSASR_NO_PERSISTENT_DECODER'] = env
+        f = feat.clone().requires_grad_(True)
+        comp = ops.attn_precompute(f, model.attention.psi.weight, model.attention.psi.bias)
+        logits, att, chars = ops.decoder_loop(f, comp, enc_len, teacher, modes, uniforms,
+                                              model._decoder_params())
+        model.zero_grad()
+        (logits * torch.linspace(0.5, 1.5, 50, device='cuda')).sum().backward()
+        torch.cuda.synchronize()
+        ops.check_persistent_status()
+        results.append((logits.detach().cpu(), att.cpu(), chars.cpu(), f.grad.cpu(),
+                        model.decoder.layer_1.weight_ih.grad.cpu().clone(),
+                        model.attention.phi.weight.grad.cpu().clone()))
+    import os
+    os.environ.pop('SSASR_NO_PERSISTENT_DECODER', None)
+    a, b = results
+    assert torch.equal(a[2], b[2])                                  # same characters fed
+    np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), atol=2e-6, rtol=0)
+    for x, y in zip(a[3:], b[3:]):
+        np.testing.assert_allclose(x.numpy(), y.numpy(), atol=5e-5 * max(1.0, float(y.abs().max())), rtol=0)
