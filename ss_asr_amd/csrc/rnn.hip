@@ -71,8 +71,10 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
       p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
       dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(256);
-      const bool fenced = getenv("SSASR_PERSISTENT_FENCED") != nullptr;   // diagnostic: release/acquire form
-      if (fenced) {
+      // exchange by sentinel (default) or by arrival counter (SSASR_PERSISTENT_COUNTER=1, for A/B)
+      const bool sentinel = getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
+      if (sentinel) {
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * Np * H), st));
         if (kpw == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<1, true>), pgrid, pblock, 0, st, p);
         else if (kpw == 2) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<2, true>), pgrid, pblock, 0, st, p);
         else if (kpw == 4) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
@@ -150,9 +152,16 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
       p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
       p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
       dim3 pgrid((unsigned)(H / 16), 2, (unsigned)chunks), pblock(256);
-      if (kpw == 4) hipLaunchKernelGGL(lstm_enc_bwd_persistent_kernel<4>, pgrid, pblock, 0, st, p);
-      else if (kpw == 8) hipLaunchKernelGGL(lstm_enc_bwd_persistent_kernel<8>, pgrid, pblock, 0, st, p);
-      else hipLaunchKernelGGL(lstm_enc_bwd_persistent_kernel<16>, pgrid, pblock, 0, st, p);
+      if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(2 * S * 4 * H * Np), st));
+        if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
+        else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, true>), pgrid, pblock, 0, st, p);
+        else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), pgrid, pblock, 0, st, p);
+      } else {
+        if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, false>), pgrid, pblock, 0, st, p);
+        else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, false>), pgrid, pblock, 0, st, p);
+        else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, false>), pgrid, pblock, 0, st, p);
+      }
       SSASR_LAUNCH_CHECK();
     }
   }

@@ -363,7 +363,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned PERSIST_MAX_SPINS = 1u << 20;   // ~ a second of polling, then give up for good
 
-template <int KPW, bool FENCED>   // k-blocks per wave = H / 64; FENCED: release/acquire form
+constexpr unsigned PERSIST_SENTINEL = 0x7FC0DEADu;   // a NaN: h = o * tanh(c) can never produce it
+
+// SENTINEL = true: no arrival counter.  The host pre-fills the exchange image
+// with PERSIST_SENTINEL; a consumer first polls one 16-byte piece per producer
+// tile, then loads its operands and re-loads until no element is the sentinel.
+// That removes the producer's store drain, the atomic and the counter poll
+// from the per-step critical path.
+template <int KPW, bool SENTINEL>   // k-blocks per wave = H / 64
 __global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * FWD_NB * 64];
   __shared__ __attribute__((aligned(16))) float sH[32 * 4];
@@ -420,28 +427,49 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist
 #pragma unroll
     for (int t = 0; t < FWD_NB; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (i > 0) {
-      if (tid == 0 && !broken) {
-        const unsigned target = ntile * (unsigned)i;
+      const unsigned sbase = (unsigned)((int64_t)sp * Np * H * 4);   // step offset in bytes
+      if (!SENTINEL) {
+        if (tid == 0 && !broken) {
+          const unsigned target = ntile * (unsigned)i;
+          unsigned spins = 0;
+          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; broken = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      } else if (wave == 0 && !broken) {
         unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; broken = true; break; }
+        for (;;) {
+          bool ok = true;
+          for (unsigned tl = lane; tl < ntile; tl += 64) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((tl * Np + n0) * 16), (int)sbase, 16);
+            ok = ok && v.x != PERSIST_SENTINEL && v.y != PERSIST_SENTINEL && v.z != PERSIST_SENTINEL &&
+                 v.w != PERSIST_SENTINEL;
+          }
+          if (__all(ok)) break;
+          if (++spins > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; broken = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
-      }
-      if (FENCED) {
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();
       float4 b[KPW][FWD_NB];
       u32x4 raw[KPW][FWD_NB];
-      const unsigned sbase = (unsigned)((int64_t)sp * Np * H * 4);   // step offset in bytes
+      for (unsigned tries = 0;; ++tries) {
+        bool bad = false;
 #pragma unroll
-      for (int j = 0; j < KPW; ++j) {
-        const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);  // 4 unit tiles per k-block
+        for (int j = 0; j < KPW; ++j) {
+          const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);  // 4 unit tiles per k-block
 #pragma unroll
-        for (int t = 0; t < FWD_NB; ++t)
-          raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, FENCED ? 0 : 16);
+          for (int t = 0; t < FWD_NB; ++t) {
+            raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, 16);
+            if (SENTINEL)
+              bad = bad || raw[j][t].x == PERSIST_SENTINEL || raw[j][t].y == PERSIST_SENTINEL ||
+                    raw[j][t].z == PERSIST_SENTINEL || raw[j][t].w == PERSIST_SENTINEL;
+          }
+        }
+        if (!SENTINEL || !__any(bad)) break;
+        if (tries > (1u << 16)) { if (lane == 0) *e.status = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
       }
       // NB: convert the whole vector at once; __builtin_bit_cast on a single
       // ext-vector element (v.y) silently reads element 0 with this compiler.
@@ -484,14 +512,12 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist
         u32x4 pv = {__builtin_bit_cast(unsigned, hv.x), __builtin_bit_cast(unsigned, hv.y),
                     __builtin_bit_cast(unsigned, hv.z), __builtin_bit_cast(unsigned, hv.w)};
         __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
-                                               (int)((int64_t)s * Np * H * 4), FENCED ? 0 : 16);
+                                               (int)((int64_t)s * Np * H * 4), 16);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (FENCED) {
-        if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (!SENTINEL) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -659,7 +685,7 @@ struct EncPersistBwd {
   int S, N, H;
 };
 
-template <int KPW>   // k-blocks per wave = (4H / 16) / 4 = H / 16
+template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
 __global__ __launch_bounds__(256) void lstm_enc_bwd_persistent_kernel(EncPersistBwd e) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -714,21 +740,48 @@ __global__ __launch_bounds__(256) void lstm_enc_bwd_persistent_kernel(EncPersist
     }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (i > 0) {
-      if (tid == 0 && !broken) {
-        const unsigned target = ntile * (unsigned)i;
+      const unsigned sbase = (unsigned)((size_t)sn * step_bytes);
+      if (!SENTINEL) {
+        if (tid == 0 && !broken) {
+          const unsigned target = ntile * (unsigned)i;
+          unsigned spins = 0;
+          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; broken = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      } else if (wave == 0 && !broken) {
+        // one 16-byte piece per (producer tile, gate): k-block g * kt + tl, sub-block 0, column n0
+        const unsigned nprobe = 4u * ntile;
         unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; broken = true; break; }
+        for (;;) {
+          bool ok = true;
+          for (unsigned pb = lane; pb < nprobe; pb += 64) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((pb * 4 * Np + n0) * 16), (int)sbase, 16);
+            ok = ok && v.x != PERSIST_SENTINEL && v.y != PERSIST_SENTINEL && v.z != PERSIST_SENTINEL &&
+                 v.w != PERSIST_SENTINEL;
+          }
+          if (__all(ok)) break;
+          if (++spins > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; broken = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
       __syncthreads();
       u32x4 raw[KPW];
-      const unsigned sbase = (unsigned)((size_t)sn * step_bytes);
+      for (unsigned tries = 0;; ++tries) {
+        bool bad = false;
 #pragma unroll
-      for (int j = 0; j < KPW; ++j)
-        raw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo + (unsigned)((wave + 4 * j) * 4 * Np * 16)),
-                                                       (int)sbase, 16);
+        for (int j = 0; j < KPW; ++j) {
+          raw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo + (unsigned)((wave + 4 * j) * 4 * Np * 16)),
+                                                         (int)sbase, 16);
+          if (SENTINEL)
+            bad = bad || raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
+                  raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
+        }
+        if (!SENTINEL || !__any(bad)) break;
+        if (tries > (1u << 16)) { if (lane == 0) *e.status = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
 #pragma unroll
       for (int j = 0; j < KPW; j += 2) {
         const f32x4 f0 = __builtin_bit_cast(f32x4, raw[j]);
