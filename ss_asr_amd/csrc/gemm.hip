@@ -37,47 +37,88 @@ struct Operand {
   bool vec;     // 16-byte loads are legal
 };
 
-// Loads this thread's share of one BMN x BK operand tile into registers.
+// Per-thread view of one operand's tile stream.  Source offsets are derived
+// ONCE (the row map may need a 64-bit divide) and then advanced by a constant
+// per K step, so the steady-state loop issues plain 16-byte loads with one
+// pointer add each and no predicates.
 template <int BMN, bool T>
-__device__ __forceinline__ void load_tile(const Operand& op, int mn0, int k0, int kend, int tid,
-                                          float4 (&v)[TileGeom<BMN, T>::NV]) {
+struct TileLoader {
+  static constexpr int NV = TileGeom<BMN, T>::NV;
+  static constexpr int PER_ROW = BMN / 4;        // float4 per k-row of an MN-contiguous tile
+  const float* ptr[NV];     // source of this thread's i-th float4 at the current K position
+  int64_t kin[NV];          // T with an (outer, inner) map: position inside the inner run
+  int idx[NV];              // row (or first of 4 mn) this float4 belongs to
+  int kofs[NV];             // k offset of this float4 inside the tile
+  int extent;
+  RowMap m;
+
+  __device__ __forceinline__ void init(const Operand& op, int mn0, int k0, int tid) {
+    extent = op.extent;
+    m = op.m;
 #pragma unroll
-  for (int i = 0; i < TileGeom<BMN, T>::NV; ++i) {
-    const int f = tid + i * 256;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (!T) {
-      const int row = mn0 + f / (BK / 4);
-      const int k = k0 + (f % (BK / 4)) * 4;
-      if (row < op.extent && k < kend) {
-        const float* src = op.p + rm_off(op.m, row) + k;
-        if (op.vec && k + 3 < kend) {
-          x = *reinterpret_cast<const float4*>(src);
-        } else {
-          x.x = src[0];
-          if (k + 1 < kend) x.y = src[1];
-          if (k + 2 < kend) x.z = src[2];
-          if (k + 3 < kend) x.w = src[3];
-        }
-      }
-    } else {
-      constexpr int PER_ROW = BMN / 4;
-      const int k = k0 + f / PER_ROW;
-      const int mn = mn0 + (f % PER_ROW) * 4;
-      if (k < kend && mn < op.extent) {
-        const float* src = op.p + rm_off(op.m, k) + mn;
-        if (op.vec && mn + 3 < op.extent) {
-          x = *reinterpret_cast<const float4*>(src);
-        } else {
-          x.x = src[0];
-          if (mn + 1 < op.extent) x.y = src[1];
-          if (mn + 2 < op.extent) x.z = src[2];
-          if (mn + 3 < op.extent) x.w = src[3];
-        }
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      if constexpr (!T) {
+        const int row = mn0 + f / (BK / 4);
+        idx[i] = row;
+        kofs[i] = (f % (BK / 4)) * 4;
+        ptr[i] = op.p + rm_off(op.m, row < extent ? row : 0) + k0 + kofs[i];
+        kin[i] = 0;
+      } else {
+        idx[i] = mn0 + (f % PER_ROW) * 4;
+        kofs[i] = f / PER_ROW;
+        const int64_t k = (int64_t)k0 + kofs[i];
+        ptr[i] = op.p + rm_off(op.m, k) + idx[i];
+        kin[i] = op.m.inner ? k % op.m.inner : 0;
       }
     }
-    v[i] = x;
   }
-}
+
+  // advance by one K step (BK)
+  __device__ __forceinline__ void advance() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if constexpr (!T) {
+        ptr[i] += BK;
+      } else if (m.inner == 0) {
+        ptr[i] += (int64_t)BK * m.ld;
+      } else {
+        int64_t in = kin[i] + BK;
+        int64_t off = (int64_t)BK * m.si;
+        while (in >= m.inner) { in -= m.inner; off += m.so - m.inner * m.si; }
+        kin[i] = in;
+        ptr[i] += off;
+      }
+    }
+  }
+
+  // interior tile, full K step, 16-byte aligned
+  __device__ __forceinline__ void load_fast(float4 (&v)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(ptr[i]);
+  }
+
+  // edge tiles / last partial K step / unaligned operands
+  __device__ __forceinline__ void load_guarded(float4 (&v)[NV], int k0, int kend, bool vec) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k = k0 + kofs[i];
+      if (k < kend && idx[i] < extent) {
+        const int left = T ? extent - idx[i] : kend - k;   // valid elements along the contiguous axis
+        if (vec && left >= 4) {
+          x = *reinterpret_cast<const float4*>(ptr[i]);
+        } else {
+          x.x = ptr[i][0];
+          if (left > 1) x.y = ptr[i][1];
+          if (left > 2) x.z = ptr[i][2];
+          if (left > 3) x.w = ptr[i][3];
+        }
+      }
+      v[i] = x;
+    }
+  }
+};
 
 template <int BMN, bool T>
 __device__ __forceinline__ void store_tile(float* lds, int tid,
@@ -131,6 +172,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
 
   Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
   Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
+  TileLoader<BM, TA> la;
+  TileLoader<BN, TB> lb;
+  la.init(opA, m0, kbeg, tid);
+  lb.init(opB, n0, kbeg, tid);
+  // whole block inside the matrix and 16-byte loads legal: the steady state is branch free
+  const bool interior = vecA && vecB && m0 + BM <= g.M && n0 + BN <= g.N;
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -140,8 +187,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
 
   float4 ra[GA::NV], rb[GB::NV];
   if (kbeg < kend) {
-    load_tile<BM, TA>(opA, m0, kbeg, kend, tid, ra);
-    load_tile<BN, TB>(opB, n0, kbeg, kend, tid, rb);
+    if (interior && kbeg + BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
+    else { la.load_guarded(ra, kbeg, kend, vecA); lb.load_guarded(rb, kbeg, kend, vecB); }
     store_tile<BM, TA>(lds, tid, ra);
     store_tile<BN, TB>(lds + GA::FLOATS, tid, rb);
   }
@@ -151,8 +198,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) {
-      load_tile<BM, TA>(opA, m0, k0 + BK, kend, tid, ra);
-      load_tile<BN, TB>(opB, n0, k0 + BK, kend, tid, rb);
+      la.advance();
+      lb.advance();
+      if (interior && k0 + 2 * BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
+      else { la.load_guarded(ra, k0 + BK, kend, vecA); lb.load_guarded(rb, k0 + BK, kend, vecB); }
     }
     const float* curA = lds + buf * STAGE;
     const float* curB = curA + GA::FLOATS;
