@@ -62,13 +62,15 @@ struct TileLoader {
         const int row = mn0 + f / (BK / 4);
         idx[i] = row;
         kofs[i] = (f % (BK / 4)) * 4;
-        ptr[i] = op.p + rm_off(op.m, row < extent ? row : 0) + k0 + kofs[i];
+        // rows past the edge read the last row: legal memory, results never stored
+        ptr[i] = op.p + rm_off(op.m, min(row, extent - 1)) + k0 + kofs[i];
         kin[i] = 0;
       } else {
         idx[i] = mn0 + (f % PER_ROW) * 4;
         kofs[i] = f / PER_ROW;
         const int64_t k = (int64_t)k0 + kofs[i];
-        ptr[i] = op.p + rm_off(op.m, k) + idx[i];
+        // float4 groups past the edge read group 0 on the fast path (never stored)
+        ptr[i] = op.p + rm_off(op.m, k) + (idx[i] + 3 < extent || !op.vec ? idx[i] : 0);
         kin[i] = op.m.inner ? k % op.m.inner : 0;
       }
     }
@@ -92,7 +94,8 @@ struct TileLoader {
     }
   }
 
-  // interior tile, full K step, 16-byte aligned
+  // full K step, 16-byte loads legal (and extent % 4 == 0 for an MN-contiguous
+  // operand): no predicates, edge tiles included
   __device__ __forceinline__ void load_fast(float4 (&v)[NV]) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(ptr[i]);
@@ -108,6 +111,12 @@ struct TileLoader {
         const int left = T ? extent - idx[i] : kend - k;   // valid elements along the contiguous axis
         if (vec && left >= 4) {
           x = *reinterpret_cast<const float4*>(ptr[i]);
+        } else if (vec && T) {
+          // ptr was redirected to group 0; rebuild the true address
+          const float* q = ptr[i] + idx[i];
+          x.x = q[0];
+          if (left > 1) x.y = q[1];
+          if (left > 2) x.z = q[2];
         } else {
           x.x = ptr[i][0];
           if (left > 1) x.y = ptr[i][1];
@@ -161,9 +170,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
   const int r = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int bz = blockIdx.z / g.splitk;
-  const int kz = blockIdx.z - bz * g.splitk;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // Workgroups are handed to the 8 XCDs round-robin in launch order and each
+  // XCD has its own L2.  Re-map the launch index so that one XCD works on a
+  // contiguous run of tiles (N fastest, then M, then the split-K / batch
+  // slice): its A row-blocks are then fetched by that XCD only.
+  int bx = blockIdx.x, by = blockIdx.y, bzz = blockIdx.z;
+  {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int total = nx * ny * gridDim.z;
+    const int lin = bx + nx * (by + ny * bzz);
+    const int xcd = lin & 7, j = lin >> 3;
+    const int per = total >> 3, rem = total & 7;
+    const int t = xcd * per + min(xcd, rem) + j;
+    bx = t % nx;
+    const int u = t / nx;
+    by = u % ny;
+    bzz = u / ny;
+  }
+  const int bz = bzz / g.splitk;
+  const int kz = bzz - bz * g.splitk;
+  const int m0 = by * BM, n0 = bx * BN;
 
   int kchunk = (g.K + g.splitk - 1) / g.splitk;
   kchunk = (kchunk + BK - 1) / BK * BK;
@@ -176,8 +202,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
   TileLoader<BN, TB> lb;
   la.init(opA, m0, kbeg, tid);
   lb.init(opB, n0, kbeg, tid);
-  // whole block inside the matrix and 16-byte loads legal: the steady state is branch free
-  const bool interior = vecA && vecB && m0 + BM <= g.M && n0 + BN <= g.N;
+  // 16-byte loads legal everywhere: the steady state is branch free, edge tiles
+  // included (their out-of-range rows alias valid ones and are dropped at the store)
+  const bool interior = vecA && vecB && (!TA || g.M % 4 == 0) && (!TB || g.N % 4 == 0);
 
   f32x4 acc[TM][TN];
 #pragma unroll
