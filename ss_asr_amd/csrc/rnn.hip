@@ -20,6 +20,15 @@ int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, floa
   return SSASR_OK;
 }
 
+// Initial pacing delay of a persistent recurrence (PersistPacer, rnn_kernels.h),
+// in units of 64 cycles; the kernel adapts it from there.
+static int persist_delay(const char* env, int dflt) {
+  const char* v = getenv(env);
+  if (!v) return dflt;
+  const int d = atoi(v);
+  return d < 0 ? 0 : (d > 96 ? 96 : d);
+}
+
 // ---------------------------------------------------------------------------
 // C-ABI: bidirectional LSTM layer over a logical time-major [S, N, I] input.
 // ---------------------------------------------------------------------------
@@ -62,15 +71,17 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     const int kpw = (int)(H / 64);
     const bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
                       chunks == 1 && (H / 4) * 2 * chunks <= 256 && S * Np * H * 4 < (1ll << 31) &&
-                      aligned16(hx) && !getenv("SSASR_NO_PERSISTENT");
+                      aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
+                      ys_n % 4 == 0 && !getenv("SSASR_NO_PERSISTENT");
     if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
     if (fits) {
       EncPersist p{};
       p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
       p.gates = gates; p.cs = cs; p.hs = hs; p.hx = hx; p.y = y; p.lens = lens;
       p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
+      p.delay = persist_delay("SSASR_PERSIST_DELAY_FWD", 24);
       p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
-      dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(256);
+      dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
       // exchange by sentinel (default) or by arrival counter (SSASR_PERSISTENT_COUNTER=1, for A/B)
       const bool sentinel = getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
       if (sentinel) {
@@ -150,8 +161,9 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
       EncPersistBwd p{};
       p.whhT = ws_whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens;
       p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
+      p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 16);
       p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
-      dim3 pgrid((unsigned)(H / 16), 2, (unsigned)chunks), pblock(256);
+      dim3 pgrid((unsigned)(H / 16), 2, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
       if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(2 * S * 4 * H * Np), st));
         if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);

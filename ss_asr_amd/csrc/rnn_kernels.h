@@ -32,6 +32,11 @@
 #pragma once
 #include "common.h"
 
+#ifndef SSASR_PTRACE         // diagnostic builds (tools/persistbench.hip) define these
+#define SSASR_PTRACE(step, slot)
+#define SSASR_PTRACE_H(step, slot)
+#define SSASR_PRETRY(tries)
+#endif
 #ifndef SSASR_STAMP          // diagnostic builds (tools/stepbench.hip) define this
 #define SSASR_STAMP(i)
 #define SSASR_STAMP_DRAIN()
@@ -355,6 +360,7 @@ struct EncPersist {
   const int32_t* lens;
   unsigned* cnt;         // [2][chunks] arrival counters, zero at launch
   int* status;           // set to 1 if a spin timed out
+  int delay;             // initial pacing delay (PersistPacer)
   int ys_s, ys_n;
   int S, N, H;
 };
@@ -370,11 +376,46 @@ constexpr unsigned PERSIST_SENTINEL = 0x7FC0DEADu;   // a NaN: h = o * tanh(c) c
 // tile, then loads its operands and re-loads until no element is the sentinel.
 // That removes the producer's store drain, the atomic and the counter poll
 // from the per-step critical path.
+// Pacing of the operand loads (SENTINEL mode).  Polling the exchange image costs
+// fabric requests that slow down the very stores it waits for (measured: any
+// probe cadence is slower than none), so nothing polls: after a step closes,
+// the helper wave sleeps `delay` x 64 cycles, releases the operand loads through
+// a barrier, and the loads verify themselves against the fill pattern
+// (re-fetching only missing pieces).  The delay adapts per workgroup: a step
+// that needed a re-fetch lengthens it, a run of clean steps shortens it, which
+// settles where about one step in sixteen misses (the measured optimum of a
+// fixed delay had a 5-10 % miss rate).
+struct PersistPacer {
+  int delay;      // in s_sleep(1) units of 64 cycles
+  int clean;      // clean steps since the last change
+  __device__ __forceinline__ void sleep() const {
+    for (int k = 0; k < delay; ++k) __builtin_amdgcn_s_sleep(1);
+  }
+  __device__ __forceinline__ void update(bool missed) {
+    if (missed) { delay = min(delay + 4, 96); clean = 0; }
+    else if (++clean >= 4) { delay = max(delay - 1, 0); clean = 0; }
+  }
+};
+
+// Five waves.  Waves 0-3 own the recurrence (operand loads, matrix product;
+// waves 0 and 1 the gate epilogue, wave 0 the publishing store).  Wave 4 is a
+// helper: it paces the operand loads (SENTINEL: PersistPacer; else it polls the
+// arrival counter) and releases them through a barrier; one step ahead it
+// streams the step's input->hidden pre-activations from HBM into LDS, and one
+// step behind it writes the row-major copies of the results (gates, c, h, y),
+// so that no HBM latency, no scattered store and no address arithmetic for
+// them sits in the recurrence waves.
 template <int KPW, bool SENTINEL>   // k-blocks per wave = H / 64
-__global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
+__global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * FWD_NB * 64];
-  __shared__ __attribute__((aligned(16))) float sH[32 * 4];
+  // step results staged for the helper wave: [i, f, g, o, c, h][column][4 units]
+  __shared__ __attribute__((aligned(16))) float stage[6][16 * FWD_NB][4];
+  __shared__ float addbuf[2][FWD_NB][4][64];     // [parity][epilogue wave][gate][lane]
+  __shared__ int missed;                         // a wave of this step had to re-fetch (feeds the pacer)
+  float* sH = &stage[5][0][0];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) missed = 0;
+  __syncthreads();
   const int r = lane & 15, q = lane >> 4;
   const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
   const int S = e.S, N = e.N, H = e.H;
@@ -383,7 +424,85 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist
   const unsigned ntile = gridDim.x;
   const int64_t rows = (int64_t)S * N;
   unsigned* cnt = e.cnt + d * gridDim.z + chunk;
+  float* gbase = e.gates + (int64_t)d * rows * 4 * H;
+  const size_t xbytes = (size_t)S * Np * H * sizeof(float);
+  float* xbase = e.hx + (int64_t)d * S * Np * H;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)xbytes, 0x00020000);
+  const int u = 4 * tile + q;                   // epilogue lanes and helper lanes: unit u, column n0 + 16 * bt + r
 
+  if (wave == 4) {
+    // ------------------------------ helper wave ------------------------------
+    PersistPacer pacer{e.delay, 0};
+    float nadd[FWD_NB][4];
+    auto fetch = [&](int i) {
+      const int s = d ? S - 1 - i : i;
+#pragma unroll
+      for (int bt = 0; bt < FWD_NB; ++bt) {
+        const int n = n0 + 16 * bt + r;
+        const int64_t g0 = ((int64_t)s * N + (n < N ? n : N - 1)) * 4 * H + u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nadd[bt][g] = gbase[g0 + (int64_t)g * H];
+      }
+    };
+    auto publish = [&](int i) {
+#pragma unroll
+      for (int bt = 0; bt < FWD_NB; ++bt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) addbuf[i & 1][bt][g][lane] = nadd[bt][g];
+    };
+    // Row-major copies of a step's results (activated gates, c, h, y) leave
+    // through this wave one step later, as 16-byte stores: 7 arrays x 32 columns
+    // = 224 pieces of 4 units.
+    float* cbase = e.cs + (int64_t)d * rows * H;
+    float* hbase = e.hs + (int64_t)d * rows * H;
+    auto flush = [&](int i) {
+      const int s = d ? S - 1 - i : i;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = lane + 64 * k;
+        const int a = p / (16 * FWD_NB), col = p % (16 * FWD_NB);
+        const int n = n0 + col;
+        if (a < 7 && n < N) {
+          const float4 v = *reinterpret_cast<const float4*>(&stage[a < 6 ? a : 5][col][0]);
+          const int64_t row = (int64_t)s * N + n;
+          float* dst = a < 4 ? gbase + row * 4 * H + (int64_t)a * H + 4 * tile
+                     : a == 4 ? cbase + row * H + 4 * tile
+                     : a == 5 ? hbase + row * H + 4 * tile
+                              : e.y + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + 4 * tile;
+          *reinterpret_cast<float4*>(dst) = v;
+        }
+      }
+    };
+    fetch(0); publish(0);
+    if (S > 1) fetch(1);
+    for (int i = 0; i < S; ++i) {
+      if (i > 0) {
+        SSASR_PTRACE_H(i, 8);
+        if (SENTINEL) {
+          pacer.sleep();
+        } else if (lane == 0) {
+          const unsigned target = ntile * (unsigned)i;
+          unsigned spins = 0;
+          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        SSASR_PTRACE_H(i, 9);
+        __syncthreads();                              // operand loads released
+      }
+      // addbuf[(i + 1) & 1] was last read in step i - 1
+      if (i + 1 < S) { publish(i + 1); if (i + 2 < S) fetch(i + 2); }
+      if (i > 0) flush(i - 1);                        // stage is rewritten after the next barrier
+      __syncthreads();                                // product done
+      if (SENTINEL && i > 0) { pacer.update(missed != 0); missed = 0; }
+      __syncthreads();                                // epilogue done
+    }
+    flush(S - 1);
+    return;
+  }
+
+  // ---------------------------- recurrence waves -----------------------------
   // this wave's share of the weight tile, resident for the whole layer
   float4 wreg[KPW];
   {
@@ -394,19 +513,10 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist
   }
 
   const int bt = wave;                          // epilogue role of waves 0 and 1
-  const int u = 4 * tile + q;
   const int n = n0 + 16 * bt + r;
   const bool epi = bt < FWD_NB && n < N;
   float cstate = 0.f;
-  bool broken = false;       // a timed-out workgroup stops waiting (results are then invalid)
   const int len = (epi && e.lens) ? e.lens[n] : 0x7fffffff;
-
-  float* gbase = e.gates + (int64_t)d * rows * 4 * H;
-  float* cbase = e.cs + (int64_t)d * rows * H;
-  float* hbase = e.hs + (int64_t)d * rows * H;
-  const size_t xbytes = (size_t)S * Np * H * sizeof(float);
-  float* xbase = e.hx + (int64_t)d * S * Np * H;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)xbytes, 0x00020000);
   unsigned xo[FWD_NB];                           // lane part of the h_{s-1} operand address
 #pragma unroll
   for (int t = 0; t < FWD_NB; ++t) {
@@ -417,60 +527,46 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist
   for (int i = 0; i < S; ++i) {
     const int s = d ? S - 1 - i : i;
     const int sp = d ? s + 1 : s - 1;
-    const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u;
-    float add[4] = {0.f, 0.f, 0.f, 0.f};
-    if (epi) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) add[g] = gbase[g0 + (int64_t)g * H];
-    }
     f32x4 acc[FWD_NB], acc2[FWD_NB];
 #pragma unroll
     for (int t = 0; t < FWD_NB; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    SSASR_PTRACE(i, 0);
     if (i > 0) {
       const unsigned sbase = (unsigned)((int64_t)sp * Np * H * 4);   // step offset in bytes
-      if (!SENTINEL) {
-        if (tid == 0 && !broken) {
-          const unsigned target = ntile * (unsigned)i;
-          unsigned spins = 0;
-          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; broken = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-      } else if (wave == 0 && !broken) {
-        unsigned spins = 0;
-        for (;;) {
-          bool ok = true;
-          for (unsigned tl = lane; tl < ntile; tl += 64) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((tl * Np + n0) * 16), (int)sbase, 16);
-            ok = ok && v.x != PERSIST_SENTINEL && v.y != PERSIST_SENTINEL && v.z != PERSIST_SENTINEL &&
-                 v.w != PERSIST_SENTINEL;
-          }
-          if (__all(ok)) break;
-          if (++spins > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; broken = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      __syncthreads();
+      __syncthreads();                                // released by the helper wave
+      SSASR_PTRACE(i, 2);
       float4 b[KPW][FWD_NB];
       u32x4 raw[KPW][FWD_NB];
-      for (unsigned tries = 0;; ++tries) {
-        bool bad = false;
 #pragma unroll
-        for (int j = 0; j < KPW; ++j) {
-          const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);  // 4 unit tiles per k-block
+      for (int j = 0; j < KPW; ++j) {
+        const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);  // 4 unit tiles per k-block
 #pragma unroll
-          for (int t = 0; t < FWD_NB; ++t) {
-            raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, 16);
-            if (SENTINEL)
-              bad = bad || raw[j][t].x == PERSIST_SENTINEL || raw[j][t].y == PERSIST_SENTINEL ||
-                    raw[j][t].z == PERSIST_SENTINEL || raw[j][t].w == PERSIST_SENTINEL;
-          }
-        }
-        if (!SENTINEL || !__any(bad)) break;
-        if (tries > (1u << 16)) { if (lane == 0) *e.status = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
+        for (int t = 0; t < FWD_NB; ++t)
+          raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, 16);
       }
+      if (SENTINEL) {
+        // re-fetch any piece that still holds the fill pattern
+        for (unsigned tries = 0;; ++tries) {
+          bool anybad = false;
+#pragma unroll
+          for (int j = 0; j < KPW; ++j) {
+            const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);
+#pragma unroll
+            for (int t = 0; t < FWD_NB; ++t) {
+              const bool bad = raw[j][t].x == PERSIST_SENTINEL || raw[j][t].y == PERSIST_SENTINEL ||
+                               raw[j][t].z == PERSIST_SENTINEL || raw[j][t].w == PERSIST_SENTINEL;
+              if (__any(bad)) {
+                anybad = true;
+                raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, 16);
+              }
+            }
+          }
+          if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
+          if (tries > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      SSASR_PTRACE(i, 3);
       // NB: convert the whole vector at once; __builtin_bit_cast on a single
       // ext-vector element (v.y) silently reads element 0 with this compiler.
 #pragma unroll
@@ -485,26 +581,28 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist
     }
 #pragma unroll
     for (int t = 0; t < FWD_NB; ++t) red[(wave * FWD_NB + t) * 64 + lane] = acc[t] + acc2[t];
-    __syncthreads();
+    SSASR_PTRACE(i, 4);
+    __syncthreads();                                  // product done
+    SSASR_PTRACE(i, 5);
     if (epi) {
       const f32x4 p = red_sum<FWD_NB>(red, bt, lane);
-      float gi = fast_sigmoid(p[0] + add[0]), gf = fast_sigmoid(p[1] + add[1]);
-      float gg = fast_tanh(p[2] + add[2]), go = fast_sigmoid(p[3] + add[3]);
+      const float* ab = &addbuf[i & 1][bt][0][lane];
+      float gi = fast_sigmoid(p[0] + ab[0]), gf = fast_sigmoid(p[1] + ab[64]);
+      float gg = fast_tanh(p[2] + ab[128]), go = fast_sigmoid(p[3] + ab[192]);
       float c = gf * cstate + gi * gg;
       float h = go * fast_tanh(c);
       if (s >= len) { gi = gf = gg = go = 0.f; c = 0.f; h = 0.f; }
       cstate = c;
-      sH[(16 * bt + r) * 4 + q] = h;
-      gbase[g0] = gi;
-      gbase[g0 + H] = gf;
-      gbase[g0 + 2 * (int64_t)H] = gg;
-      gbase[g0 + 3 * (int64_t)H] = go;
-      const int64_t hu = ((int64_t)s * N + n) * H + u;
-      cbase[hu] = c;
-      hbase[hu] = h;
-      e.y[(int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + u] = h;
+      const int col = 16 * bt + r;
+      stage[0][col][q] = gi;
+      stage[1][col][q] = gf;
+      stage[2][col][q] = gg;
+      stage[3][col][q] = go;
+      stage[4][col][q] = c;
+      stage[5][col][q] = h;
     }
-    __syncthreads();
+    SSASR_PTRACE(i, 6);
+    __syncthreads();                                  // epilogue done
     if (wave == 0) {
       if (lane < 32 && n0 + lane < Np) {
         const float4 hv = n0 + lane < N ? *reinterpret_cast<const float4*>(sH + lane * 4)
@@ -514,6 +612,7 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_persistent_kernel(EncPersist
         __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
                                                (int)((int64_t)s * Np * H * 4), 16);
       }
+      SSASR_PTRACE(i, 7);
       if (!SENTINEL) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -681,14 +780,28 @@ struct EncPersistBwd {
   const int32_t* lens;
   unsigned* cnt;         // [2][chunks]
   int* status;
+  int delay;             // initial pacing delay (PersistPacer)
   int ys_s, ys_n;
   int S, N, H;
 };
 
 template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
-__global__ __launch_bounds__(256) void lstm_enc_bwd_persistent_kernel(EncPersistBwd e) {
+__global__ __launch_bounds__(320) void lstm_enc_bwd_persistent_kernel(EncPersistBwd e) {
+  // Five waves.  Waves 0-3 own the recurrence (operand loads, matrix product;
+  // wave 0 also the gate epilogue and the publishing stores).  Wave 4 is a
+  // helper: it paces the operand loads (as in the forward kernel) and
+  // releases them through a barrier, and one step
+  // ahead it streams the saved activations of the next step from HBM and folds
+  // them into the per-element coefficients of the gate derivatives, which it
+  // leaves in LDS.  Its HBM latency sits on its own memory counter, and the
+  // 50-odd registers of saved activations and coefficients exist in its loop
+  // only.
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
+  __shared__ __attribute__((aligned(16))) float4 coef[2][7][64];   // [parity][A, O, I, G, F, C, dy][lane]
+  __shared__ int missed;                        // a wave of this step had to re-fetch (feeds the pacer)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) missed = 0;
+  __syncthreads();
   const int r = lane & 15, q = lane >> 4;
   const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
   const int S = e.S, N = e.N, H = e.H;
@@ -698,90 +811,137 @@ __global__ __launch_bounds__(256) void lstm_enc_bwd_persistent_kernel(EncPersist
   const int64_t rows = (int64_t)S * N;
   unsigned* cnt = e.cnt + d * gridDim.z + chunk;
 
+  const int u0 = 16 * tile + 4 * q;             // lane (q, r) of waves 0 and 4: units u0..u0+3 of column n
+  const int n = n0 + r;
+  const bool col_ok = n < N;
+  float* gbase = e.gates + (int64_t)d * rows * 4 * H;
+  const float* cbase = e.cs + (int64_t)d * rows * H;
+
+  if (wave == 4) {
+    // ------------------------------ helper wave ------------------------------
+    const int len = (col_ok && e.lens) ? e.lens[n] : 0x7fffffff;
+    float4 gi, gf, gg, go, cpv, cv, ad;
+    auto fetch = [&](int i) {
+      const int s = d ? i : S - 1 - i;
+      const int sp = d ? s + 1 : s - 1;
+      const bool has_prev = d ? (s < S - 1) : (s > 0);
+      const int64_t hu = ((int64_t)s * N + n) * H + u0;
+      const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
+      gi = ld4(gbase + g0);
+      gf = ld4(gbase + g0 + H);
+      gg = ld4(gbase + g0 + 2 * (int64_t)H);
+      go = ld4(gbase + g0 + 3 * (int64_t)H);
+      cv = ld4(cbase + hu);
+      cpv = has_prev ? ld4(cbase + ((int64_t)sp * N + n) * H + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ad = ld4(e.dy + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + u0);
+    };
+    // dh = product + dy;  dc = dc_carry + dh * A;  d_o = dh * O;  d_i = dc * I;
+    // d_g = dc * G;  d_f = dc * F;  dc_carry' = dc * C
+    auto publish = [&](int i) {
+      const int s = d ? i : S - 1 - i;
+      const bool live = s < len;
+      const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
+      const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
+      const float cp_[4] = {cpv.x, cpv.y, cpv.z, cpv.w}, c_[4] = {cv.x, cv.y, cv.z, cv.w};
+      float kA[4], kO[4], kI[4], kG[4], kF[4], kC[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float tc = fast_tanh(c_[k]);
+        kA[k] = go_[k] * (1.f - tc * tc);
+        kO[k] = live ? tc * go_[k] * (1.f - go_[k]) : 0.f;
+        kI[k] = live ? gg_[k] * gi_[k] * (1.f - gi_[k]) : 0.f;
+        kG[k] = live ? gi_[k] * (1.f - gg_[k] * gg_[k]) : 0.f;
+        kF[k] = live ? cp_[k] * gf_[k] * (1.f - gf_[k]) : 0.f;
+        kC[k] = live ? gf_[k] : 0.f;
+      }
+      float4* c = &coef[i & 1][0][lane];
+      c[0 * 64] = make_float4(kA[0], kA[1], kA[2], kA[3]);
+      c[1 * 64] = make_float4(kO[0], kO[1], kO[2], kO[3]);
+      c[2 * 64] = make_float4(kI[0], kI[1], kI[2], kI[3]);
+      c[3 * 64] = make_float4(kG[0], kG[1], kG[2], kG[3]);
+      c[4 * 64] = make_float4(kF[0], kF[1], kF[2], kF[3]);
+      c[5 * 64] = make_float4(kC[0], kC[1], kC[2], kC[3]);
+      c[6 * 64] = ad;
+    };
+    if (col_ok) { fetch(0); publish(0); if (S > 1) fetch(1); }
+    PersistPacer pacer{e.delay, 0};
+    for (int i = 0; i < S; ++i) {
+      if (i > 0) {
+        SSASR_PTRACE_H(i, 8);
+        if (SENTINEL) {
+          pacer.sleep();
+        } else if (lane == 0) {
+          const unsigned target = ntile * (unsigned)i;
+          unsigned spins = 0;
+          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        SSASR_PTRACE_H(i, 9);
+        __syncthreads();    // operand loads released
+      }
+      // coef[(i + 1) & 1] was last read in step i - 1, which ended at the closing barrier
+      if (col_ok && i + 1 < S) { publish(i + 1); if (i + 2 < S) fetch(i + 2); }
+      __syncthreads();      // product done
+      if (SENTINEL && i > 0) { pacer.update(missed != 0); missed = 0; }
+      __syncthreads();      // step closed
+    }
+    return;
+  }
+
+  // ---------------------------- recurrence waves -----------------------------
   float4 wreg[KPW];
   {
     const float* wp = e.whhT + ((int64_t)d * H + 16 * tile + r) * 4 * H + 4 * q;
 #pragma unroll
     for (int j = 0; j < KPW; ++j) wreg[j] = *reinterpret_cast<const float4*>(wp + (wave + 4 * j) * 16);
   }
-
-  const int u0 = 16 * tile + 4 * q;             // epilogue (wave 0): units u0..u0+3 of column n
-  const int n = n0 + r;
-  const bool epi = wave == 0 && n < N;
-  const int len = (epi && e.lens) ? e.lens[n] : 0x7fffffff;
+  const bool epi = wave == 0 && col_ok;
   float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps
-  bool broken = false;
 
-  float* gbase = e.gates + (int64_t)d * rows * 4 * H;
-  const float* cbase = e.cs + (int64_t)d * rows * H;
   const size_t step_bytes = (size_t)4 * H * Np * sizeof(float);
   float* xbase = e.gx + (int64_t)d * S * 4 * H * Np;
   const __amdgpu_buffer_rsrc_t xrs =
       __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)(step_bytes * S), 0x00020000);
-  const unsigned xo = (unsigned)((q * Np + (n < N ? n : n0)) * 16);
+  const unsigned xo = (unsigned)((q * Np + (col_ok ? n : n0)) * 16);
 
   for (int i = 0; i < S; ++i) {
     const int s = d ? i : S - 1 - i;            // reverse of the forward order
     const int sn = d ? s - 1 : s + 1;           // step published by the previous iteration
-    const int sp = d ? s + 1 : s - 1;           // forward-order predecessor
-    const bool has_prev = d ? (s < S - 1) : (s > 0);
-    const int64_t hu = ((int64_t)s * N + n) * H + u0;
-    const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 gi = z4, gf = z4, gg = z4, go = z4, cpv = z4, cv = z4, ad1 = z4;
-    if (epi) {
-      gi = ld4(gbase + g0);
-      gf = ld4(gbase + g0 + H);
-      gg = ld4(gbase + g0 + 2 * (int64_t)H);
-      go = ld4(gbase + g0 + 3 * (int64_t)H);
-      cv = ld4(cbase + hu);
-      if (has_prev) cpv = ld4(cbase + ((int64_t)sp * N + n) * H + u0);
-      ad1 = ld4(e.dy + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + u0);
-    }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    SSASR_PTRACE(i, 0);
     if (i > 0) {
       const unsigned sbase = (unsigned)((size_t)sn * step_bytes);
-      if (!SENTINEL) {
-        if (tid == 0 && !broken) {
-          const unsigned target = ntile * (unsigned)i;
-          unsigned spins = 0;
-          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; broken = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-      } else if (wave == 0 && !broken) {
-        // one 16-byte piece per (producer tile, gate): k-block g * kt + tl, sub-block 0, column n0
-        const unsigned nprobe = 4u * ntile;
-        unsigned spins = 0;
-        for (;;) {
-          bool ok = true;
-          for (unsigned pb = lane; pb < nprobe; pb += 64) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((pb * 4 * Np + n0) * 16), (int)sbase, 16);
-            ok = ok && v.x != PERSIST_SENTINEL && v.y != PERSIST_SENTINEL && v.z != PERSIST_SENTINEL &&
-                 v.w != PERSIST_SENTINEL;
-          }
-          if (__all(ok)) break;
-          if (++spins > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; broken = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      __syncthreads();
+      __syncthreads();      // released by the helper wave
+      SSASR_PTRACE(i, 2);
+      // (SENTINEL) re-fetch any piece that still holds the fill pattern
       u32x4 raw[KPW];
-      for (unsigned tries = 0;; ++tries) {
-        bool bad = false;
 #pragma unroll
-        for (int j = 0; j < KPW; ++j) {
-          raw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo + (unsigned)((wave + 4 * j) * 4 * Np * 16)),
-                                                         (int)sbase, 16);
-          if (SENTINEL)
-            bad = bad || raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
-                  raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
+      for (int j = 0; j < KPW; ++j)
+        raw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo + (unsigned)((wave + 4 * j) * 4 * Np * 16)),
+                                                       (int)sbase, 16);
+      if (SENTINEL) {
+        for (unsigned tries = 0;; ++tries) {
+          bool anybad = false;
+#pragma unroll
+          for (int j = 0; j < KPW; ++j) {
+            const bool bad = raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
+                             raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
+            if (__any(bad)) {
+              anybad = true;
+              raw[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                  xrs, (int)(xo + (unsigned)((wave + 4 * j) * 4 * Np * 16)), (int)sbase, 16);
+            }
+          }
+          if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
+          if (tries > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; break; }
+          __builtin_amdgcn_s_sleep(2);
         }
-        if (!SENTINEL || !__any(bad)) break;
-        if (tries > (1u << 16)) { if (lane == 0) *e.status = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
       }
+      SSASR_PTRACE(i, 3);
+      // NB: convert the whole vector at once; __builtin_bit_cast on a single
+      // ext-vector element silently reads element 0 with this compiler.
 #pragma unroll
       for (int j = 0; j < KPW; j += 2) {
         const f32x4 f0 = __builtin_bit_cast(f32x4, raw[j]);
@@ -797,29 +957,33 @@ __global__ __launch_bounds__(256) void lstm_enc_bwd_persistent_kernel(EncPersist
       }
     }
     red[wave * 64 + lane] = acc + acc2;
-    __syncthreads();
+    SSASR_PTRACE(i, 4);
+    __syncthreads();        // product done
+    SSASR_PTRACE(i, 5);
     if (wave == 0) {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 di = z4, df = z4, dg = z4, dov = z4;
       if (epi) {
+        const float4* c = &coef[i & 1][0][lane];
+        const float4 cA = c[0 * 64], cO = c[1 * 64], cI = c[2 * 64], cG = c[3 * 64], cF = c[4 * 64],
+                     cC = c[5 * 64], ad1 = c[6 * 64];
         f32x4 dhv = red[lane];
 #pragma unroll
         for (int w = 1; w < 4; ++w) dhv += red[w * 64 + lane];
-        const bool live = s < len;
-        const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
-        const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
-        const float cp_[4] = {cpv.x, cpv.y, cpv.z, cpv.w}, c_[4] = {cv.x, cv.y, cv.z, cv.w};
+        const float kA[4] = {cA.x, cA.y, cA.z, cA.w}, kO[4] = {cO.x, cO.y, cO.z, cO.w};
+        const float kI[4] = {cI.x, cI.y, cI.z, cI.w}, kG[4] = {cG.x, cG.y, cG.z, cG.w};
+        const float kF[4] = {cF.x, cF.y, cF.z, cF.w}, kC[4] = {cC.x, cC.y, cC.z, cC.w};
         const float dc_[4] = {dcv.x, dcv.y, dcv.z, dcv.w}, a1_[4] = {ad1.x, ad1.y, ad1.z, ad1.w};
         float rdi[4], rdf[4], rdg[4], rdo[4], rdc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float dh = dhv[k] + a1_[k];
-          const float tc = fast_tanh(c_[k]);
-          const float dc = dc_[k] + dh * go_[k] * (1.f - tc * tc);
-          rdo[k] = live ? dh * tc * go_[k] * (1.f - go_[k]) : 0.f;
-          rdi[k] = live ? dc * gg_[k] * gi_[k] * (1.f - gi_[k]) : 0.f;
-          rdg[k] = live ? dc * gi_[k] * (1.f - gg_[k] * gg_[k]) : 0.f;
-          rdf[k] = live ? dc * cp_[k] * gf_[k] * (1.f - gf_[k]) : 0.f;
-          rdc[k] = live ? dc * gf_[k] : 0.f;
+          const float dc = dc_[k] + dh * kA[k];
+          rdo[k] = dh * kO[k];
+          rdi[k] = dc * kI[k];
+          rdg[k] = dc * kG[k];
+          rdf[k] = dc * kF[k];
+          rdc[k] = dc * kC[k];
         }
         di = make_float4(rdi[0], rdi[1], rdi[2], rdi[3]);
         df = make_float4(rdf[0], rdf[1], rdf[2], rdf[3]);
@@ -838,15 +1002,20 @@ __global__ __launch_bounds__(256) void lstm_enc_bwd_persistent_kernel(EncPersist
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dov), xrs, (int)(lo + (unsigned)((3 * kt + tile) * 4 * Np * 16)), (int)so, 16);
       }
       if (epi) {
+        const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
         st4(gbase + g0, di);
         st4(gbase + g0 + H, df);
         st4(gbase + g0 + 2 * (int64_t)H, dg);
         st4(gbase + g0 + 3 * (int64_t)H, dov);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      SSASR_PTRACE(i, 6);
+      if (!SENTINEL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      SSASR_PTRACE(i, 7);
     }
-    __syncthreads();      // red is rewritten by the next iteration
+    __syncthreads();      // step closed: red and coef[i & 1] may be rewritten
   }
 }
 
