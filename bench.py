@@ -111,44 +111,92 @@ def attention_roofline(device, B=32, T=100, A=128, E=512, D=256, iters=400):
                 shape=dict(B=B, T=T, A=A, E=E), timing='HIP-graph replay of %d launches, HIP events' % iters)
 
 
-def lstm_step_roofline(device, N=32, H=256, iters=400):
-    """The recurrent step kernel (dominant by time): h[N,H] x W_hh^T[H,4H] plus
-    the gate math, per direction.  Priced against the fp32 MFMA peak although
-    it is latency bound (1 launch = 2 directions = 2 * 2*N*H*4H flops)."""
+def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
+    """The dominant kernels by time: the persistent BPTT recurrence and the
+    persistent forward recurrence of one encoder layer (one launch = S time
+    steps x 2 directions).  Timed live with HIP events on the launching stream
+    around ssasr_bilstm_bwd / ssasr_bilstm_fwd at the workload's second-layer
+    shape.  The backward call is made with dx = dw = NULL, so it runs the two
+    weight transposes (5 us), the fill of the exchange image and the BPTT
+    kernel; the forward call also contains the input->hidden GEMMs, which are
+    timed separately and subtracted.
+
+    Both are priced against the fp32 MFMA peak because the contraction
+    h[N,H] x W_hh[H,4H] is the algorithmic work (2 * 2*N*H*4H flop per step),
+    but they are latency bound: per step one cross-XCD exchange
+    (write-through store -> visible -> load round trip, ~1.3 us on this part)
+    precedes a 16 x 16 x 1024 product per workgroup.  `us_per_step` against
+    `exchange_floor_us` is the honest reading."""
     import ctypes as C
-    from ss_asr_amd import _lib
+    from ss_asr_amd import _lib, ops
     lib = _lib.load()
     g = torch.Generator(device='cpu').manual_seed(6)
-    S, I = 64, 80
-    x = torch.randn(S, N, I, generator=g).to(device)
-    w = [(torch.randn(4 * H, I, generator=g) / 9).to(device), (torch.randn(4 * H, H, generator=g) / 16).to(device),
+    I = 2 * 2 * H                                        # pyramid input of layers 2-3
+    x = (torch.randn(S, N, I, generator=g) / 4).to(device)
+    w = [(torch.randn(4 * H, I, generator=g) / 32).to(device), (torch.randn(4 * H, H, generator=g) / 16).to(device),
          torch.zeros(4 * H, device=device), torch.zeros(4 * H, device=device)] * 2
     y = torch.empty(S, N, 2 * H, device=device)
+    dy = (torch.randn(S, N, 2 * H, generator=g) / 8).to(device)
     gates = torch.empty(2, S * N, 4 * H, device=device)
     cs = torch.empty(2, S * N, H, device=device)
     hs = torch.empty(2, S * N, H, device=device)
+    hx = torch.empty(2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4, device=device)
+    gx = torch.empty(2 * S * 4 * H * ((N + 15) // 16 * 16), device=device)
+    ws_t = torch.empty(2, H, 4 * H, device=device)
+    ws_dc = torch.empty(2, 2, N, H, device=device)
+    sync = torch.zeros(8, device=device, dtype=torch.int32)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    p = lambda t: C.c_void_p(t.data_ptr())
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 
-    def run():
-        lib.ssasr_bilstm_fwd(p(x), N * I, I, S, N, I, H, None, *[p(t) for t in w], p(y), N * 2 * H, 2 * H,
-                             p(gates), p(cs), p(hs), None, None, st)
-    run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(1, iters // S)
+    def fwd():
+        ops.check(lib.ssasr_bilstm_fwd(p(x), N * I, I, S, N, I, H, None, *[p(t) for t in w], p(y), N * 2 * H, 2 * H,
+                                       p(gates), p(cs), p(hs), p(hx), p(sync), st), 'ssasr_bilstm_fwd')
+
+    def bwd():
+        ops.check(lib.ssasr_bilstm_bwd(p(dy), N * 2 * H, 2 * H, p(x), N * I, I, S, N, I, H, None,
+                                       p(w[0]), p(w[1]), p(w[4]), p(w[5]), p(gates), p(cs), p(hs),
+                                       None, N * I, I, None, None, None, None, None, None,
+                                       p(ws_t), p(ws_dc), p(gx), p(sync), st), 'ssasr_bilstm_bwd')
+
+    def i2h():
+        for d in range(2):
+            ops.gemm(x.view(S * N, I), w[4 * d], out=gates[d])
+
+    def timed(fn, n):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n             # us per call
+
+    us_i2h = timed(i2h, reps)
+    us_fwd = timed(fwd, reps) - us_i2h
+    # every bwd call consumes `gates`; the values only have to be finite
+    us_bwd = timed(lambda: (fwd(), bwd()), reps) - us_fwd - us_i2h
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (reps * S)       # includes 1/S of the i2h GEMM
-    flops = 2 * (2.0 * N * H * 4 * H)
-    tf = flops / (us * 1e-6) / 1e12
-    return dict(kernel='lstm_cell_fwd_kernel', bound='mfma', achieved=round(tf, 3), peak=MFMA_F32_PEAK_TF,
-                unit='TFLOP/s', frac=round(tf / MFMA_F32_PEAK_TF, 5), traffic=None,
-                flops_per_launch=flops, us_per_launch=round(us, 3),
-                note='latency bound: one launch per time step; floor = kernel boundary ~1.45 us')
+    if int(sync[4]):
+        raise RuntimeError('persistent recurrence timed out')
+    flops = S * 2 * (2.0 * N * H * 4 * H)
+    # algorithmic HBM bytes per step and direction: saved gates in, gate derivatives out (N*4H each),
+    # c, c_prev, dy in (N*H each); forward: pre-activations in, gates + c + h + y out
+    bytes_bwd = S * 2 * (N * H * 4) * (4 + 4 + 3)
+    bytes_fwd = S * 2 * (N * H * 4) * (4 + 4 + 3)
+    out = []
+    for name, us, nbytes in (('lstm_enc_bwd_persistent_kernel<16, true>', us_bwd, bytes_bwd),
+                             ('lstm_enc_fwd_persistent_kernel<4, true>', us_fwd, bytes_fwd)):
+        tf = flops / (us * 1e-6) / 1e12
+        out.append(dict(kernel=name, bound='mfma', achieved=round(tf, 3), peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
+                        frac=round(tf / MFMA_F32_PEAK_TF, 5), traffic=None, flops_per_launch=flops,
+                        us_per_launch=round(us, 1), us_per_step=round(us / S, 3), exchange_floor_us=1.3,
+                        algorithmic_bytes_per_launch=nbytes,
+                        hbm_frac=round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        shape=dict(S=S, N=N, H=H, directions=2),
+                        note='latency bound: one cross-XCD exchange per time step; see DESIGN.md 4.2'))
+    return out
 
 
 def cpu_baseline(batch):
@@ -238,6 +286,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     last_loss = float(loss.detach()) if loss is not None else float('nan')
+    from ss_asr_amd import ops
+    ops.check_persistent_status()             # a timed-out persistent recurrence voids the run
     if rank == 0:
         note('gpu: %d steps in %.3f s -> %.1f utt/s (loss %.4f)' % (args.steps, dt, world * args.batch * args.steps / dt, last_loss))
 
@@ -260,10 +310,19 @@ def main():
     if not args.no_roofline:
         att = attention_roofline(device)
         note('attention kernel: %s' % att)
-        rec = lstm_step_roofline(device)
-        note('recurrent step kernel: %s' % rec)
-        out['roofline'] = att
-        out['roofline_recurrent_step'] = rec
+        bptt, fwd_rec = recurrence_roofline(device)
+        note('BPTT recurrence: %s' % bptt)
+        note('forward recurrence: %s' % fwd_rec)
+        traffic = os.path.join(ROOT, 'profiles', 'r01_traffic.json')    # rocprofv3 --pmc passes, see profiles/README.md
+        if os.path.exists(traffic):
+            with open(traffic) as f:
+                t = json.load(f)
+            bptt['traffic'] = t.get('bptt_bytes_per_launch')
+            fwd_rec['traffic'] = t.get('fwd_bytes_per_launch')
+            att['traffic'] = t.get('attention_bytes_per_launch')
+        out['roofline'] = bptt                       # dominant kernel of the step (profiles/)
+        out['roofline_forward_recurrence'] = fwd_rec
+        out['roofline_attention'] = att
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(host_batches[nb // 2])
     print(json.dumps(out), flush=True)
