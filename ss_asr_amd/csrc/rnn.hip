@@ -67,10 +67,16 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   // One persistent launch when the whole grid is certain to be resident
   // (rnn_kernels.h, "persistent forward recurrence"); else one launch per step.
   {
-    const int64_t chunks = (N + 31) / 32, Np = (N + 7) & ~(int64_t)7;
+    // 16 columns per workgroup spreads a layer over twice the workgroups (shorter
+    // product, half the exchange read per workgroup) when they all fit the chip;
+    // else 32 columns.  SSASR_FWD_NB=1|2 forces one for A/B.
     const int kpw = (int)(H / 64);
+    const int64_t Np = (N + 7) & ~(int64_t)7;
+    int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
+    if (const char* v = getenv("SSASR_FWD_NB")) nb = atoi(v) == 1 ? 1 : 2;
+    const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
     const bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
-                      chunks == 1 && (H / 4) * 2 * chunks <= 256 && S * Np * H * 4 < (1ll << 31) &&
+                      (H / 4) * 2 * chunks <= 256 && S * Np * H * 4 < (1ll << 31) &&
                       aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
                       ys_n % 4 == 0 && !getenv("SSASR_NO_PERSISTENT");
     if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
@@ -84,18 +90,23 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
       // exchange by sentinel (default) or by arrival counter (SSASR_PERSISTENT_COUNTER=1, for A/B)
       const bool sentinel = getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
-      if (sentinel) {
+      if (sentinel)
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * Np * H), st));
-        if (kpw == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<1, true>), pgrid, pblock, 0, st, p);
-        else if (kpw == 2) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<2, true>), pgrid, pblock, 0, st, p);
-        else if (kpw == 4) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
-        else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<8, true>), pgrid, pblock, 0, st, p);
-      } else {
-        if (kpw == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<1, false>), pgrid, pblock, 0, st, p);
-        else if (kpw == 2) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<2, false>), pgrid, pblock, 0, st, p);
-        else if (kpw == 4) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, false>), pgrid, pblock, 0, st, p);
-        else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<8, false>), pgrid, pblock, 0, st, p);
-      }
+#define SSASR_FWD_LAUNCH(K, SEN, NBT) \
+      hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<K, SEN, NBT>), pgrid, pblock, 0, st, p)
+#define SSASR_FWD_PICK(SEN, NBT)                                    \
+      do {                                                          \
+        if (kpw == 1) SSASR_FWD_LAUNCH(1, SEN, NBT);                \
+        else if (kpw == 2) SSASR_FWD_LAUNCH(2, SEN, NBT);           \
+        else if (kpw == 4) SSASR_FWD_LAUNCH(4, SEN, NBT);           \
+        else SSASR_FWD_LAUNCH(8, SEN, NBT);                         \
+      } while (0)
+      if (sentinel && nb == 1) SSASR_FWD_PICK(true, 1);
+      else if (sentinel) SSASR_FWD_PICK(true, 2);
+      else if (nb == 1) SSASR_FWD_PICK(false, 1);
+      else SSASR_FWD_PICK(false, 2);
+#undef SSASR_FWD_PICK
+#undef SSASR_FWD_LAUNCH
       SSASR_LAUNCH_CHECK();
       return SSASR_OK;
     }

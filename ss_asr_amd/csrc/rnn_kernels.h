@@ -405,12 +405,12 @@ struct PersistPacer {
 // step behind it writes the row-major copies of the results (gates, c, h, y),
 // so that no HBM latency, no scattered store and no address arithmetic for
 // them sits in the recurrence waves.
-template <int KPW, bool SENTINEL>   // k-blocks per wave = H / 64
+template <int KPW, bool SENTINEL, int NB>   // k-blocks per wave = H / 64; NB x 16 batch columns per workgroup
 __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[4 * FWD_NB * 64];
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * NB * 64];
   // step results staged for the helper wave: [i, f, g, o, c, h][column][4 units]
-  __shared__ __attribute__((aligned(16))) float stage[6][16 * FWD_NB][4];
-  __shared__ float addbuf[2][FWD_NB][4][64];     // [parity][epilogue wave][gate][lane]
+  __shared__ __attribute__((aligned(16))) float stage[6][16 * NB][4];
+  __shared__ float addbuf[2][NB][4][64];     // [parity][epilogue wave][gate][lane]
   __shared__ int missed;                         // a wave of this step had to re-fetch (feeds the pacer)
   float* sH = &stage[5][0][0];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   const int r = lane & 15, q = lane >> 4;
   const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
   const int S = e.S, N = e.N, H = e.H;
-  const int n0 = chunk * 32;
+  const int n0 = chunk * 16 * NB;
   const int Np = (N + 7) & ~7;                 // image columns: 128-byte lines never shared by two tiles
   const unsigned ntile = gridDim.x;
   const int64_t rows = (int64_t)S * N;
@@ -433,11 +433,11 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   if (wave == 4) {
     // ------------------------------ helper wave ------------------------------
     PersistPacer pacer{e.delay, 0};
-    float nadd[FWD_NB][4];
+    float nadd[NB][4];
     auto fetch = [&](int i) {
       const int s = d ? S - 1 - i : i;
 #pragma unroll
-      for (int bt = 0; bt < FWD_NB; ++bt) {
+      for (int bt = 0; bt < NB; ++bt) {
         const int n = n0 + 16 * bt + r;
         const int64_t g0 = ((int64_t)s * N + (n < N ? n : N - 1)) * 4 * H + u;
 #pragma unroll
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
     };
     auto publish = [&](int i) {
 #pragma unroll
-      for (int bt = 0; bt < FWD_NB; ++bt)
+      for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) addbuf[i & 1][bt][g][lane] = nadd[bt][g];
     };
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int p = lane + 64 * k;
-        const int a = p / (16 * FWD_NB), col = p % (16 * FWD_NB);
+        const int a = p / (16 * NB), col = p % (16 * NB);
         const int n = n0 + col;
         if (a < 7 && n < N) {
           const float4 v = *reinterpret_cast<const float4*>(&stage[a < 6 ? a : 5][col][0]);
@@ -514,12 +514,12 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
 
   const int bt = wave;                          // epilogue role of waves 0 and 1
   const int n = n0 + 16 * bt + r;
-  const bool epi = bt < FWD_NB && n < N;
+  const bool epi = bt < NB && n < N;
   float cstate = 0.f;
   const int len = (epi && e.lens) ? e.lens[n] : 0x7fffffff;
-  unsigned xo[FWD_NB];                           // lane part of the h_{s-1} operand address
+  unsigned xo[NB];                           // lane part of the h_{s-1} operand address
 #pragma unroll
-  for (int t = 0; t < FWD_NB; ++t) {
+  for (int t = 0; t < NB; ++t) {
     const int nn = n0 + 16 * t + r;
     xo[t] = (unsigned)((q * Np + (nn < N ? nn : 0)) * 16);
   }
@@ -527,21 +527,21 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   for (int i = 0; i < S; ++i) {
     const int s = d ? S - 1 - i : i;
     const int sp = d ? s + 1 : s - 1;
-    f32x4 acc[FWD_NB], acc2[FWD_NB];
+    f32x4 acc[NB], acc2[NB];
 #pragma unroll
-    for (int t = 0; t < FWD_NB; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < NB; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     SSASR_PTRACE(i, 0);
     if (i > 0) {
       const unsigned sbase = (unsigned)((int64_t)sp * Np * H * 4);   // step offset in bytes
       __syncthreads();                                // released by the helper wave
       SSASR_PTRACE(i, 2);
-      float4 b[KPW][FWD_NB];
-      u32x4 raw[KPW][FWD_NB];
+      float4 b[KPW][NB];
+      u32x4 raw[KPW][NB];
 #pragma unroll
       for (int j = 0; j < KPW; ++j) {
         const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);  // 4 unit tiles per k-block
 #pragma unroll
-        for (int t = 0; t < FWD_NB; ++t)
+        for (int t = 0; t < NB; ++t)
           raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, 16);
       }
       if (SENTINEL) {
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
           for (int j = 0; j < KPW; ++j) {
             const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);
 #pragma unroll
-            for (int t = 0; t < FWD_NB; ++t) {
+            for (int t = 0; t < NB; ++t) {
               const bool bad = raw[j][t].x == PERSIST_SENTINEL || raw[j][t].y == PERSIST_SENTINEL ||
                                raw[j][t].z == PERSIST_SENTINEL || raw[j][t].w == PERSIST_SENTINEL;
               if (__any(bad)) {
@@ -572,20 +572,20 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
 #pragma unroll
       for (int j = 0; j < KPW; ++j) {
 #pragma unroll
-        for (int t = 0; t < FWD_NB; ++t) {
+        for (int t = 0; t < NB; ++t) {
           const f32x4 f = __builtin_bit_cast(f32x4, raw[j][t]);
           b[j][t] = make_float4(f[0], f[1], f[2], f[3]);
         }
       }
-      seg_group_mma<FWD_NB, KPW>(acc, acc2, wreg, b, KPW);
+      seg_group_mma<NB, KPW>(acc, acc2, wreg, b, KPW);
     }
 #pragma unroll
-    for (int t = 0; t < FWD_NB; ++t) red[(wave * FWD_NB + t) * 64 + lane] = acc[t] + acc2[t];
+    for (int t = 0; t < NB; ++t) red[(wave * NB + t) * 64 + lane] = acc[t] + acc2[t];
     SSASR_PTRACE(i, 4);
     __syncthreads();                                  // product done
     SSASR_PTRACE(i, 5);
     if (epi) {
-      const f32x4 p = red_sum<FWD_NB>(red, bt, lane);
+      const f32x4 p = red_sum<NB>(red, bt, lane);
       const float* ab = &addbuf[i & 1][bt][0][lane];
       float gi = fast_sigmoid(p[0] + ab[0]), gf = fast_sigmoid(p[1] + ab[64]);
       float gg = fast_tanh(p[2] + ab[128]), go = fast_sigmoid(p[3] + ab[192]);
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
     SSASR_PTRACE(i, 6);
     __syncthreads();                                  // epilogue done
     if (wave == 0) {
-      if (lane < 32 && n0 + lane < Np) {
+      if (lane < 16 * NB && n0 + lane < Np) {
         const float4 hv = n0 + lane < N ? *reinterpret_cast<const float4*>(sH + lane * 4)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         u32x4 pv = {__builtin_bit_cast(unsigned, hv.x), __builtin_bit_cast(unsigned, hv.y),

@@ -118,14 +118,16 @@ int main(int argc, char** argv) {
   pb.whhT = whhT; pb.gates = gates; pb.cs = cs; pb.dy = dy; pb.gx = gx; pb.lens = nullptr;
   pb.cnt = (unsigned*)sync; pb.status = sync + 4; pb.delay = getenv("DELAY_B") ? atoi(getenv("DELAY_B")) : 16;
   pb.ys_s = (int)ys_s; pb.ys_n = (int)ys_n; pb.S = (int)S; pb.N = (int)N; pb.H = (int)H;
-  const int chF = (int)((N + 31) / 32), chB = (int)((N + 15) / 16);
+  const int nbF = getenv("NB_F") ? atoi(getenv("NB_F")) : 2;
+  const int chF = (int)((N + 16 * nbF - 1) / (16 * nbF)), chB = (int)((N + 15) / 16);
 
   float ms; int status;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemsetAsync(sync, 0, 32, st));
     CK(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * NpF * H), st));
     CK(hipEventRecord(e0, st));
-    hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true>), dim3(H / 4, 2, chF), dim3(320), 0, st, pf);
+    if (nbF == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 1>), dim3(H / 4, 2, chF), dim3(320), 0, st, pf);
+    else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 2>), dim3(H / 4, 2, chF), dim3(320), 0, st, pf);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
