@@ -65,8 +65,10 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
  * of b_ih and of b_hh alike.  Workspaces: ws_whhT [2][H][4H], ws_dc [2][2][N][H].
  * dw_ih_f == NULL defers every weight gradient to ssasr_bilstm_wgrad.
  * Optional, enabling the single-launch persistent BPTT (H in {64,128,256},
- * N <= 32): gx [2][S][4H][roundup(N,16)] floats, sync_ws int32[8]; NULL = one
+ * N <= 32): gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats of exchange
+ * workspace (contents irrelevant on entry), sync_ws int32[8]; NULL = one
  * launch per step. */
+int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);
 int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
                      int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H, const int32_t* lens,
                      const float* w_ih_f, const float* w_hh_f, const float* w_ih_r,

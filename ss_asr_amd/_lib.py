@@ -61,6 +61,7 @@ SIGNATURES = {
     'ssasr_ce_loss_bwd': (I32, [P, P, P, P, P, I64, I64, I64, P, P]),
     'ssasr_clip_adadelta_ws': (I64, [I64]),
     'ssasr_clip_adadelta': (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, P, P, P]),
+    'ssasr_bilstm_bwd_gx_floats': (I64, [I64, I64, I64]),
     'ssasr_frame_lengths': (I32, [P, I64, I64, I64, P, P]),
     'ssasr_logmel_frames': (I64, [I64, I64]),
     'ssasr_logmel': (I32, [P, I64, I64, I64, I64, P, P, P, P, P, P, P, P]),

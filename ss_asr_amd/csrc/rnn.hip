@@ -128,6 +128,16 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
                                   float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
                                   int accumulate, void* stream);
 
+// Exchange workspace of the persistent BPTT: the larger of the gather form's
+// per-step image and the K-split form's ring (0: no persistent form for this shape).
+extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
+  if (S <= 0 || N <= 0 || N > 32 || (H != 64 && H != 128 && H != 256)) return 0;
+  const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
+  const int64_t gather = 2 * S * 4 * H * Np;
+  const int64_t ring = 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;
+  return gather > ring ? gather : ring;
+}
+
 // Backward of the layer.  `gates` is consumed: on return it holds the gate
 // pre-activation derivatives.  dw_* / db_* are overwritten.
 extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
@@ -175,7 +185,15 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
       p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 16);
       p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
       dim3 pgrid((unsigned)(H / 16), 2, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
-      if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
+      if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr) {
+        // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
+        const size_t ring = (size_t)2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
+        p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
+        if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1>), pgrid, pblock, 0, st, p);
+        else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2>), pgrid, pblock, 0, st, p);
+        else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4>), pgrid, pblock, 0, st, p);
+      } else if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(2 * S * 4 * H * Np), st));
         if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
         else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, true>), pgrid, pblock, 0, st, p);

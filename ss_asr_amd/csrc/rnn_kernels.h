@@ -1019,6 +1019,265 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_persistent_kernel(EncPersist
   }
 }
 
+// ----------- persistent backward recurrence, K split (reduce-scatter) -----------
+// Same ownership as above (a workgroup = 16 hidden units x 16 columns of one
+// direction) but the product is split over K instead of over the outputs: a
+// workgroup multiplies only ITS 64 gate-derivative rows into partial dh tiles
+// for ALL H units (W_hh^T slice [H][64] resident in registers, 64 MFMAs per
+// wave as before) and sends tile i to the workgroup that owns units 16i..;
+// the owner adds the H/16 partial tiles it receives.  Per step a workgroup
+// then reads H/16 KB (16 KB at H = 256) from the fabric instead of the whole
+// 64 KB gate-derivative image, which is what bounded the gather form.
+//
+// Exchange image: [dir][chunk][slot][dest tile][source tile][lane][4] floats;
+// lane (q, r) of the producing wave holds rows 4q..4q+3 of column r of the MFMA
+// result, which is exactly what lane (q, r) of the consumer's epilogue wants,
+// so a tile travels as one 1 KB store instruction (8 whole lines).  Slots form
+// a ring of BWD_RS_RING steps: after a workgroup has consumed a slot its helper
+// wave re-arms it with the fill pattern and drains that store before the
+// workgroup publishes anything else, so the next writer of the slot (RING
+// steps later, and only after it has consumed data published after the drain)
+// cannot be overtaken; a violated assumption could only show as a timeout,
+// never as wrong data.  The host fills the ring once per launch (8 MB).
+constexpr int BWD_RS_RING = 8;
+
+struct BpttSaved {        // helper-wave state: saved activations of one step -> coefficients
+  float4 gi, gf, gg, go, cpv, cv, ad;
+  __device__ __forceinline__ void fetch(const EncPersistBwd& e, const float* gbase, const float* cbase, int d,
+                                        int i, int n, int u0) {
+    const int S = e.S, N = e.N, H = e.H;
+    const int s = d ? i : S - 1 - i;
+    const int sp = d ? s + 1 : s - 1;
+    const bool has_prev = d ? (s < S - 1) : (s > 0);
+    const int64_t hu = ((int64_t)s * N + n) * H + u0;
+    const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
+    gi = ld4(gbase + g0);
+    gf = ld4(gbase + g0 + H);
+    gg = ld4(gbase + g0 + 2 * (int64_t)H);
+    go = ld4(gbase + g0 + 3 * (int64_t)H);
+    cv = ld4(cbase + hu);
+    cpv = has_prev ? ld4(cbase + ((int64_t)sp * N + n) * H + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ad = ld4(e.dy + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + u0);
+  }
+  // dh = product + dy;  dc = dc_carry + dh * A;  d_o = dh * O;  d_i = dc * I;
+  // d_g = dc * G;  d_f = dc * F;  dc_carry' = dc * C
+  __device__ __forceinline__ void publish(float4* c /* &coef[parity][0][lane] */, bool live) const {
+    const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
+    const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
+    const float cp_[4] = {cpv.x, cpv.y, cpv.z, cpv.w}, c_[4] = {cv.x, cv.y, cv.z, cv.w};
+    float kA[4], kO[4], kI[4], kG[4], kF[4], kC[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float tc = fast_tanh(c_[k]);
+      kA[k] = go_[k] * (1.f - tc * tc);
+      kO[k] = live ? tc * go_[k] * (1.f - go_[k]) : 0.f;
+      kI[k] = live ? gg_[k] * gi_[k] * (1.f - gi_[k]) : 0.f;
+      kG[k] = live ? gi_[k] * (1.f - gg_[k] * gg_[k]) : 0.f;
+      kF[k] = live ? cp_[k] * gf_[k] * (1.f - gf_[k]) : 0.f;
+      kC[k] = live ? gf_[k] : 0.f;
+    }
+    c[0 * 64] = make_float4(kA[0], kA[1], kA[2], kA[3]);
+    c[1 * 64] = make_float4(kO[0], kO[1], kO[2], kO[3]);
+    c[2 * 64] = make_float4(kI[0], kI[1], kI[2], kI[3]);
+    c[3 * 64] = make_float4(kG[0], kG[1], kG[2], kG[3]);
+    c[4 * 64] = make_float4(kF[0], kF[1], kF[2], kF[3]);
+    c[5 * 64] = make_float4(kC[0], kC[1], kC[2], kC[3]);
+    c[6 * 64] = ad;
+  }
+};
+
+template <int TPW>   // unit tiles per wave = (H / 16) / 4: products out, partial tiles in
+__global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
+  __shared__ __attribute__((aligned(16))) float4 coef[2][7][64];   // [parity][A, O, I, G, F, C, dy][lane]
+  __shared__ __attribute__((aligned(16))) float4 sG[4][64];        // gate derivatives of this step: [gate][lane (q, r)]
+  __shared__ int missed;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) missed = 0;
+  __syncthreads();
+  const int r = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
+  const int S = e.S, N = e.N, H = e.H;
+  constexpr int T = 4 * TPW;                    // unit tiles = H / 16
+  const int n0 = chunk * 16;
+  const int64_t rows = (int64_t)S * N;
+  const int u0 = 16 * tile + 4 * q;             // lane (q, r) of waves 0 and 4: units u0..u0+3 of column n
+  const int n = n0 + r;
+  const bool col_ok = n < N;
+  float* gbase = e.gates + (int64_t)d * rows * 4 * H;
+  const float* cbase = e.cs + (int64_t)d * rows * H;
+
+  // exchange ring of this (direction, chunk) group
+  constexpr unsigned TILE_B = 64 * 16;                        // bytes of one partial tile
+  constexpr unsigned SLOT_B = (unsigned)T * T * TILE_B;       // one step of one group
+  float* xbase = e.gx + ((int64_t)d * gridDim.z + chunk) * (BWD_RS_RING * (int64_t)(SLOT_B / 4));
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)(BWD_RS_RING * SLOT_B), 0x00020000);
+
+  if (wave == 4) {
+    // ------------------------------ helper wave ------------------------------
+    const int len = (col_ok && e.lens) ? e.lens[n] : 0x7fffffff;
+    BpttSaved sv;
+    auto live = [&](int i) { return (d ? i : S - 1 - i) < len; };
+    if (col_ok) {
+      sv.fetch(e, gbase, cbase, d, 0, n, u0);
+      sv.publish(&coef[0][0][lane], live(0));
+      if (S > 1) sv.fetch(e, gbase, cbase, d, 1, n, u0);
+    }
+    PersistPacer pacer{e.delay, 0};
+    const u32x4 fill = {PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL};
+    for (int i = 0; i < S; ++i) {
+      if (i > 0) {
+        pacer.sleep();
+        // the re-arm stores of the previous step must have landed before this
+        // workgroup publishes again (see the ring argument above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();    // operand loads released
+      }
+      if (col_ok && i + 1 < S) {
+        sv.publish(&coef[(i + 1) & 1][0][lane], live(i + 1));
+        if (i + 2 < S) sv.fetch(e, gbase, cbase, d, i + 2, n, u0);
+      }
+      __syncthreads();      // partial tiles summed per wave (red), loads verified
+      if (i > 0) {
+        pacer.update(missed != 0);
+        missed = 0;
+        // re-arm what this workgroup consumed: slot (i - 1) % RING, dest = tile, all sources
+        const unsigned base = (unsigned)((i - 1) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
+      }
+      __syncthreads();      // gate derivatives in LDS
+    }
+    return;
+  }
+
+  // ---------------------------- recurrence waves -----------------------------
+  // W_hh^T slice: A[m = hidden unit][k = this workgroup's gate rows], wave w owns
+  // unit tiles TPW*w .. ; k-block g = gate g, lane (q, r) holds k = 4q..4q+3 of it
+  float4 wreg[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int unit = 16 * (TPW * wave + t) + r;
+    const float* wp = e.whhT + ((int64_t)d * H + unit) * 4 * H + 16 * tile + 4 * q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wreg[t][g] = *reinterpret_cast<const float4*>(wp + (int64_t)g * H);
+  }
+  const bool epi = wave == 0 && col_ok;
+  float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps
+
+  for (int i = 0; i < S; ++i) {
+    const int s = d ? i : S - 1 - i;            // reverse of the forward order
+    f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+    SSASR_PTRACE(i, 0);
+    if (i > 0) {
+      __syncthreads();      // released by the helper wave
+      SSASR_PTRACE(i, 2);
+      // partial tiles for this workgroup's units from sources TPW*wave .. (+TPW)
+      const unsigned base = (unsigned)((i - 1) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
+      u32x4 raw[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((TPW * wave + t) * TILE_B + lane * 16), (int)base, 16);
+      for (unsigned tries = 0;; ++tries) {
+        bool anybad = false;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const bool bad = raw[t].x == PERSIST_SENTINEL || raw[t].y == PERSIST_SENTINEL ||
+                           raw[t].z == PERSIST_SENTINEL || raw[t].w == PERSIST_SENTINEL;
+          if (__any(bad)) {
+            anybad = true;
+            raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((TPW * wave + t) * TILE_B + lane * 16),
+                                                           (int)base, 16);
+          }
+        }
+        if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
+        if (tries > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      SSASR_PTRACE(i, 3);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) part += __builtin_bit_cast(f32x4, raw[t]);
+    }
+    red[wave * 64 + lane] = part;
+    SSASR_PTRACE(i, 4);
+    __syncthreads();        // partial sums in LDS
+    SSASR_PTRACE(i, 5);
+    if (wave == 0) {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 di = z4, df = z4, dg = z4, dov = z4;
+      if (epi) {
+        const float4* c = &coef[i & 1][0][lane];
+        const float4 cA = c[0 * 64], cO = c[1 * 64], cI = c[2 * 64], cG = c[3 * 64], cF = c[4 * 64],
+                     cC = c[5 * 64], ad1 = c[6 * 64];
+        f32x4 dhv = red[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) dhv += red[w * 64 + lane];
+        const float kA[4] = {cA.x, cA.y, cA.z, cA.w}, kO[4] = {cO.x, cO.y, cO.z, cO.w};
+        const float kI[4] = {cI.x, cI.y, cI.z, cI.w}, kG[4] = {cG.x, cG.y, cG.z, cG.w};
+        const float kF[4] = {cF.x, cF.y, cF.z, cF.w}, kC[4] = {cC.x, cC.y, cC.z, cC.w};
+        const float dc_[4] = {dcv.x, dcv.y, dcv.z, dcv.w}, a1_[4] = {ad1.x, ad1.y, ad1.z, ad1.w};
+        float rdi[4], rdf[4], rdg[4], rdo[4], rdc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dh = dhv[k] + a1_[k];
+          const float dc = dc_[k] + dh * kA[k];
+          rdo[k] = dh * kO[k];
+          rdi[k] = dc * kI[k];
+          rdg[k] = dc * kG[k];
+          rdf[k] = dc * kF[k];
+          rdc[k] = dc * kC[k];
+        }
+        di = make_float4(rdi[0], rdi[1], rdi[2], rdi[3]);
+        df = make_float4(rdf[0], rdf[1], rdf[2], rdf[3]);
+        dg = make_float4(rdg[0], rdg[1], rdg[2], rdg[3]);
+        dov = make_float4(rdo[0], rdo[1], rdo[2], rdo[3]);
+        dcv = make_float4(rdc[0], rdc[1], rdc[2], rdc[3]);
+      }
+      sG[0][lane] = di;
+      sG[1][lane] = df;
+      sG[2][lane] = dg;
+      sG[3][lane] = dov;
+      if (epi) {          // row-major copy for the dX and weight-gradient GEMMs
+        const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
+        st4(gbase + g0, di);
+        st4(gbase + g0 + H, df);
+        st4(gbase + g0 + 2 * (int64_t)H, dg);
+        st4(gbase + g0 + 3 * (int64_t)H, dov);
+      }
+      SSASR_PTRACE(i, 6);
+    }
+    __syncthreads();        // gate derivatives in LDS
+    if (i + 1 < S) {
+      // partial dh tiles of all units from this workgroup's 64 gate-derivative rows
+      float4 b[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[g] = sG[g][lane];
+      f32x4 acc[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].x, b[g].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].y, b[g].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].z, b[g].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].w, b[g].w, acc[t], 0, 0, 0);
+      }
+      const unsigned base = (unsigned)(i % BWD_RS_RING) * SLOT_B + (unsigned)tile * TILE_B;   // source = this tile
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), xrs,
+                                               (int)((TPW * wave + t) * T * TILE_B + lane * 16), (int)base, 16);
+      SSASR_PTRACE(i, 7);
+    }
+  }
+}
+
 // out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:], plain store.  Used for the
 // context gradient of the speller's first cell.
 struct PlainMm {

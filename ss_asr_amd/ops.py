@@ -167,8 +167,8 @@ class _BiLSTM(torch.autograd.Function):
         ws_t = torch.empty(2, H, 4 * H, device=dev)
         ws_dc = torch.empty(2, 2, N, H, device=dev)
         # workspaces of the persistent BPTT (exchange image + counters)
-        gx = torch.empty(2 * S * 4 * H * ((N + 15) // 16 * 16), device=dev,
-                         dtype=torch.float32) if N <= 32 and H in (64, 128, 256) else None
+        gx_floats = int(lib.ssasr_bilstm_bwd_gx_floats(S, N, H))
+        gx = torch.empty(gx_floats, device=dev, dtype=torch.float32) if gx_floats else None
         sync = torch.empty(8, device=dev, dtype=torch.int32) if gx is not None else None
         if sync is not None:
             _persist_status.append((sync, 4))

@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&whh, sizeof(float) * 2 * 4 * H * H));
   CK(hipMalloc(&whhT, sizeof(float) * 2 * 4 * H * H));
   CK(hipMalloc(&hx, sizeof(float) * 2 * S * NpF * H));
-  CK(hipMalloc(&gx, sizeof(float) * 2 * S * 4 * H * NpB));
+  CK(hipMalloc(&gx, sizeof(float) * std::max<size_t>(2 * S * 4 * H * NpB, (size_t)2 * 2 * BWD_RS_RING * 256 * 256)));
   CK(hipMalloc(&sync, 64));
   CK(hipMemset(gates, 0, sizeof(float) * 2 * rows * 4 * H));
   CK(hipMemset(whh, 0, sizeof(float) * 2 * 4 * H * H));
@@ -138,15 +138,18 @@ int main(int argc, char** argv) {
   double us_per_tick = 0.01;   // 100 MHz
   if (report("fwd", (int)(H / 4) * 2 * chF, us_per_tick, (int)(H / 4))) return 1;
   CK(hipMemset(gates, 0, sizeof(float) * 2 * rows * 4 * H));
+  const bool rs = getenv("GATHER") == nullptr;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemsetAsync(sync, 0, 32, st));
-    CK(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(2 * S * 4 * H * NpB), st));
+    CK(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL,
+                         rs ? (size_t)2 * chB * BWD_RS_RING * 256 * 256 : (size_t)(2 * S * 4 * H * NpB), st));
     CK(hipEventRecord(e0, st));
-    hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
+    if (rs) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
+    else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
-    printf("bwd persistent: %.3f us / step (status %d)\n", ms * 1e3 / S, status);
+    printf("bwd %s: %.3f us / step (status %d)\n", rs ? "K-split" : "gather", ms * 1e3 / S, status);
   }
   if (report("bwd", (int)(H / 16) * 2 * chB, us_per_tick, (int)(H / 16))) return 1;
   return 0;
