@@ -84,4 +84,5 @@ struct GemmDesc {
 };
 int ssasr_launch_gemm(const GemmDesc& g, hipStream_t st);
 int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);
-int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st);
+int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st,
+                        float* out2 = nullptr);

@@ -10,12 +10,13 @@ int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hip
   return SSASR_OK;
 }
 
-int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st) {
+int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st,
+                        float* out2) {
   int64_t gy64 = (rows + 255) / 256;
   int gy = gy64 > 64 ? 64 : (int)gy64;
   if (gy < 1) gy = 1;
   dim3 grid((cols + 63) / 64, gy), block(256);
-  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, m, rows, cols, ld, out);
+  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, m, rows, cols, ld, out, out2);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
@@ -287,13 +288,9 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
       }
     }
     if (!accumulate) SSASR_HIP(hipMemsetAsync(db[d], 0, sizeof(float) * 4 * H, st));
-    rc = ssasr_launch_colsum(dG, rows, (int)(4 * H), 4 * H, db[d], st);
+    if (!accumulate && db2[d]) SSASR_HIP(hipMemsetAsync(db2[d], 0, sizeof(float) * 4 * H, st));
+    rc = ssasr_launch_colsum(dG, rows, (int)(4 * H), 4 * H, db[d], st, db2[d]);
     if (rc) return rc;
-    if (db2[d]) {
-      if (!accumulate) SSASR_HIP(hipMemsetAsync(db2[d], 0, sizeof(float) * 4 * H, st));
-      rc = ssasr_launch_colsum(dG, rows, (int)(4 * H), 4 * H, db2[d], st);
-      if (rc) return rc;
-    }
   }
   return SSASR_OK;
 }

@@ -1325,8 +1325,8 @@ __global__ void transpose_kernel(const float* src, float* dst, int rows, int col
   }
 }
 
-// out[c] += sum_r m[r][c]   (out pre-zeroed; rows split over blockIdx.y)
-__global__ void colsum_kernel(const float* m, int64_t rows, int cols, int64_t ld, float* out) {
+// out[c] += sum_r m[r][c], and out2[c] likewise when given (rows split over blockIdx.y)
+__global__ void colsum_kernel(const float* m, int64_t rows, int cols, int64_t ld, float* out, float* out2) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int lanes_y = blockDim.x >> 6;
   const int ty = threadIdx.x >> 6;
@@ -1342,6 +1342,7 @@ __global__ void colsum_kernel(const float* m, int64_t rows, int cols, int64_t ld
     float v = 0.f;
     for (int j = 0; j < lanes_y; ++j) v += sm[j][threadIdx.x];
     atomicAdd(out + c, v);
+    if (out2) atomicAdd(out2 + c, v);
   }
 }
 
