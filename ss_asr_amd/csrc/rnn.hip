@@ -191,9 +191,14 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
         const size_t ring = (size_t)2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
         p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
-        if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1>), pgrid, pblock, 0, st, p);
-        else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2>), pgrid, pblock, 0, st, p);
-        else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4>), pgrid, pblock, 0, st, p);
+        // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
+        const bool halves = kpw >= 8 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
+        if (halves) pgrid.z *= 2;
+        if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, 0, st, p);
+        else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, 0, st, p);
+        else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, 0, st, p);
+        else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, 0, st, p);
+        else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, 0, st, p);
       } else if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(2 * S * 4 * H * Np), st));
         if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);

@@ -1086,8 +1086,17 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
   }
 };
 
-template <int TPW>   // unit tiles per wave = (H / 16) / 4: products out, partial tiles in
+// HV = 2: two workgroups per (unit tile, chunk).  Both sum the same partial
+// tiles and run the same gate epilogue (duplicated, deterministic), but each
+// multiplies its gate derivatives into only half of the H units, which halves
+// the product on the critical path.  Only half 0 writes the row-major copy and
+// re-arms the ring, and it does so three steps late: by then every workgroup
+// has consumed data that was published after the other half consumed the slot.
+template <int TPW, int HV>   // TPW = unit tiles per wave = (H / 16) / 4; grid.z = chunks * HV
 __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
+  constexpr int OT = TPW / HV;                  // product tiles per wave
+  constexpr int LAG = HV == 2 ? 3 : 1;          // steps between consuming a slot and re-arming it
+  static_assert(TPW % HV == 0 && LAG + 2 <= BWD_RS_RING, "ring too short");
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
   __shared__ __attribute__((aligned(16))) float4 coef[2][7][64];   // [parity][A, O, I, G, F, C, dy][lane]
   __shared__ __attribute__((aligned(16))) float4 sG[4][64];        // gate derivatives of this step: [gate][lane (q, r)]
@@ -1096,7 +1105,8 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   if (tid == 0) missed = 0;
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
+  const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z / HV, half = blockIdx.z % HV;
+  const int nchunk = gridDim.z / HV;
   const int S = e.S, N = e.N, H = e.H;
   constexpr int T = 4 * TPW;                    // unit tiles = H / 16
   const int n0 = chunk * 16;
@@ -1110,7 +1120,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   // exchange ring of this (direction, chunk) group
   constexpr unsigned TILE_B = 64 * 16;                        // bytes of one partial tile
   constexpr unsigned SLOT_B = (unsigned)T * T * TILE_B;       // one step of one group
-  float* xbase = e.gx + ((int64_t)d * gridDim.z + chunk) * (BWD_RS_RING * (int64_t)(SLOT_B / 4));
+  float* xbase = e.gx + ((int64_t)d * nchunk + chunk) * (BWD_RS_RING * (int64_t)(SLOT_B / 4));
   const __amdgpu_buffer_rsrc_t xrs =
       __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)(BWD_RS_RING * SLOT_B), 0x00020000);
 
@@ -1142,8 +1152,10 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       if (i > 0) {
         pacer.update(missed != 0);
         missed = 0;
-        // re-arm what this workgroup consumed: slot (i - 1) % RING, dest = tile, all sources
-        const unsigned base = (unsigned)((i - 1) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
+      }
+      if (half == 0 && i >= LAG) {
+        // re-arm what was consumed in step i - LAG + 1: slot (i - LAG) % RING, dest = tile, all sources
+        const unsigned base = (unsigned)((i - LAG) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
 #pragma unroll
         for (int j = 0; j < T; ++j)
           __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
@@ -1155,11 +1167,12 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
 
   // ---------------------------- recurrence waves -----------------------------
   // W_hh^T slice: A[m = hidden unit][k = this workgroup's gate rows], wave w owns
-  // unit tiles TPW*w .. ; k-block g = gate g, lane (q, r) holds k = 4q..4q+3 of it
-  float4 wreg[TPW][4];
+  // unit tiles otile0 .. otile0 + OT; k-block g = gate g, lane (q, r) holds k = 4q..4q+3 of it
+  const int otile0 = half * (T / HV) + OT * wave;
+  float4 wreg[OT][4];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int unit = 16 * (TPW * wave + t) + r;
+  for (int t = 0; t < OT; ++t) {
+    const int unit = 16 * (otile0 + t) + r;
     const float* wp = e.whhT + ((int64_t)d * H + unit) * 4 * H + 16 * tile + 4 * q;
 #pragma unroll
     for (int g = 0; g < 4; ++g) wreg[t][g] = *reinterpret_cast<const float4*>(wp + (int64_t)g * H);
@@ -1239,7 +1252,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       sG[1][lane] = df;
       sG[2][lane] = dg;
       sG[3][lane] = dov;
-      if (epi) {          // row-major copy for the dX and weight-gradient GEMMs
+      if (epi && half == 0) {          // row-major copy for the dX and weight-gradient GEMMs
         const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
         st4(gbase + g0, di);
         st4(gbase + g0 + H, df);
@@ -1254,25 +1267,38 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       float4 b[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) b[g] = sG[g][lane];
-      f32x4 acc[TPW];
+      // two accumulators per tile: with OT = 1 a single chain would wait on its own result
+      f32x4 acc[OT], acc2[OT];
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < OT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < 4; g += 2) {
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].x, b[g].x, acc[t], 0, 0, 0);
+        for (int t = 0; t < OT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].x, b[g].x, acc[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g + 1].x, b[g + 1].x, acc2[t], 0, 0, 0);
+        }
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].y, b[g].y, acc[t], 0, 0, 0);
+        for (int t = 0; t < OT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].y, b[g].y, acc[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g + 1].y, b[g + 1].y, acc2[t], 0, 0, 0);
+        }
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].z, b[g].z, acc[t], 0, 0, 0);
+        for (int t = 0; t < OT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].z, b[g].z, acc[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g + 1].z, b[g + 1].z, acc2[t], 0, 0, 0);
+        }
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].w, b[g].w, acc[t], 0, 0, 0);
+        for (int t = 0; t < OT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].w, b[g].w, acc[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g + 1].w, b[g + 1].w, acc2[t], 0, 0, 0);
+        }
       }
       const unsigned base = (unsigned)(i % BWD_RS_RING) * SLOT_B + (unsigned)tile * TILE_B;   // source = this tile
 #pragma unroll
-      for (int t = 0; t < TPW; ++t)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), xrs,
-                                               (int)((TPW * wave + t) * T * TILE_B + lane * 16), (int)base, 16);
+      for (int t = 0; t < OT; ++t)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t] + acc2[t]), xrs,
+                                               (int)((otile0 + t) * T * TILE_B + lane * 16), (int)base, 16);
       SSASR_PTRACE(i, 7);
     }
   }
