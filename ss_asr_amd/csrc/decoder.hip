@@ -4,10 +4,23 @@
 #include "../../include/ssasr.h"
 #include "attn_kernels.h"
 #include "rnn_kernels.h"
+#ifdef SSASR_TRACE_BUILD      // diagnostic library (tools/dectrace.py): per-phase timestamps of the persistent decode loop
+constexpr int DTR_STEPS = 64, DTR_SLOTS = 8, DTR_WG = 192;
+__device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
+#define SSASR_DTRACE(step, slot) do { if (threadIdx.x == 0 && (step) < DTR_STEPS) { \
+  unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  g_dtrace[(blockIdx.x * DTR_STEPS + (step)) * DTR_SLOTS + (slot)] = t_; } } while (0)
+#endif
 #include "decoder_persistent.h"
 #include <cstdlib>
 
 extern "C" int ssasr_abi_version(void) { return 2; }
+#ifdef SSASR_TRACE_BUILD
+extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
+  SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
+  return SSASR_OK;
+}
+#endif
 
 // ------------------------------ attention ---------------------------------
 extern "C" int ssasr_attn_precompute_fwd(const float* feat, const float* w_psi, const float* b_psi,
@@ -178,9 +191,25 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     p.cnt = reinterpret_cast<unsigned*>(d.ws_sync); p.status = d.ws_sync + 5;
     p.B = (int)B; p.T = (int)T; p.U = (int)U; p.V = (int)V;
     const size_t lds = decoder_persistent_lds((int)T);
-    SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_persistent_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(decoder_fwd_persistent_kernel, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
+    if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
+      // self-verifying hand-offs: every exchanged buffer starts as the fill pattern
+      const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4, img_q = (size_t)(PD_A / 16) * PD_BP * 16;   // floats per step
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, img_h * U, st));
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx2, (int)PERSIST_SENTINEL, img_h * U, st));
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_qx, (int)PERSIST_SENTINEL, img_q * U, st));
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ctx, (int)PERSIST_SENTINEL, (size_t)(U * B * E), st));
+      for (int64_t t = 0; t + 1 < U; ++t)        // embeddings the loop itself produces
+        if (d.step_mode[t] != 0)
+          SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)(d.emb_in + (t + 1) * B * D), (int)PERSIST_SENTINEL,
+                                      (size_t)(B * D), st));
+      SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(decoder_fwd_persistent_kernel<true>, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
+    } else {
+      SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(decoder_fwd_persistent_kernel<false>, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
+    }
     SSASR_LAUNCH_CHECK();
   }
   const int nch = attn_pick_nch((int)E);

@@ -15,13 +15,21 @@
 //     not teacher forced.
 // Stage hand-offs (h1 -> q -> ctx -> h1, h1 -> h2, h2 -> char -> emb) use the
 // protocol of the persistent recurrences (rnn_kernels.h): write-through (sc1)
-// stores that cover whole 128-byte lines per store instruction, drain, one
-// agent-scope add to a monotonic per-stage counter; consumers poll, barrier,
-// and read with sc1 loads.  Every step uses fresh addresses.  All spins are
-// bounded; a timeout sets *status and the launch still terminates.
+// stores that cover whole 128-byte lines per store instruction into buffers the
+// host pre-filled with the NaN pattern PERSIST_SENTINEL; consumers read with sc1
+// loads and re-fetch any 16-byte piece that still holds the pattern (SEN =
+// true).  Measured with the arrival counters this kernel first used (SEN =
+// false: drain, one agent-scope add per producer, consumers poll): 128 adds to
+// one address plus 192 pollers cost 5.5 us per hand-off, 23 us per decode step.
+// Every step uses fresh addresses.  All spins are bounded; a timeout sets
+// *status and the launch still terminates.
 #pragma once
 #include "attn_kernels.h"
 #include "rnn_kernels.h"
+
+#ifndef SSASR_DTRACE          // diagnostic builds (tools/dectrace.py) define this
+#define SSASR_DTRACE(step, slot)
+#endif
 
 namespace {
 
@@ -62,6 +70,40 @@ struct PdWaiter {
   }
 };
 
+// Fetches b[lo..hi) through ld(j) (an sc1 load returning the raw bits) and, when
+// SEN, re-fetches pieces that still hold the fill pattern.
+template <bool SEN, int NV, typename F>
+__device__ __forceinline__ void pd_fetch(float4 (&b)[NV], F ld, int lo, int hi, int* status) {
+  u32x4 raw[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) raw[j] = (j >= lo && j < hi) ? ld(j) : u32x4{0u, 0u, 0u, 0u};
+  if (SEN) {
+    for (unsigned tries = 0;; ++tries) {
+      bool anybad = false;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const bool bad = raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
+                         raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
+        if (__any(bad)) {
+          anybad = true;
+          raw[j] = ld(j);
+        }
+      }
+      if (!anybad) break;
+      if (tries > PERSIST_MAX_SPINS) { if ((threadIdx.x & 63) == 0) *status = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const f32x4 f = __builtin_bit_cast(f32x4, raw[j]);
+    b[j] = make_float4(f[0], f[1], f[2], f[3]);
+  }
+}
+__device__ __forceinline__ u32x4 pd_ld_raw(const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+}
+
 __device__ __forceinline__ float4 pd_ld_sc1(const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
   const f32x4 f = __builtin_bit_cast(f32x4, v);
@@ -92,6 +134,7 @@ __device__ __forceinline__ void pd_mma(f32x4& acc, f32x4& acc2, const float4 (&w
 //       then 128 compute workgroups (tile = c >> 1, 16-column chunk = c & 1): 192 in all.
 // The kernel needs ~256 VGPRs, i.e. one workgroup per CU: 192 leaves 64 CUs of slack.
 // dynamic LDS: T * 256 floats (feat slice) + 2176 floats scratch
+template <bool SEN>
 __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -124,6 +167,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
     const __amdgpu_buffer_rsrc_t rc = pd_rsrc(p.ctx, (size_t)U * B * PD_E * sizeof(float));
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = 0; t < U; ++t) {
+      SSASR_DTRACE(t, 0);
       float4 c[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -132,8 +176,12 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
       }
       float4 q4 = z4;
       if (t > 0) {
-        wt.wait_ge(p.cnt + PC_Q, n_phi * (unsigned)t);
-        q4 = pd_ld_sc1(rq, (unsigned)(t * img_q + (((l32 >> 2) * PD_BP + b) * 16 + (l32 & 3) * 4) * 4));
+        if (!SEN) wt.wait_ge(p.cnt + PC_Q, n_phi * (unsigned)t);
+        const unsigned qoff = (unsigned)(t * img_q + (((l32 >> 2) * PD_BP + b) * 16 + (l32 & 3) * 4) * 4);
+        float4 qv[1];
+        pd_fetch<SEN, 1>(qv, [=](int) { return pd_ld_raw(rq, qoff); }, 0, 1, p.status);
+        q4 = qv[0];
+        SSASR_DTRACE(t, 1);
       }
       if (chunk == 0 && hw == 0) *reinterpret_cast<float4*>(p.q + ((int64_t)t * B + b) * PD_A + 4 * l32) = q4;
       float e[16];
@@ -157,6 +205,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
         ssum += pv;
       }
       if (l32 == 0) { sM[hw] = m; sM[8 + hw] = ssum; }
+      SSASR_DTRACE(t, 2);
       __syncthreads();
       float gm = sM[0];
 #pragma unroll
@@ -195,6 +244,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
       }
       *reinterpret_cast<float4*>(sRed + hw * 256 + 4 * l32) = acc;
       *reinterpret_cast<float4*>(sRed + hw * 256 + 128 + 4 * l32) = accb;
+      SSASR_DTRACE(t, 3);
       __syncthreads();
       if (wave == 0) {
         {     // 64 lanes x 16 bytes = the 1 KB half row of ctx: whole 128-byte lines
@@ -206,8 +256,11 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
           }
           pd_st_sc1(rc, (unsigned)((((int64_t)t * B + b) * PD_E + chunk * 256 + 4 * lane) * 4), v);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CTX, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!SEN) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CTX, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        SSASR_DTRACE(t, 4);
       }
       __syncthreads();     // sM / sRed are rewritten next step
     }
@@ -295,22 +348,28 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
       if (lane < 16)
         pd_st_sc1(rimg, (unsigned)(t * img_h + ((tile * PD_BP + 16 * chunk + lane) * 16)),
                   *reinterpret_cast<const float4*>(sH + lane * 4));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(p.cnt + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!SEN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(p.cnt + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     __syncthreads();
   };
 
   for (int t = 0; t <= U; ++t) {
     // (A) h1_{t-1} from every compute workgroup
-    if (t > 0) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
+    SSASR_DTRACE(t, 0);
+    if (!SEN && t > 0) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
+    SSASR_DTRACE(t, 1);
 
     // (B) phi_t: q_t = tanh(W_phi h1_{t-1})          (16 workgroups)
     if (is_phi && t > 0 && t < U) {
       float4 bq[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        bq[j] = pd_ld_sc1(rh1, (unsigned)((t - 1) * img_h + (wave + 4 * j) * 4 * PD_BP * 16 + xoi));
+      {
+        const unsigned o1 = (unsigned)((t - 1) * img_h + wave * 4 * PD_BP * 16 + xoi);
+        pd_fetch<SEN, 4>(bq, [=](int j) { return pd_ld_raw(rh1, o1 + (unsigned)(4 * j) * 4 * PD_BP * 16); }, 0, 4,
+                         p.status);
+      }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
       pd_mma<4>(acc, acc2, wp, bq, 0, 4);
       red[wave * 64 + lane] = acc + acc2;
@@ -322,23 +381,27 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
         // D fragment: rows 4q..4q+3 of this A tile, column = utterance 16*chunk + r
         const float4 qv = make_float4(tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3]));
         pd_st_sc1(rq, (unsigned)(t * img_q + ((atile * PD_BP + 16 * chunk + r) * 16 + 4 * q) * 4), qv);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_Q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!SEN) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_Q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       __syncthreads();
     }
 
+    SSASR_DTRACE(t, 2);
     // (C) cell 2 of step t-1 (overlaps the attention workgroups' step t)
     if (t > 0) {
       const int s = t - 1;
-      if (s > 0) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)s);
+      if (!SEN && s > 0) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)s);
       float4 b2[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int kb = wave + 4 * j;                           // 0..15: h1_s, 16..31: h2_{s-1}
-        if (j < 4) b2[j] = pd_ld_sc1(rh1, (unsigned)(s * img_h + kb * 4 * PD_BP * 16 + xoi));
-        else b2[j] = s > 0 ? pd_ld_sc1(rh2, (unsigned)((s - 1) * img_h + (kb - 16) * 4 * PD_BP * 16 + xoi))
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      {
+        const unsigned o1 = (unsigned)(s * img_h + wave * 4 * PD_BP * 16 + xoi);
+        const unsigned o2 = (unsigned)((s > 0 ? s - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
+        pd_fetch<SEN, 8>(b2, [=](int j) {      // kb = wave + 4 j: 0..15 h1_s, 16..31 h2_{s-1}
+          return j < 4 ? pd_ld_raw(rh1, o1 + (unsigned)(4 * j) * 4 * PD_BP * 16)
+                       : pd_ld_raw(rh2, o2 + (unsigned)(4 * (j - 4)) * 4 * PD_BP * 16);
+        }, 0, s > 0 ? 8 : 4, p.status);
       }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
       pd_mma<8>(acc, acc2, w2, b2, 0, s > 0 ? 8 : 4);
@@ -349,13 +412,15 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
       if (mode != 0) {
         ++nsamp;
         if (is_chr && s + 1 <= U) {
-          wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)(s + 1));
+          if (!SEN) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)(s + 1));
           const int b = c;
           float* sV = sH;                                       // [256] h2_s of utterance b
           float* sL = sH + 256;                                 // [V] logits
           if (tid < 64) {
-            const float4 hv = pd_ld_sc1(rh2, (unsigned)(s * img_h + ((tid * PD_BP + b) * 16)));
-            *reinterpret_cast<float4*>(sV + 4 * tid) = hv;
+            const unsigned ho = (unsigned)(s * img_h + ((tid * PD_BP + b) * 16));
+            float4 hv[1];
+            pd_fetch<SEN, 1>(hv, [=](int) { return pd_ld_raw(rh2, ho); }, 0, 1, p.status);
+            *reinterpret_cast<float4*>(sV + 4 * tid) = hv[0];
           }
           __syncthreads();
           for (int v = wave; v < p.V; v += 4) {
@@ -388,8 +453,10 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
             best = __shfl(best, 0, 64);
             pd_st_sc1(re, (unsigned)((((int64_t)(s + 1) * B + b) * D + 4 * lane) * 4),
                       aload4(p.embed + (int64_t)best * D + 4 * lane));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CHAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!SEN) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CHAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
           __syncthreads();
         }
@@ -398,23 +465,31 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
     if (t == U) break;
 
     // (E) ctx_t from the attention workgroups, emb_t from the character role
-    wt.wait_ge(p.cnt + PC_CTX, n_att * (unsigned)(t + 1));
-    if (t > 0 && p.modes[t - 1] != 0) wt.wait_ge(p.cnt + PC_CHAR, n_chr * nsamp);
+    SSASR_DTRACE(t, 3);
+    if (!SEN) {
+      wt.wait_ge(p.cnt + PC_CTX, n_att * (unsigned)(t + 1));
+      if (t > 0 && p.modes[t - 1] != 0) wt.wait_ge(p.cnt + PC_CHAR, n_chr * nsamp);
+    }
+    SSASR_DTRACE(t, 4);
 
     // (F) cell 1 of step t: [emb_t | ctx_t | h1_{t-1}]
     {
       float4 b1[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int kb = wave + 4 * j;                           // 0..15 emb, 16..47 ctx, 48..63 h1
-        if (j < 4) b1[j] = pd_ld_sc1(re, (unsigned)((((int64_t)t * B + nc) * D + 16 * kb + 4 * q) * 4));
-        else if (j < 12) b1[j] = pd_ld_sc1(rc, (unsigned)((((int64_t)t * B + nc) * E + 16 * (kb - 16) + 4 * q) * 4));
-        else b1[j] = t > 0 ? pd_ld_sc1(rh1, (unsigned)((t - 1) * img_h + (kb - 48) * 4 * PD_BP * 16 + xoi))
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      {
+        const unsigned oe = (unsigned)((((int64_t)t * B + nc) * D + 16 * wave + 4 * q) * 4);
+        const unsigned oc = (unsigned)((((int64_t)t * B + nc) * E + 16 * wave + 4 * q) * 4);
+        const unsigned oh = (unsigned)((t > 0 ? t - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
+        pd_fetch<SEN, 16>(b1, [=](int j) {     // kb = wave + 4 j: 0..15 emb, 16..47 ctx, 48..63 h1
+          return j < 4 ? pd_ld_raw(re, oe + (unsigned)(64 * j) * 4)
+               : j < 12 ? pd_ld_raw(rc, oc + (unsigned)(64 * (j - 4)) * 4)
+                        : pd_ld_raw(rh1, oh + (unsigned)(4 * (j - 12)) * 4 * PD_BP * 16);
+        }, 0, t > 0 ? 16 : 12, p.status);
       }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
       pd_mma<16>(acc, acc2, w1, b1, 0, t > 0 ? 16 : 12);
+      SSASR_DTRACE(t, 5);
       cell_finish(acc, acc2, bias1, cst1, t, p.gates1, p.c1, p.h1, rh1, PC_H1);
+      SSASR_DTRACE(t, 6);
     }
   }
 }
