@@ -188,6 +188,10 @@ typedef struct ssasr_decoder_grads {
   float* ws_dqpre;          /* [U][B][A]                                         */
   float* ws_dc;             /* [2][2][B][D]                                      */
   float* ws_demb;           /* [U][B][D]                                         */
+  /* optional (both or neither): exchange ring + status words of the persistent
+   * cell-2 BPTT, ssasr_bilstm_bwd_gx_floats(U, B, D) floats and int32[8]        */
+  float* ws_gx;
+  int32_t* ws_sync;
 } ssasr_decoder_grads;
 
 /* Backward of ssasr_decoder_fwd.  gates1 / gates2 of `d` are consumed. */

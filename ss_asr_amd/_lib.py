@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -37,7 +37,7 @@ class DecoderGrads(C.Structure):
     _fields_ = [(n, P) for n in (
         'dlogits', 'dfeat', 'dcomp', 'dw_phi', 'dw_ih1', 'dw_hh1', 'db1', 'dw_ih2', 'dw_hh2',
         'db2', 'dembed', 'dw_ct', 'db_ct', 'ws_t_ih1', 'ws_t_hh1', 'ws_t_ih2', 'ws_t_hh2',
-        'ws_dh2', 'ws_dctx', 'ws_de', 'ws_dqpre', 'ws_dc', 'ws_demb')]
+        'ws_dh2', 'ws_dctx', 'ws_de', 'ws_dqpre', 'ws_dc', 'ws_demb', 'ws_gx', 'ws_sync')]
 
 
 SIGNATURES = {

@@ -84,5 +84,13 @@ struct GemmDesc {
 };
 int ssasr_launch_gemm(const GemmDesc& g, hipStream_t st);
 int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);
+// Persistent BPTT of `dirs` LSTM directions over S steps x N <= 32 columns (rnn.hip):
+// gates [dirs][S*N][4H] activated gates in / gate derivatives out, whhT [dirs][H][4H],
+// dy[s * ys_s + n * ys_n + d * H + u], gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats.
+// Returns SSASR_EARG when the shape has no persistent form.
+int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
+                                 int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
+                                 int64_t N, int64_t H, int dirs, hipStream_t st);
+extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);
 int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st,
                         float* out2 = nullptr);

@@ -14,7 +14,7 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #include "decoder_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 2; }
+extern "C" int ssasr_abi_version(void) { return 3; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
@@ -338,12 +338,31 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   dim3 cgrid = cell_bwd_grid(D, 1, B), cblock(256);
   float* dc1 = g.ws_dc;               // [2][B][D]
   float* dc2 = g.ws_dc + 2 * B * D;   // [2][B][D]
+  // The second cell's BPTT does not depend on the first cell or the attention:
+  // dh2_t = dH2L[t] + dG2[t+1] . W_hh2 is an ordinary LSTM layer over U steps.  With
+  // the ring workspace it runs first, as ONE persistent launch of the encoder's
+  // K-split BPTT kernel (one direction), and its contribution dG2 . W_ih2 to dh1
+  // becomes one GEMM over all steps (into ws_dh2, which is free by then).
+  const bool cell2_first = g.ws_gx && g.ws_sync && ssasr_bilstm_bwd_gx_floats(U, B, D) > 0 &&
+                           !getenv("SSASR_NO_PERSISTENT") && !getenv("SSASR_NO_PERSISTENT_DECODER");
+  if (cell2_first) {
+    if ((rc = ssasr_launch_bptt_persistent(g.ws_t_hh2, d.gates2, d.c2, g.ws_dh2, B * D, D, nullptr, g.ws_gx,
+                                           g.ws_sync, U, B, D, 1, st)))
+      return rc;
+    GemmDesc m{};
+    m.A = d.gates2; m.ma = rm_dense(4 * D);
+    m.B = d.w_ih2; m.mb = rm_dense(D);
+    m.C = g.ws_dh2; m.mc = rm_dense(D);
+    m.M = (int)rows; m.N = (int)D; m.K = (int)(4 * D); m.ta = 0; m.tb = 1;
+    m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
+    if ((rc = ssasr_launch_gemm(m, st))) return rc;
+  }
   for (int64_t t = U - 1; t >= 0; --t) {
     const int64_t i = U - 1 - t;
     const bool last = (t == U - 1);
     // cell 2: dh2_t = dH2L[t] + dG2[t+1] . W_hh2
     CellBwdPair p2{};
-    {
+    if (!cell2_first) {
       CellBwd& c = p2.d[0];
       int ns = 0;
       if (!last) {
@@ -358,14 +377,15 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
       c.dc_out = dc2 + ((i + 1) & 1) * B * D;
       c.N = (int)B; c.H = (int)D;
     }
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, cgrid, cblock, 0, st, p2);
+    if (!cell2_first) hipLaunchKernelGGL(lstm_cell_bwd_kernel, cgrid, cblock, 0, st, p2);
 
     // cell 1: dh1_t = dG2[t] . W_ih2 + dG1[t+1] . W_hh1 + dqpre[t+1] . W_phi
     CellBwdPair p1{};
     {
       CellBwd& c = p1.d[0];
       int ns = 0;
-      seg_set(c.sl, ns++, d.gates2 + t * B * 4 * D, 4 * D, g.ws_t_ih2, 4 * D, (int)(4 * D));
+      if (cell2_first) { c.add1 = g.ws_dh2 + t * B * D; c.ld1 = (int)D; }     // = dG2[t] . W_ih2
+      else seg_set(c.sl, ns++, d.gates2 + t * B * 4 * D, 4 * D, g.ws_t_ih2, 4 * D, (int)(4 * D));
       if (!last) {
         seg_set(c.sl, ns++, d.gates1 + (t + 1) * B * 4 * D, 4 * D, g.ws_t_hh1, 4 * D, (int)(4 * D));
         seg_set(c.sl, ns++, g.ws_dqpre + (t + 1) * B * A, A, d.w_phi_t, A, (int)A);

@@ -139,6 +139,49 @@ extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
   return gather > ring ? gather : ring;
 }
 
+int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
+                                 int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
+                                 int64_t N, int64_t H, int dirs, hipStream_t st) {
+  const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
+  const int kpw = (int)(H / 16);
+  if (!gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || chunks > 2 || dirs < 1 || dirs > 2 ||
+      S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) || !aligned16(cs) ||
+      !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
+    return SSASR_EARG;
+  SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
+  EncPersistBwd p{};
+  p.whhT = whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens;
+  p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
+  p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 16);
+  p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
+  dim3 pgrid((unsigned)(H / 16), (unsigned)dirs, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
+  if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr) {
+    // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
+    const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
+    p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
+    SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
+    // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
+    const bool halves = kpw >= 8 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
+    if (halves) pgrid.z *= 2;
+    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, 0, st, p);
+    else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, 0, st, p);
+    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, 0, st, p);
+    else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, 0, st, p);
+    else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, 0, st, p);
+  } else if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
+    SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(dirs * S * 4 * H * Np), st));
+    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
+    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, true>), pgrid, pblock, 0, st, p);
+    else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), pgrid, pblock, 0, st, p);
+  } else {
+    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, false>), pgrid, pblock, 0, st, p);
+    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, false>), pgrid, pblock, 0, st, p);
+    else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, false>), pgrid, pblock, 0, st, p);
+  }
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
 // Backward of the layer.  `gates` is consumed: on return it holds the gate
 // pre-activation derivatives.  dw_* / db_* are overwritten.
 extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
@@ -174,43 +217,10 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31)) return SSASR_EARG;
   if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
   bool persistent = false;
-  {
-    const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
-    const int kpw = (int)(H / 16);
-    persistent = gx && sync_ws && (kpw == 4 || kpw == 8 || kpw == 16) && chunks <= 2 &&
-                 S * 4 * H * Np * 4 < (1ll << 31) && aligned16(gx) && !getenv("SSASR_NO_PERSISTENT");
-    if (persistent) {
-      EncPersistBwd p{};
-      p.whhT = ws_whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens;
-      p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
-      p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 16);
-      p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
-      dim3 pgrid((unsigned)(H / 16), 2, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
-      if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr) {
-        // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
-        const size_t ring = (size_t)2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
-        p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
-        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
-        // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
-        const bool halves = kpw >= 8 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
-        if (halves) pgrid.z *= 2;
-        if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, 0, st, p);
-        else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, 0, st, p);
-        else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, 0, st, p);
-        else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, 0, st, p);
-        else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, 0, st, p);
-      } else if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
-        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(2 * S * 4 * H * Np), st));
-        if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
-        else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, true>), pgrid, pblock, 0, st, p);
-        else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), pgrid, pblock, 0, st, p);
-      } else {
-        if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, false>), pgrid, pblock, 0, st, p);
-        else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, false>), pgrid, pblock, 0, st, p);
-        else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, false>), pgrid, pblock, 0, st, p);
-      }
-      SSASR_LAUNCH_CHECK();
-    }
+  if (gx && sync_ws && !getenv("SSASR_NO_PERSISTENT")) {
+    rc = ssasr_launch_bptt_persistent(ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st);
+    if (rc == SSASR_OK) persistent = true;
+    else if (rc != SSASR_EARG) return rc;
   }
   EncBwd e{};
   e.whhT = ws_whhT; e.gates = gates; e.cs = cs; e.dy = dy; e.dc = ws_dc; e.lens = lens;

@@ -396,6 +396,11 @@ class _DecoderLoop(torch.autograd.Function):
                   ws_t_hh2=f(D, 4 * D), ws_dh2=f(U, B, D), ws_dctx=f(U, B, E),
                   ws_de=f(B, U, T), ws_dqpre=f(U, B, A), ws_dc=f(2, 2, B, D),
                   ws_demb=f(U, B, D))
+        gx_floats = int(lib.ssasr_bilstm_bwd_gx_floats(U, B, D))
+        if gx_floats:                     # persistent BPTT of the second cell
+            ws['ws_gx'] = f(gx_floats)
+            ws['ws_sync'] = torch.zeros(8, device=dev, dtype=torch.int32)
+            _persist_status.append((ws['ws_sync'], 4))
         g = _lib.DecoderGrads()
         g.dlogits = dlogits.data_ptr()
         for k, t in list(out.items()) + list(ws.items()):
