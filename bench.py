@@ -125,7 +125,7 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
     h[N,H] x W_hh[H,4H] is the algorithmic work (2 * 2*N*H*4H flop per step),
     but they are latency bound: per step one cross-XCD exchange
     (write-through store -> visible -> load round trip, ~1.3 us on this part)
-    precedes a 16 x 16 x 1024 product per workgroup.  `us_per_step` against
+    precedes a small MFMA product per workgroup (BPTT: K-split, 8 tiles x K=64).  `us_per_step` against
     `exchange_floor_us` is the honest reading."""
     import ctypes as C
     from ss_asr_amd import _lib, ops
@@ -186,8 +186,8 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
     bytes_bwd = S * 2 * (N * H * 4) * (4 + 4 + 3)
     bytes_fwd = S * 2 * (N * H * 4) * (4 + 4 + 3)
     out = []
-    for name, us, nbytes in (('lstm_enc_bwd_persistent_kernel<16, true>', us_bwd, bytes_bwd),
-                             ('lstm_enc_fwd_persistent_kernel<4, true>', us_fwd, bytes_fwd)):
+    for name, us, nbytes in (('lstm_enc_bwd_rs_kernel<4, 2>', us_bwd, bytes_bwd),
+                             ('lstm_enc_fwd_persistent_kernel<4, true, 1>', us_fwd, bytes_fwd)):
         tf = flops / (us * 1e-6) / 1e12
         out.append(dict(kernel=name, bound='mfma', achieved=round(tf, 3), peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
                         frac=round(tf / MFMA_F32_PEAK_TF, 5), traffic=None, flops_per_launch=flops,

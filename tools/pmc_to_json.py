@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-KERNELS = {'bptt': 'lstm_enc_bwd_persistent_kernel', 'fwd': 'lstm_enc_fwd_persistent_kernel',
+KERNELS = {'bptt': 'lstm_enc_bwd_rs_kernel', 'fwd': 'lstm_enc_fwd_persistent_kernel',
            'attention': 'attn_step_fwd'}
 
 
