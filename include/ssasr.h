@@ -192,7 +192,13 @@ typedef struct ssasr_decoder_grads {
    * cell-2 BPTT, ssasr_bilstm_bwd_gx_floats(U, B, D) floats and int32[8]        */
   float* ws_gx;
   int32_t* ws_sync;
+  /* optional (needs ws_gx / ws_sync too): ssasr_decoder_bwd_chain_floats(...) floats
+   * for the persistent first-cell <-> attention backward chain                      */
+  float* ws_chain;
 } ssasr_decoder_grads;
+
+/* Workspace of the persistent decoder backward chain (0: shape has none). */
+int64_t ssasr_decoder_bwd_chain_floats(int64_t U, int64_t B, int64_t T, int64_t A, int64_t E, int64_t D);
 
 /* Backward of ssasr_decoder_fwd.  gates1 / gates2 of `d` are consumed. */
 int ssasr_decoder_bwd(const ssasr_decoder* d, const ssasr_decoder_grads* g, void* stream);

@@ -12,15 +12,23 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
   g_dtrace[(blockIdx.x * DTR_STEPS + (step)) * DTR_SLOTS + (slot)] = t_; } } while (0)
 #endif
 #include "decoder_persistent.h"
+#include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 3; }
+extern "C" int ssasr_abi_version(void) { return 4; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
   return SSASR_OK;
 }
 #endif
+
+extern "C" int64_t ssasr_decoder_bwd_chain_floats(int64_t U, int64_t B, int64_t T, int64_t A, int64_t E, int64_t D) {
+  if (A != PD_A || E != PD_E || D != PD_D || B <= 0 || B > 32 || T <= 0 || T > 128 || U <= 0) return 0;
+  if (chain_xc_floats(U) * sizeof(float) >= (1ull << 31)) return 0;        // 32-bit buffer offsets
+  return (int64_t)(U * B * A + ((U * B + 63) & ~(int64_t)63) + chain_xa_floats(U) + chain_xc_floats(U) +
+                   chain_xu_floats(U, B));
+}
 
 // ------------------------------ attention ---------------------------------
 extern "C" int ssasr_attn_precompute_fwd(const float* feat, const float* w_psi, const float* b_psi,
@@ -357,7 +365,41 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
-  for (int64_t t = U - 1; t >= 0; --t) {
+  // The remaining chain (first cell <-> attention) as one persistent launch
+  // (decoder_bwd_persistent.h) when its workspace is given.
+  const bool chain = cell2_first && g.ws_chain && ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D) > 0 &&
+                     !getenv("SSASR_NO_PERSISTENT_DECODER_BWD");
+  if (chain) {
+    float* wsV = g.ws_chain;
+    float* wsS = wsV + U * B * A;
+    float* xa = wsS + ((U * B + 63) & ~(int64_t)63);
+    float* xc = xa + chain_xa_floats(U);
+    float* xu = xc + chain_xc_floats(U);
+    {   // V[t][b][:] = att[b][t][:] . comp[b]      (all steps, one batched product)
+      GemmDesc m{};
+      m.A = d.att; m.ma = rm_dense(T); m.sa = U * T;
+      m.B = d.comp; m.mb = rm_dense(A); m.sb = T * A;
+      m.C = wsV; m.mc = rm_dense(B * A); m.sc = A;
+      m.M = (int)U; m.N = (int)A; m.K = (int)T; m.ta = 0; m.tb = 1;
+      m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = (int)B;
+      if ((rc = ssasr_launch_gemm(m, st))) return rc;
+    }
+    SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)xa, (int)PERSIST_SENTINEL,
+                                chain_xa_floats(U) + chain_xc_floats(U) + chain_xu_floats(U, B), st));
+    DecBwdChain c{};
+    c.gates1 = d.gates1; c.c1 = d.c1; c.add1 = g.ws_dh2; c.att = d.att; c.q = d.q; c.feat = d.feat;
+    c.comp = d.comp; c.enc_len = d.enc_len; c.V = wsV; c.whh1T = g.ws_t_hh1; c.wih1T = g.ws_t_ih1;
+    c.wphiT = d.w_phi_t; c.dctx = g.ws_dctx; c.de = g.ws_de; c.dqpre = g.ws_dqpre; c.ssum = wsS;
+    c.xa = xa; c.xc = xc; c.xu = xu; c.status = g.ws_sync + 5;
+    c.B = (int)B; c.T = (int)T; c.U = (int)U;
+    const size_t lds = chain_lds_bytes((int)T);
+    SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_chain_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(decoder_bwd_chain_kernel, dim3(CB_NATTWG + 64), dim3(320), lds, st, c);
+    hipLaunchKernelGGL(chain_de_fixup_kernel, dim3(256), dim3(256), 0, st, g.ws_de, d.att, wsS, (int)B, (int)U, (int)T);
+    SSASR_LAUNCH_CHECK();
+  }
+  for (int64_t t = U - 1; t >= 0 && !chain; --t) {
     const int64_t i = U - 1 - t;
     const bool last = (t == U - 1);
     // cell 2: dh2_t = dH2L[t] + dG2[t+1] . W_hh2

@@ -1,0 +1,409 @@
+// Persistent backward of the decode loop's serial chain: first speller cell
+// <-> attention (the second cell's BPTT has no part in it and runs before, see
+// decoder.hip), all U steps in ONE launch, for A = 128, E = 512, D = 256,
+// B <= 32, T <= 128.
+//
+// Per step t (U-1 .. 0) the chain is
+//   dh1_t   = dG2_t W_ih2 (given, all steps)  +  dG1_{t+1} W_hh1  +  dqpre_{t+1} W_phi
+//   dG1_t   = gate derivatives(dh1_t, dc1 carry)                    (src/asr.py:314-326 backwards)
+//   dctx_t  = dG1_t W_ih1[:, D:]
+//   dalpha  = feat . dctx_t ;  de = alpha (dalpha - sum alpha dalpha) ;  dq = de^T comp ;
+//   dqpre_t = dq (1 - q_t^2)                                        (src/asr.py:383-390 backwards)
+// i.e. two dependent stages per step.  Two roles:
+//  * 64 "cell" workgroups (16-unit tile j, 16-utterance chunk c, half h), the
+//    K-split form of rnn_kernels.h: owner (j, c) sums the 16 partial dh1 tiles it
+//    receives, adds the W_phi term, runs the gate epilogue, then multiplies ITS 64
+//    gate-derivative rows into partial tiles of dh1_{t-1} (half h: 8 of 16 unit
+//    tiles) and of dctx_t (half h: 16 of 32 column tiles), weights resident in
+//    registers.  A helper wave pre-folds the saved activations into coefficients.
+//  * 2 "attention" workgroups per utterance, split over the encoder frames: each
+//    keeps its half of feat[b] in LDS for the whole loop, sums the 16 partial dctx
+//    tiles, and publishes U_h = sum_frames alpha dalpha comp  (128 values) and
+//    s_h = sum_frames alpha dalpha.  Because de is linear in the global scalar
+//    s = s_0 + s_1, the consumer forms dq = U_0 + U_1 - s V_t with
+//    V_t = alpha_t^T comp precomputed for all steps by one GEMM: the two halves
+//    never have to meet, and the step has two hand-offs instead of three.
+// Hand-offs are the self-verifying write-through exchanges of rnn_kernels.h
+// (fresh, pattern-filled buffers for every step).  de is stored as alpha dalpha;
+// the "- alpha s" term is applied after the loop by chain_de_fixup_kernel.
+#pragma once
+#include "decoder_persistent.h"
+
+namespace {
+
+constexpr int CB_NATTWG = 64;                 // attention workgroups: utterance b = x >> 1, frame half = x & 1
+constexpr int CB_XU = 160;                    // floats per (step, utterance, half): U[128], s, padding to 5 lines
+
+struct DecBwdChain {
+  float* gates1;          // [U][B][4D] activated gates in, gate derivatives out (row-major)
+  const float* c1;        // [U][B][D]
+  const float* add1;      // [U][B][D]   dG2 . W_ih2
+  const float* att;       // [B][U][T]
+  const float* q;         // [U][B][A]
+  const float* feat;      // [B][T][E]
+  const float* comp;      // [B][T][A]
+  const int32_t* enc_len;
+  const float* V;         // [U][B][A]   alpha_t^T comp
+  const float* whh1T;     // [D][4D]
+  const float* wih1T;     // [D+E][4D]
+  const float* wphiT;     // [D][A]
+  float* dctx;            // [U][B][E]
+  float* de;              // [B][U][T]   alpha * dalpha
+  float* dqpre;           // [U][B][A]
+  float* ssum;            // [U][B]
+  float* xa;              // [U][2][16 dest][16 src][64][4]   partial dh1 tiles
+  float* xc;              // [U][2][16 src][32 col tile][64][4] partial dctx tiles
+  float* xu;              // [U][B][2][CB_XU]
+  int* status;
+  int B, T, U;
+};
+
+__host__ __device__ inline size_t chain_xa_floats(int64_t U) { return (size_t)U * 2 * 16 * 16 * 256; }
+__host__ __device__ inline size_t chain_xc_floats(int64_t U) { return (size_t)U * 2 * 16 * 32 * 256; }
+__host__ __device__ inline size_t chain_xu_floats(int64_t U, int64_t B) { return (size_t)U * B * 2 * CB_XU; }
+inline size_t chain_lds_bytes(int T) {
+  const size_t att = ((size_t)((T + 1) / 2) * PD_E + PD_E + 8 * PD_A + 16) * sizeof(float);
+  const size_t cell = (4 * 64 * 4 + 2 * 7 * 64 * 4 + 4 * 64 * 4 + 8 * 4 * 16 * 4) * sizeof(float);
+  return att > cell ? att : cell;
+}
+
+// de[b][t][tau] -= att[b][t][tau] * s[t][b]   (t >= 1)
+__global__ void chain_de_fixup_kernel(float* de, const float* att, const float* ssum, int B, int U, int T) {
+  const int64_t n = (int64_t)B * U * T;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / ((int64_t)U * T);
+    const int64_t t = (i / T) % U;
+    if (t > 0) de[i] -= att[i] * ssum[t * B + b];
+  }
+}
+
+template <int NV, typename F>
+__device__ __forceinline__ void cb_fetch(u32x4 (&raw)[NV], F ld, int* status) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) raw[j] = ld(j);
+  for (unsigned tries = 0;; ++tries) {
+    bool anybad = false;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const bool bad = raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
+                       raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
+      if (__any(bad)) {
+        anybad = true;
+        raw[j] = ld(j);
+      }
+    }
+    if (!anybad) break;
+    if (tries > PERSIST_MAX_SPINS) { if ((threadIdx.x & 63) == 0) *status = 1; break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// grid: CB_NATTWG attention workgroups, then 16 tiles x 2 chunks x 2 halves = 64 cell workgroups; 320 threads
+// dynamic LDS: chain_lds_bytes(T)
+__global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int B = p.B, T = p.T, U = p.U;
+  constexpr int D = PD_D, E = PD_E, A = PD_A;
+  const __amdgpu_buffer_rsrc_t rxa = pd_rsrc(p.xa, chain_xa_floats(U) * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rxc = pd_rsrc(p.xc, chain_xc_floats(U) * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rxu = pd_rsrc(p.xu, chain_xu_floats(U, B) * sizeof(float));
+  constexpr unsigned TILE_B = 64 * 16;                       // bytes of one 16 x 16 tile in lane order
+  constexpr unsigned XA_STEP = 2u * 16 * 16 * TILE_B, XC_STEP = 2u * 16 * 32 * TILE_B;
+
+  if (blockIdx.x < CB_NATTWG) {
+    // ------------------------------ attention role ------------------------------
+    const int b = blockIdx.x >> 1, th = blockIdx.x & 1;
+    if (b >= B || wave == 4) return;
+    const int Th = (T + 1) / 2;
+    const int tau0 = th * Th;
+    int len = p.enc_len ? p.enc_len[b] : T;
+    len = len < T ? len : T;
+    const int nrow = max(0, min(len, tau0 + Th) - tau0);     // live frames of this half
+    float* sF = smem;                                        // [Th][E] feat rows tau0 ..
+    float* sD = sF + (size_t)Th * E;                         // [E] dctx_t[b]
+    float* sRed = sD + E;                                    // [8][A]
+    float* sS = sRed + 8 * A;                                // [8] partial s, [8..] unused
+    const float* fb = p.feat + ((int64_t)b * T + tau0) * E;
+    for (int i = tid; i < nrow * (E / 4); i += 256)
+      *reinterpret_cast<float4*>(sF + 4 * i) = aload4(fb + 4 * (int64_t)i);
+    __syncthreads();
+    const int c = b >> 4, bl = b & 15;
+    // dctx gather: thread -> (column tile ct, row quad q, source half jh); 8 source tiles each
+    const int ct = tid >> 3, gq = (tid >> 1) & 3, jh = tid & 1;
+    const int hw = tid >> 5, l32 = tid & 31;                 // 8 groups of 32 lanes for the frame loops
+    const float* cb = p.comp + ((int64_t)b * T + tau0) * A + 4 * l32;
+    for (int t = U - 1; t >= 0; --t) {
+      {
+        const unsigned base = (unsigned)t * XC_STEP + (unsigned)c * (16 * 32 * TILE_B) +
+                              (unsigned)ct * TILE_B + (unsigned)(gq * 16 + bl) * 16;
+        u32x4 raw[8];
+        cb_fetch<8>(raw, [=](int j) { return pd_ld_raw(rxc, base + (unsigned)(jh * 8 + j) * (32 * TILE_B)); }, p.status);
+        f32x4 s0 = __builtin_bit_cast(f32x4, raw[0]), s1 = __builtin_bit_cast(f32x4, raw[1]);
+#pragma unroll
+        for (int j = 2; j < 8; j += 2) {
+          s0 += __builtin_bit_cast(f32x4, raw[j]);
+          s1 += __builtin_bit_cast(f32x4, raw[j + 1]);
+        }
+        f32x4 v = s0 + s1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], 1, 64);
+        if (jh == 0) {
+          const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(sD + 16 * ct + 4 * gq) = o;
+          if (th == 0) *reinterpret_cast<float4*>(p.dctx + ((int64_t)t * B + b) * E + 16 * ct + 4 * gq) = o;
+        }
+      }
+      __syncthreads();
+      if (t == 0) break;          // step 0: q = 0, nothing flows through the energies
+      // dalpha, alpha * dalpha, and this group's share of s and U
+      const float* ab = p.att + ((int64_t)b * U + t) * T + tau0;
+      float4 uacc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float sacc = 0.f;
+      for (int tl = hw; tl < nrow; tl += 8) {
+        const float* fr = sF + (size_t)tl * E + 16 * l32;
+        const float* dr = sD + 16 * l32;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 f = *reinterpret_cast<const float4*>(fr + 4 * k);
+          const float4 dd = *reinterpret_cast<const float4*>(dr + 4 * k);
+          acc = fmaf(f.x, dd.x, acc);
+          acc = fmaf(f.y, dd.y, acc);
+          acc = fmaf(f.z, dd.z, acc);
+          acc = fmaf(f.w, dd.w, acc);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);      // within the 32-lane group
+        const float ade = ab[tl] * acc;
+        if (l32 == 0) p.de[((int64_t)b * U + t) * T + tau0 + tl] = ade;
+        sacc += ade;
+        const float4 cv = aload4(cb + (int64_t)tl * A);
+        uacc.x = fmaf(ade, cv.x, uacc.x);
+        uacc.y = fmaf(ade, cv.y, uacc.y);
+        uacc.z = fmaf(ade, cv.z, uacc.z);
+        uacc.w = fmaf(ade, cv.w, uacc.w);
+      }
+      // frames past the utterance get de = 0
+      for (int tl = nrow + tid; tl < Th && tau0 + tl < T; tl += 256) p.de[((int64_t)b * U + t) * T + tau0 + tl] = 0.f;
+      *reinterpret_cast<float4*>(sRed + hw * A + 4 * l32) = uacc;
+      if (l32 == 0) sS[hw] = sacc;
+      __syncthreads();
+      if (wave == 0 && lane < 40) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 32) {
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(sRed + g * A + 4 * lane);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+        } else if (lane == 32) {
+#pragma unroll
+          for (int g = 0; g < 8; ++g) v.x += sS[g];
+        }
+        pd_st_sc1(rxu, (unsigned)(((((int64_t)t * B + b) * 2 + th) * CB_XU + 4 * lane) * 4), v);
+      }
+      __syncthreads();            // sD / sRed / sS are rewritten next step
+    }
+    return;
+  }
+
+  // ---------------------------------- cell role ----------------------------------
+  const int cidx = blockIdx.x - CB_NATTWG;
+  const int tile = cidx >> 2, chunk = (cidx >> 1) & 1, half = cidx & 1;
+  const int r = lane & 15, q = lane >> 4;
+  const int n0 = 16 * chunk;
+  const int n = n0 + r;
+  const bool col_ok = n < B;
+  const int u0 = 16 * tile + 4 * q;                  // lane (q, r) of waves 0 and 4: units u0..u0+3 of utterance n
+  f32x4* red = reinterpret_cast<f32x4*>(smem);                              // [4][64]
+  float4* coef = reinterpret_cast<float4*>(smem + 4 * 64 * 4);              // [2][7][64]
+  float4* sG = coef + 2 * 7 * 64;                                           // [4][64]
+  float4* sQ = sG + 4 * 64;                                                 // [8 k-blocks][4 q][16 n]
+
+  if (wave == 4) {
+    // helper wave: saved activations of the next step -> coefficients (rnn_kernels.h BpttSaved)
+    EncPersistBwd e{};
+    e.dy = p.add1; e.ys_s = B * D; e.ys_n = D; e.S = U; e.N = B; e.H = D;
+    BpttSaved sv;
+    if (col_ok) {
+      sv.fetch(e, p.gates1, p.c1, 0, 0, n, u0);
+      sv.publish(&coef[(0 & 1) * 7 * 64 + lane], true);
+      if (U > 1) sv.fetch(e, p.gates1, p.c1, 0, 1, n, u0);
+    }
+    for (int i = 0; i < U; ++i) {
+      __syncthreads();                               // (1) dqpre in LDS
+      if (col_ok && i + 1 < U) {
+        sv.publish(&coef[((i + 1) & 1) * 7 * 64 + lane], true);
+        if (i + 2 < U) sv.fetch(e, p.gates1, p.c1, 0, i + 2, n, u0);
+      }
+      __syncthreads();                               // (2) partial sums in LDS
+      __syncthreads();                               // (3) gate derivatives in LDS
+    }
+    return;
+  }
+
+  // resident weight slices
+  float4 wa[2][4], wc[4][4], wp[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int unit = 16 * (half * 8 + 2 * wave + t) + r;                   // dh1 destination unit
+    const float* w = p.whh1T + (int64_t)unit * 4 * D + 16 * tile + 4 * q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wa[t][g] = aload4(w + g * D);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = 16 * (half * 16 + 4 * wave + t) + r;                   // ctx column
+    const float* w = p.wih1T + (int64_t)(D + col) * 4 * D + 16 * tile + 4 * q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wc[t][g] = aload4(w + g * D);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)      // W_phi term: A[m = unit][k = a], k-blocks 2 * wave + k
+    wp[k] = aload4(p.wphiT + (int64_t)(16 * tile + r) * A + 16 * (2 * wave + k) + 4 * q);
+
+  const bool epi = wave == 0 && col_ok;
+  float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nb = n < B ? n : B - 1;                  // clamped utterance for the attention results
+  const int ablk = q + 4 * wave;                     // this thread's 8 attention columns: 8 * ablk ..
+
+  for (int i = 0; i < U; ++i) {
+    const int t = U - 1 - i;
+    f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i > 0) {
+      // results of step t + 1: partial dh1 tiles and the attention's U_h, s_h
+      u32x4 raw[10];
+      const unsigned xab = (unsigned)(t + 1) * XA_STEP + (unsigned)chunk * (16 * 16 * TILE_B) +
+                           (unsigned)tile * (16 * TILE_B) + (unsigned)lane * 16;
+      const unsigned xub = (unsigned)(((((int64_t)(t + 1) * B + nb) * 2) * CB_XU + 8 * ablk) * 4);
+      cb_fetch<10>(raw, [=](int j) {
+        return j < 4 ? pd_ld_raw(rxa, xab + (unsigned)(wave + 4 * j) * TILE_B)
+             : j < 6 ? pd_ld_raw(rxu, xub + (unsigned)(j - 4) * 16)                         // U_0
+             : j < 8 ? pd_ld_raw(rxu, xub + (unsigned)(CB_XU * 4) + (unsigned)(j - 6) * 16)  // U_1
+             : pd_ld_raw(rxu, (unsigned)(((((int64_t)(t + 1) * B + nb) * 2 + (j - 8)) * CB_XU + 128) * 4));   // s_h
+      }, p.status);
+      part = (__builtin_bit_cast(f32x4, raw[0]) + __builtin_bit_cast(f32x4, raw[1])) +
+             (__builtin_bit_cast(f32x4, raw[2]) + __builtin_bit_cast(f32x4, raw[3]));
+      const float s = __builtin_bit_cast(f32x4, raw[8])[0] + __builtin_bit_cast(f32x4, raw[9])[0];
+      const float* vq = p.V + ((int64_t)(t + 1) * B + nb) * A + 8 * ablk;
+      const float* qq = p.q + ((int64_t)(t + 1) * B + nb) * A + 8 * ablk;
+      float4 dq[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const f32x4 ua = __builtin_bit_cast(f32x4, raw[4 + k]), ub = __builtin_bit_cast(f32x4, raw[6 + k]);
+        const float4 vv = aload4(vq + 4 * k), qv = aload4(qq + 4 * k);
+        dq[k].x = col_ok ? (ua[0] + ub[0] - s * vv.x) * (1.f - qv.x * qv.x) : 0.f;
+        dq[k].y = col_ok ? (ua[1] + ub[1] - s * vv.y) * (1.f - qv.y * qv.y) : 0.f;
+        dq[k].z = col_ok ? (ua[2] + ub[2] - s * vv.z) * (1.f - qv.z * qv.z) : 0.f;
+        dq[k].w = col_ok ? (ua[3] + ub[3] - s * vv.w) * (1.f - qv.w * qv.w) : 0.f;
+        // MFMA B layout: k-block = a / 16, row quad = (a % 16) / 4
+        const int a0 = 8 * ablk + 4 * k;
+        sQ[((a0 >> 4) * 4 + ((a0 & 15) >> 2)) * 16 + r] = dq[k];
+      }
+      if (tile == 0 && half == 0 && col_ok) {          // row-major copies for the batched products
+        float* o = p.dqpre + ((int64_t)(t + 1) * B + n) * A + 8 * ablk;
+        st4(o, dq[0]);
+        st4(o + 4, dq[1]);
+        if (ablk == 0) p.ssum[(int64_t)(t + 1) * B + n] = s;
+      }
+    }
+    __syncthreads();        // (1) dqpre in LDS
+    if (i > 0) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float4 b0 = sQ[((2 * wave) * 4 + q) * 16 + r], b1 = sQ[((2 * wave + 1) * 4 + q) * 16 + r];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[0].x, b0.x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[1].x, b1.x, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[0].y, b0.y, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[1].y, b1.y, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[0].z, b0.z, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[1].z, b1.z, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[0].w, b0.w, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[1].w, b1.w, acc2, 0, 0, 0);
+      part += acc + acc2;
+    }
+    red[wave * 64 + lane] = part;
+    __syncthreads();        // (2) partial sums in LDS
+    if (wave == 0) {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 di = z4, df = z4, dg = z4, dov = z4;
+      if (epi) {
+        const float4* c = &coef[(i & 1) * 7 * 64 + lane];
+        const float4 cA = c[0 * 64], cO = c[1 * 64], cI = c[2 * 64], cG = c[3 * 64], cF = c[4 * 64],
+                     cC = c[5 * 64], ad1 = c[6 * 64];
+        f32x4 dhv = red[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) dhv += red[w * 64 + lane];
+        const float kA[4] = {cA.x, cA.y, cA.z, cA.w}, kO[4] = {cO.x, cO.y, cO.z, cO.w};
+        const float kI[4] = {cI.x, cI.y, cI.z, cI.w}, kG[4] = {cG.x, cG.y, cG.z, cG.w};
+        const float kF[4] = {cF.x, cF.y, cF.z, cF.w}, kC[4] = {cC.x, cC.y, cC.z, cC.w};
+        const float dc_[4] = {dcv.x, dcv.y, dcv.z, dcv.w}, a1_[4] = {ad1.x, ad1.y, ad1.z, ad1.w};
+        float rdi[4], rdf[4], rdg[4], rdo[4], rdc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dh = dhv[k] + a1_[k];
+          const float dc = dc_[k] + dh * kA[k];
+          rdo[k] = dh * kO[k];
+          rdi[k] = dc * kI[k];
+          rdg[k] = dc * kG[k];
+          rdf[k] = dc * kF[k];
+          rdc[k] = dc * kC[k];
+        }
+        di = make_float4(rdi[0], rdi[1], rdi[2], rdi[3]);
+        df = make_float4(rdf[0], rdf[1], rdf[2], rdf[3]);
+        dg = make_float4(rdg[0], rdg[1], rdg[2], rdg[3]);
+        dov = make_float4(rdo[0], rdo[1], rdo[2], rdo[3]);
+        dcv = make_float4(rdc[0], rdc[1], rdc[2], rdc[3]);
+      }
+      sG[0 * 64 + lane] = di;
+      sG[1 * 64 + lane] = df;
+      sG[2 * 64 + lane] = dg;
+      sG[3 * 64 + lane] = dov;
+      if (epi && half == 0) {
+        float* g0 = p.gates1 + ((int64_t)t * B + n) * 4 * D + u0;
+        st4(g0, di);
+        st4(g0 + D, df);
+        st4(g0 + 2 * D, dg);
+        st4(g0 + 3 * D, dov);
+      }
+    }
+    __syncthreads();        // (3) gate derivatives in LDS
+    {
+      float4 bg[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bg[g] = sG[g * 64 + lane];
+      f32x4 aa[2], ac[4];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) aa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ac[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define CB_STEP(C)                                                                                   \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                  \
+        ac[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[k][g].C, bg[g].C, ac[k], 0, 0, 0);           \
+      if (t > 0) {                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                \
+          aa[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k][g].C, bg[g].C, aa[k], 0, 0, 0);         \
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { CB_STEP(x) CB_STEP(y) CB_STEP(z) CB_STEP(w) }
+#undef CB_STEP
+      // dctx partial tiles first: the attention stage is next on the critical path
+      const unsigned xcb = (unsigned)t * XC_STEP + (unsigned)chunk * (16 * 32 * TILE_B) +
+                           (unsigned)tile * (32 * TILE_B) + (unsigned)lane * 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ac[k]), rxc,
+                                               (int)(xcb + (unsigned)(half * 16 + 4 * wave + k) * TILE_B), 0, 16);
+      if (t > 0) {
+        const unsigned xab = (unsigned)t * XA_STEP + (unsigned)chunk * (16 * 16 * TILE_B) + (unsigned)tile * TILE_B +
+                             (unsigned)lane * 16;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, aa[k]), rxa,
+                                                 (int)(xab + (unsigned)(half * 8 + 2 * wave + k) * (16 * TILE_B)), 0, 16);
+      }
+    }
+  }
+}
+
+}  // namespace

@@ -401,6 +401,10 @@ class _DecoderLoop(torch.autograd.Function):
             ws['ws_gx'] = f(gx_floats)
             ws['ws_sync'] = torch.zeros(8, device=dev, dtype=torch.int32)
             _persist_status.append((ws['ws_sync'], 4))
+            _persist_status.append((ws['ws_sync'], 5))
+            chain_floats = int(lib.ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D))
+            if chain_floats:              # persistent first-cell <-> attention chain
+                ws['ws_chain'] = f(chain_floats)
         g = _lib.DecoderGrads()
         g.dlogits = dlogits.data_ptr()
         for k, t in list(out.items()) + list(ws.items()):
