@@ -195,6 +195,11 @@ typedef struct ssasr_decoder_grads {
   /* optional (needs ws_gx / ws_sync too): ssasr_decoder_bwd_chain_floats(...) floats
    * for the persistent first-cell <-> attention backward chain                      */
   float* ws_chain;
+  /* optional second copies of the bias gradients (b_ih and b_hh share theirs)        */
+  float* db1_2; float* db2_2;
+  /* != 0: ssasr_decoder_bwd leaves every parameter gradient (dw_*, db*, dembed) to
+   * ssasr_decoder_wgrad, which may run later and on another stream                  */
+  int32_t defer_wgrad;
 } ssasr_decoder_grads;
 
 /* Workspace of the persistent decoder backward chain (0: shape has none). */
@@ -202,6 +207,11 @@ int64_t ssasr_decoder_bwd_chain_floats(int64_t U, int64_t B, int64_t T, int64_t 
 
 /* Backward of ssasr_decoder_fwd.  gates1 / gates2 of `d` are consumed. */
 int ssasr_decoder_bwd(const ssasr_decoder* d, const ssasr_decoder_grads* g, void* stream);
+
+/* Parameter gradients of the decode loop from what ssasr_decoder_bwd(defer_wgrad = 1)
+ * left in d / g (gate derivatives, dqpre, dlogits): 11 products over all steps, off the
+ * critical path of the backward pass.  accumulate = 0 overwrites the outputs, 1 adds. */
+int ssasr_decoder_wgrad(const ssasr_decoder* d, const ssasr_decoder_grads* g, int accumulate, void* stream);
 
 /* Masked cross entropy of src/trainer.py:426-434.  logits [B][U][V]; labels
  * int32 [B][U] (0 = ignore); denom [B] = count(y != 0) per row as float.

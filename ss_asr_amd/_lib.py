@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -37,7 +37,8 @@ class DecoderGrads(C.Structure):
     _fields_ = [(n, P) for n in (
         'dlogits', 'dfeat', 'dcomp', 'dw_phi', 'dw_ih1', 'dw_hh1', 'db1', 'dw_ih2', 'dw_hh2',
         'db2', 'dembed', 'dw_ct', 'db_ct', 'ws_t_ih1', 'ws_t_hh1', 'ws_t_ih2', 'ws_t_hh2',
-        'ws_dh2', 'ws_dctx', 'ws_de', 'ws_dqpre', 'ws_dc', 'ws_demb', 'ws_gx', 'ws_sync', 'ws_chain')]
+        'ws_dh2', 'ws_dctx', 'ws_de', 'ws_dqpre', 'ws_dc', 'ws_demb', 'ws_gx', 'ws_sync', 'ws_chain',
+        'db1_2', 'db2_2')] + [('defer_wgrad', C.c_int32)]
 
 
 SIGNATURES = {
@@ -57,6 +58,7 @@ SIGNATURES = {
     'ssasr_attn_step_bwd': (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P, P, P]),
     'ssasr_decoder_fwd': (I32, [C.POINTER(Decoder), P]),
     'ssasr_decoder_bwd': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), P]),
+    'ssasr_decoder_wgrad': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), I32, P]),
     'ssasr_ce_loss_fwd': (I32, [P, P, P, I64, I64, I64, P, P, P]),
     'ssasr_ce_loss_bwd': (I32, [P, P, P, P, P, I64, I64, I64, P, P]),
     'ssasr_clip_adadelta_ws': (I64, [I64]),

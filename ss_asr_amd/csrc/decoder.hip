@@ -15,7 +15,7 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 4; }
+extern "C" int ssasr_abi_version(void) { return 5; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
@@ -332,10 +332,6 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
-  SSASR_HIP(hipMemsetAsync(g.dw_ct, 0, sizeof(float) * V * D, st));
-  if ((rc = gemm_tn_acc(g.dlogits, logit_rows, d.h2, rm_dense(D), g.dw_ct, D, V, D, rows, st))) return rc;
-  SSASR_HIP(hipMemsetAsync(g.db_ct, 0, sizeof(float) * V, st));
-  if ((rc = ssasr_launch_colsum(g.dlogits, B * U, (int)V, V, g.db_ct, st))) return rc;
 
   // K-contiguous copies of the recurrent weights for the per-step products.
   if ((rc = ssasr_launch_transpose(d.w_ih1, g.ws_t_ih1, (int)(4 * D), (int)(D + E), st))) return rc;
@@ -487,24 +483,49 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = (int)B;
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
+  if (g.defer_wgrad) return SSASR_OK;
+  return ssasr_decoder_wgrad(dp, gp, 0, stream);
+}
+
+extern "C" int ssasr_decoder_wgrad(const ssasr_decoder* dp, const ssasr_decoder_grads* gp, int accumulate,
+                                   void* stream) {
+  if (!dp || !gp) return SSASR_EARG;
+  const ssasr_decoder& d = *dp;
+  const ssasr_decoder_grads& g = *gp;
+  const int64_t B = d.B, E = d.E, A = d.A, D = d.D, V = d.V, U = d.U;
+  if (!g.dlogits || !g.dw_phi || !g.dw_ih1 || !g.dw_hh1 || !g.db1 || !g.dw_ih2 || !g.dw_hh2 || !g.db2 ||
+      !g.dembed || !g.dw_ct || !g.db_ct || !g.ws_dqpre || !g.ws_demb)
+    return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  const int64_t rows = U * B;
+  const RowMap logit_rows{0, B, V, U * V};        // row t*B+b of a [B][U][V] tensor
+#define SSASR_ZERO(ptr, n) do { if (!accumulate) SSASR_HIP(hipMemsetAsync((ptr), 0, sizeof(float) * (n), st)); } while (0)
+  // char_trans: dW_ct = dlogits^T . h2 ; db_ct = colsum
+  SSASR_ZERO(g.dw_ct, V * D);
+  if ((rc = gemm_tn_acc(g.dlogits, logit_rows, d.h2, rm_dense(D), g.dw_ct, D, V, D, rows, st))) return rc;
+  SSASR_ZERO(g.db_ct, V);
+  if ((rc = ssasr_launch_colsum(g.dlogits, B * U, (int)V, V, g.db_ct, st))) return rc;
   // dW_phi = sum_{t>=1} dqpre[t]^T . h1[t-1]
-  SSASR_HIP(hipMemsetAsync(g.dw_phi, 0, sizeof(float) * A * D, st));
+  SSASR_ZERO(g.dw_phi, A * D);
   if ((rc = gemm_tn_acc(g.ws_dqpre + B * A, rm_dense(A), d.h1, rm_dense(D), g.dw_phi, D, A, D, (U - 1) * B, st))) return rc;
   // cell 1: dW_ih1 = dG1^T . [emb_in | ctx], dW_hh1 = dG1[1:]^T . h1[:-1], db1
-  SSASR_HIP(hipMemsetAsync(g.dw_ih1, 0, sizeof(float) * 4 * D * (D + E), st));
+  SSASR_ZERO(g.dw_ih1, 4 * D * (D + E));
   if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.emb_in, rm_dense(D), g.dw_ih1, D + E, 4 * D, D, rows, st))) return rc;
   if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.ctx, rm_dense(E), g.dw_ih1 + D, D + E, 4 * D, E, rows, st))) return rc;
-  SSASR_HIP(hipMemsetAsync(g.dw_hh1, 0, sizeof(float) * 4 * D * D, st));
+  SSASR_ZERO(g.dw_hh1, 4 * D * D);
   if ((rc = gemm_tn_acc(d.gates1 + B * 4 * D, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_hh1, D, 4 * D, D, (U - 1) * B, st))) return rc;
-  SSASR_HIP(hipMemsetAsync(g.db1, 0, sizeof(float) * 4 * D, st));
-  if ((rc = ssasr_launch_colsum(d.gates1, rows, (int)(4 * D), 4 * D, g.db1, st))) return rc;
+  SSASR_ZERO(g.db1, 4 * D);
+  if (g.db1_2) SSASR_ZERO(g.db1_2, 4 * D);
+  if ((rc = ssasr_launch_colsum(d.gates1, rows, (int)(4 * D), 4 * D, g.db1, st, g.db1_2))) return rc;
   // cell 2
-  SSASR_HIP(hipMemsetAsync(g.dw_ih2, 0, sizeof(float) * 4 * D * D, st));
+  SSASR_ZERO(g.dw_ih2, 4 * D * D);
   if ((rc = gemm_tn_acc(d.gates2, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_ih2, D, 4 * D, D, rows, st))) return rc;
-  SSASR_HIP(hipMemsetAsync(g.dw_hh2, 0, sizeof(float) * 4 * D * D, st));
+  SSASR_ZERO(g.dw_hh2, 4 * D * D);
   if ((rc = gemm_tn_acc(d.gates2 + B * 4 * D, rm_dense(4 * D), d.h2, rm_dense(D), g.dw_hh2, D, 4 * D, D, (U - 1) * B, st))) return rc;
-  SSASR_HIP(hipMemsetAsync(g.db2, 0, sizeof(float) * 4 * D, st));
-  if ((rc = ssasr_launch_colsum(d.gates2, rows, (int)(4 * D), 4 * D, g.db2, st))) return rc;
+  SSASR_ZERO(g.db2, 4 * D);
+  if (g.db2_2) SSASR_ZERO(g.db2_2, 4 * D);
+  if ((rc = ssasr_launch_colsum(d.gates2, rows, (int)(4 * D), 4 * D, g.db2, st, g.db2_2))) return rc;
   // embedding: demb = dG1 . W_ih1[:, :D], scattered onto the rows that were fed
   {
     GemmDesc m{};
@@ -515,9 +536,10 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
-  SSASR_HIP(hipMemsetAsync(g.dembed, 0, sizeof(float) * V * D, st));
+  SSASR_ZERO(g.dembed, V * D);
   hipLaunchKernelGGL(embed_scatter_add_kernel, dim3((unsigned)rows), dim3(64), 0, st, g.ws_demb, d.chars,
                      g.dembed, rows, (int)D);
+#undef SSASR_ZERO
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }

@@ -336,8 +336,9 @@ _DEC_PARAMS = ('w_phi', 'w_ih1', 'w_hh1', 'b_ih1', 'b_hh1', 'w_ih2', 'w_hh2', 'b
 
 class _DecoderLoop(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, comp, enc_len, teacher, step_mode, uniforms, *params):
+    def forward(ctx, feat, comp, enc_len, teacher, step_mode, uniforms, sinks, *params):
         lib = _lib.load()
+        ctx.sinks = sinks
         _need_gpu(feat, comp, enc_len, *params)
         feat, comp = _f32c(feat), _f32c(comp)
         params = [_f32c(t) for t in params]
@@ -389,9 +390,18 @@ class _DecoderLoop(torch.autograd.Function):
         B, T, E, A, D, V, U = d.B, d.T, d.E, d.A, d.D, d.V, d.U
         dlogits = _f32c(dlogits)
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        out = dict(dfeat=f(B, T, E), dcomp=f(B, T, A), dw_phi=f(A, D), dw_ih1=f(4 * D, D + E),
-                   dw_hh1=f(4 * D, D), db1=f(4 * D), dw_ih2=f(4 * D, D), dw_hh2=f(4 * D, D),
-                   db2=f(4 * D), dembed=f(V, D), dw_ct=f(V, D), db_ct=f(V))
+        # Parameter gradients: with optimizer-owned flat gradients they are deferred to
+        # the side stream and accumulated in place (as for the BiLSTM layers).
+        sinks = ctx.sinks
+        if sinks is None:
+            out = dict(dfeat=f(B, T, E), dcomp=f(B, T, A), dw_phi=f(A, D), dw_ih1=f(4 * D, D + E),
+                       dw_hh1=f(4 * D, D), db1=f(4 * D), dw_ih2=f(4 * D, D), dw_hh2=f(4 * D, D),
+                       db2=f(4 * D), dembed=f(V, D), dw_ct=f(V, D), db_ct=f(V))
+        else:
+            sk = dict(zip(_DEC_PARAMS, sinks))
+            out = dict(dfeat=f(B, T, E), dcomp=f(B, T, A), dw_phi=sk['w_phi'], dw_ih1=sk['w_ih1'],
+                       dw_hh1=sk['w_hh1'], db1=sk['b_ih1'], dw_ih2=sk['w_ih2'], dw_hh2=sk['w_hh2'],
+                       db2=sk['b_ih2'], dembed=sk['embed'], dw_ct=sk['w_ct'], db_ct=sk['b_ct'])
         ws = dict(ws_t_ih1=f(D + E, 4 * D), ws_t_hh1=f(D, 4 * D), ws_t_ih2=f(D, 4 * D),
                   ws_t_hh2=f(D, 4 * D), ws_dh2=f(U, B, D), ws_dctx=f(U, B, E),
                   ws_de=f(B, U, T), ws_dqpre=f(U, B, A), ws_dc=f(2, 2, B, D),
@@ -409,9 +419,22 @@ class _DecoderLoop(torch.autograd.Function):
         g.dlogits = dlogits.data_ptr()
         for k, t in list(out.items()) + list(ws.items()):
             setattr(g, k, t.data_ptr())
+        if sinks is not None:
+            g.db1_2, g.db2_2 = sk['b_hh1'].data_ptr(), sk['b_hh2'].data_ptr()
+            g.defer_wgrad = 1
         check(lib.ssasr_decoder_bwd(C.byref(d), C.byref(g), _stream()), 'ssasr_decoder_bwd')
+        if sinks is not None:
+            main = torch.cuda.current_stream()
+            side = side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                check(lib.ssasr_decoder_wgrad(C.byref(d), C.byref(g), 1, C.c_void_p(side.cuda_stream)),
+                      'ssasr_decoder_wgrad')
+            for t in list(bufs.values()) + list(ws.values()) + [dlogits]:
+                t.record_stream(side)
+            return (out['dfeat'], out['dcomp']) + (None,) * 17
         o = out
-        return (o['dfeat'], o['dcomp'], None, None, None, None,
+        return (o['dfeat'], o['dcomp'], None, None, None, None, None,
                 o['dw_phi'], o['dw_ih1'], o['dw_hh1'], o['db1'], o['db1'].clone(),
                 o['dw_ih2'], o['dw_hh2'], o['db2'], o['db2'].clone(),
                 o['dembed'], o['dw_ct'], o['db_ct'])
@@ -424,8 +447,8 @@ def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params):
     teacher: int32 [B, L] device tensor of character ids or None.
     params: dict with the keys of ``_DEC_PARAMS``.
     Returns (logits [B,U,V], att [B,U,T] (no grad), chars [U+1,B] int32)."""
-    return _DecoderLoop.apply(feat, comp, enc_len, teacher, list(step_mode), uniforms,
-                              *[params[k] for k in _DEC_PARAMS])
+    plist = [params[k] for k in _DEC_PARAMS]
+    return _DecoderLoop.apply(feat, comp, enc_len, teacher, list(step_mode), uniforms, _grad_sinks(plist), *plist)
 
 
 # ---------------------------------------------------------------------------
