@@ -32,6 +32,9 @@
 #pragma once
 #include "common.h"
 
+#ifndef SSASR_PERSIST_PRIO   // wave priority of the latency-bound persistent kernels (0..3)
+#define SSASR_PERSIST_PRIO 3
+#endif
 #ifndef SSASR_PTRACE         // diagnostic builds (tools/persistbench.hip) define these
 #define SSASR_PTRACE(step, slot)
 #define SSASR_PTRACE_H(step, slot)
@@ -1094,6 +1097,7 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
 // has consumed data that was published after the other half consumed the slot.
 template <int TPW, int HV>   // TPW = unit tiles per wave = (H / 16) / 4; grid.z = chunks * HV
 __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
+  if (SSASR_PERSIST_PRIO) __builtin_amdgcn_s_setprio(SSASR_PERSIST_PRIO);
   constexpr int OT = TPW / HV;                  // product tiles per wave
   constexpr int LAG = HV == 2 ? 3 : 1;          // steps between consuming a slot and re-arming it
   static_assert(TPW % HV == 0 && LAG + 2 <= BWD_RS_RING, "ring too short");
