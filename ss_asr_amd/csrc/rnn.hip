@@ -77,7 +77,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     if (const char* v = getenv("SSASR_FWD_NB")) nb = atoi(v) == 1 ? 1 : 2;
     const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
     const bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
-                      (H / 4) * 2 * chunks <= 256 && S * Np * H * 4 < (1ll << 31) &&
+                      (H / 4) * 2 * chunks <= 512 && S * Np * H * 4 < (1ll << 31) &&   // <= 2 workgroups per CU
                       aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
                       ys_n % 4 == 0 && !getenv("SSASR_NO_PERSISTENT");
     if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
@@ -132,7 +132,7 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
 // Exchange workspace of the persistent BPTT: the larger of the gather form's
 // per-step image and the K-split form's ring (0: no persistent form for this shape).
 extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
-  if (S <= 0 || N <= 0 || N > 32 || (H != 64 && H != 128 && H != 256)) return 0;
+  if (S <= 0 || N <= 0 || N > 128 || (H != 64 && H != 128 && H != 256)) return 0;
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int64_t gather = 2 * S * 4 * H * Np;
   const int64_t ring = 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;
@@ -144,7 +144,10 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
                                  int64_t N, int64_t H, int dirs, hipStream_t st) {
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int kpw = (int)(H / 16);
-  if (!gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || chunks > 2 || dirs < 1 || dirs > 2 ||
+  const bool ksplit = getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr;
+  // every workgroup must be resident: at most one (K-split) per CU; the gather form is kept to two chunks
+  if (!gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
+      (ksplit ? (H / 16) * dirs * chunks > 256 : chunks > 2) ||
       S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) || !aligned16(cs) ||
       !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
     return SSASR_EARG;
@@ -155,13 +158,13 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
   p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 16);
   p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
   dim3 pgrid((unsigned)(H / 16), (unsigned)dirs, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
-  if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr) {
+  if (ksplit) {
     // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
     const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
     p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
     SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
-    const bool halves = kpw >= 8 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
+    const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
     if (halves) pgrid.z *= 2;
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, 0, st, p);
     else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, 0, st, p);

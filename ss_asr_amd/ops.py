@@ -134,7 +134,7 @@ class _BiLSTM(torch.autograd.Function):
         hs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         # workspaces of the persistent recurrence (exchange image + counters)
         hx = torch.empty(2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4, device=x.device,
-                         dtype=torch.float32) if N <= 64 and H % 64 == 0 else None
+                         dtype=torch.float32) if N <= 128 and H % 64 == 0 else None
         sync = torch.empty(8, device=x.device, dtype=torch.int32) if hx is not None else None
         check(lib.ssasr_bilstm_fwd(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
                                    _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
