@@ -237,6 +237,14 @@ int ssasr_clip_adadelta(float* param, const float* grad, float* square_avg, floa
 int ssasr_frame_lengths(const float* x, int64_t B, int64_t T, int64_t F, int32_t* lens,
                         void* stream);
 
+/* Batch assembly from a device-resident corpus: what ASRDataset.__getitem__ + the
+ * DataLoader + prepare_x produce for one batch (src/ASRDataset.py:206-226, :297-315),
+ * without host round trips.  frames [sum of lengths][F] holds the unpadded frames of every
+ * utterance back to back; out[b][t][:] = frames[offsets[b] + t][:] for t < lens[b], zero
+ * rows after (out is [B][T][F], T >= max lens). */
+int ssasr_gather_batch(const float* frames, const int64_t* offsets, const int32_t* lens, int64_t B,
+                       int64_t T, int64_t F, float* out, void* stream);
+
 /* Log-mel filterbank of one waveform: log_fbank, src/preprocess.py:187-208
  * (librosa 0.6.3 melspectrogram defaults: centred reflect-padded STFT with a
  * periodic Hann window of n_fft samples, power 2, Slaney mel filters, then

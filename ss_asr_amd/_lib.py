@@ -66,6 +66,7 @@ SIGNATURES = {
     'ssasr_bilstm_bwd_gx_floats': (I64, [I64, I64, I64]),
     'ssasr_decoder_bwd_chain_floats': (I64, [I64] * 6),
     'ssasr_frame_lengths': (I32, [P, I64, I64, I64, P, P]),
+    'ssasr_gather_batch': (I32, [P, P, P, I64, I64, I64, P, P]),
     'ssasr_logmel_frames': (I64, [I64, I64]),
     'ssasr_logmel': (I32, [P, I64, I64, I64, I64, P, P, P, P, P, P, P, P]),
 }

@@ -147,7 +147,31 @@ __global__ __launch_bounds__(256) void frame_len_kernel(const float* x, int T, i
   if (threadIdx.x == 0) lens[b] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// out[b][t][:] = frames[offsets[b] + t][:] for t < lens[b], zero rows after.  grid (T, B), 64 threads.
+__global__ __launch_bounds__(64) void gather_batch_kernel(const float* frames, const int64_t* offsets,
+                                                          const int32_t* lens, int T, int F, float* out) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  float* dst = out + ((int64_t)b * T + t) * F;
+  const bool live = t < lens[b];
+  const float* src = frames + (offsets[b] + t) * F;
+  if ((F & 3) == 0 && ((reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    for (int f = threadIdx.x; f < (F >> 2); f += 64)
+      reinterpret_cast<float4*>(dst)[f] = live ? reinterpret_cast<const float4*>(src)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int f = threadIdx.x; f < F; f += 64) dst[f] = live ? src[f] : 0.f;
+  }
+}
+
 }  // namespace
+
+extern "C" int ssasr_gather_batch(const float* frames, const int64_t* offsets, const int32_t* lens, int64_t B,
+                                  int64_t T, int64_t F, float* out, void* stream) {
+  if (!frames || !offsets || !lens || !out || B <= 0 || T <= 0 || F <= 0 || B > 65535) return SSASR_EARG;
+  hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)T, (unsigned)B), dim3(64), 0, (hipStream_t)stream, frames,
+                     offsets, lens, (int)T, (int)F, out);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
 
 extern "C" int ssasr_ce_loss_fwd(const float* logits, const int32_t* labels, const float* denom,
                                  int64_t B, int64_t U, int64_t V, float* lse, float* loss,

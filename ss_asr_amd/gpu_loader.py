@@ -1,0 +1,94 @@
+"""Device-resident, bucketed batch loader for the ASR corpus.
+
+Replaces, for training on the GPU, the chain ASRDataset.__getitem__ ->
+DataLoader -> prepare_x / prepare_y (src/ASRDataset.py:206-226, :264-340): the
+whole corpus is read once (index.tsv + one .npy per utterance), its unpadded
+frames are kept back to back in ONE device tensor (a 10 h corpus is ~1.2 GB of
+the 288 GB), and a batch is assembled on the GPU by ``ssasr_gather_batch``.
+Frame and label lengths are known on the host from load time, so a training
+step has no host<->device round trip for its inputs (the reference recovers
+lengths with a row sum over the batch tensor every step, :311-315).
+
+Batches are the reference's: consecutive groups of ``batch_size`` rows of the
+index, whole batches only (:63); the index is expected to be sorted so that
+every batch is in decreasing frame-length order (conf/README.md:16).
+``bucket=True`` instead sorts the whole corpus by length first.
+
+Yields ``(x [B, T, F] float32, x_lens list, y [B, L] int64, y_lens list)`` with
+T = max(x_lens) rounded up to a multiple of 8 (the pyramid's time reduction),
+the values ``prepare_x`` / ``prepare_y`` return for the same batch.
+"""
+import numpy as np
+import torch
+
+from .ASRDataset import load_index
+from .preprocess import ALL_CHARS, SOS_TKN, TOKENS
+
+
+def plan_batches(n_rows, batch_size):
+    """Start row of every whole batch (src/ASRDataset.py:63)."""
+    return list(range(0, n_rows - batch_size + 1, batch_size))
+
+
+class GpuResidentLoader:
+    def __init__(self, tsv_file, batch_size, device, chars=TOKENS + ALL_CHARS, rank=0, world=1,
+                 bucket=False, time_multiple=8):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('GpuResidentLoader keeps the corpus on the GPU (no CPU path)')
+        rows = load_index(tsv_file)
+        if bucket:
+            rows.sort(key=lambda r: r['unpadded_num_frames'], reverse=True)
+        self.rows = rows
+        self.batch_size = batch_size
+        self.rank, self.world = rank, world
+        self.time_multiple = time_multiple
+        self.char2idx = {c: i for i, c in enumerate(chars)}
+        self.starts = plan_batches(len(rows), batch_size)
+
+        kept, lens = [], []
+        for r in rows[:self.starts[-1] + batch_size if self.starts else 0]:
+            a = np.load(r['path_to_fbank']).astype(np.float32, copy=False)
+            n = int((a.sum(-1) != 0).sum())              # prepare_x's definition of a frame
+            kept.append(a[:n])
+            lens.append(n)
+        self.feature_dim = kept[0].shape[1] if kept else 0
+        self.x_lens = lens
+        offs = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        # one upload each; batches are views of these
+        self.frames = torch.from_numpy(np.concatenate(kept, axis=0)).to(self.device) if kept else None
+        self.offsets = torch.from_numpy(offs[:-1].copy()).to(self.device)
+        self.lens_dev = torch.tensor(lens, dtype=torch.int32, device=self.device)
+        # labels: padded with <sos> like ASRDataset.get_batched_texts
+        self.y, self.y_lens = [], []
+        pad = self.char2idx[SOS_TKN]
+        for s in self.starts:
+            enc = [[self.char2idx[c] for c in r['normalized_text']] for r in rows[s:s + batch_size]]
+            L = max(len(e) for e in enc)
+            y = np.full((batch_size, L), pad, dtype=np.int64)
+            for i, e in enumerate(enc):
+                y[i, :len(e)] = e
+            self.y.append(torch.from_numpy(y).to(self.device))
+            self.y_lens.append([int(v) + 1 for v in (y != 0).sum(-1)])      # prepare_y
+
+    def __len__(self):
+        return len(self.starts)
+
+    def bytes_resident(self):
+        return 0 if self.frames is None else self.frames.numel() * 4
+
+    def batch(self, b):
+        from . import ops
+        s = self.starts[b]
+        lens = self.x_lens[s:s + self.batch_size]
+        m = self.time_multiple
+        T = (max(max(lens), 1) + m - 1) // m * m
+        x = ops.gather_batch(self.frames, self.offsets[s:s + self.batch_size],
+                             self.lens_dev[s:s + self.batch_size], T)
+        return x, list(lens), self.y[b], list(self.y_lens[b])
+
+    def __iter__(self):
+        for b in range(len(self.starts)):
+            if b % self.world == self.rank:
+                yield (b,) + self.batch(b)

@@ -503,6 +503,18 @@ def frame_lengths(x):
     return lens
 
 
+def gather_batch(frames, offsets, lens, T):
+    """[B, T, F] zero-padded batch from a device-resident corpus (see include/ssasr.h).
+    frames [rows, F] float32, offsets int64 [B], lens int32 [B], all on the GPU."""
+    lib = _lib.load()
+    _need_gpu(frames, offsets, lens)
+    B, F = offsets.shape[0], frames.shape[1]
+    out = torch.empty(B, T, F, device=frames.device, dtype=torch.float32)
+    check(lib.ssasr_gather_batch(_p(frames), _p(offsets), _p(lens), B, T, F, _p(out), _stream()),
+          'ssasr_gather_batch')
+    return out
+
+
 def clip_adadelta_(param, grad, square_avg, acc_delta, ws, stats, grad_scale=1.0, max_norm=5.0,
                    lr=1.0, rho=0.9, eps=1e-8):
     """Solver.step on flat buffers (src/trainer.py:131-148).  stats <- [norm, skipped]."""

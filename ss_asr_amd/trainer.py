@@ -153,6 +153,30 @@ class ASRTrainer(Solver):
             self.config['asr']['valid_index'], batch_size=self.valid_batch_size,
             n_jobs=n_jobs, use_gpu=self.paras.gpu)
         self.wer_step = self.config['asr']['wer_step']
+        # Training batches come from a device-resident copy of the corpus when it fits
+        # comfortably; ``asr.gpu_resident_loader: false`` keeps the DataLoader.
+        self.gpu_loader = None
+        if self.device.type == 'cuda' and self.config['asr'].get('gpu_resident_loader', True):
+            from .gpu_loader import GpuResidentLoader
+            free, _ = torch.cuda.mem_get_info(self.device)
+            est = 4 * 80 * sum(r['unpadded_num_frames'] for r in self.train_set.dataset._rows)
+            if est < free // 4:
+                self.gpu_loader = GpuResidentLoader(self.config['asr']['train_index'], self.train_batch_size,
+                                                    self.device, rank=self.rank, world=self.world)
+                self.verbose('Training corpus resident on the GPU: {:.1f} MB'.format(
+                    self.gpu_loader.bytes_resident() / 1e6))
+
+    def _train_batches(self):
+        """(batch index, x, x_lens, y, y_lens) for this rank's batches of one epoch."""
+        if self.gpu_loader is not None:
+            yield from self.gpu_loader
+            return
+        for b_ind, (x, y) in enumerate(self.train_set):
+            if b_ind % self.world != self.rank:
+                continue
+            (x, x_lens) = prepare_x(x, device=self.device)
+            (y, y_lens) = prepare_y(y, device=self.device)
+            yield b_ind, x, x_lens, y, y_lens
 
     def set_model(self):
         self.asr_model = self.setup_module(ASR, self.ckppath, self.mapper.get_dim(),
@@ -177,13 +201,9 @@ class ASRTrainer(Solver):
         epoch = 0
         while epoch < self.n_epochs:
             self.verbose("Starting epoch {} out of {}".format(epoch + 1, self.n_epochs))
-            for b_ind, (x, y) in enumerate(self.train_set):
-                if b_ind % self.world != self.rank:
-                    continue
+            for b_ind, x, x_lens, y, y_lens in self._train_batches():
                 self.verbose('Batch: {}/{}, global step: {}'.format(
                     b_ind, len(self.train_set), self.tr.step), progress=True)
-                (x, x_lens) = prepare_x(x, device=self.device)
-                (y, y_lens) = prepare_y(y, device=self.device)
                 state_len = x_lens
                 ans_len = max(y_lens) - 1
 

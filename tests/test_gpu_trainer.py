@@ -75,3 +75,28 @@ def test_asr_trainer_config1_end_to_end(tmp_path):
     saved = torch.load(os.path.join(ckpdir, 'asr.cpt'), map_location='cpu')
     for k, v in tr2.asr_model.state_dict().items():
         assert torch.equal(v.cpu(), saved[k]), k
+
+
+def test_gpu_resident_loader_yields_what_prepare_x_and_prepare_y_yield(tmp_path):
+    """batches assembled on the GPU from the resident corpus equal
+    the reference's loader + prepare_x / prepare_y on the same index."""
+    from test_host_cpu import make_corpus
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_x, prepare_y
+    from ss_asr_amd.gpu_loader import GpuResidentLoader
+    index, lens = make_corpus(str(tmp_path), n=18, t_max=37)
+    _, ds, loader = load_asr_dataset(index, batch_size=8, n_jobs=0)
+    dev = torch.device('cuda:0')
+    gl = GpuResidentLoader(index, 8, dev)
+    assert len(gl) == len(ds) == 2 and gl.feature_dim == 80
+    got = list(gl)
+    for (b, x, x_lens, y, y_lens), (xr, yr) in zip(got, loader):
+        xr, xr_lens = prepare_x(xr, device=dev)
+        yr, yr_lens = prepare_y(yr, device=dev)
+        assert x_lens == xr_lens and y_lens == yr_lens
+        assert x.shape[1] % 8 == 0 and x.shape[1] >= max(x_lens)
+        T = min(x.shape[1], xr.shape[1])
+        assert torch.equal(x[:, :T], xr[:, :T])                 # bit-exact copy of the frames
+        assert float(x[:, T:].abs().sum()) == 0.0 and float(xr[:, T:].abs().sum()) == 0.0
+        assert torch.equal(y, yr)
+    # sharding: rank r of 2 sees batches r, r + 2, ...
+    assert [t[0] for t in GpuResidentLoader(index, 8, dev, rank=1, world=2)] == [1]

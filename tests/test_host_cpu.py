@@ -200,3 +200,12 @@ def test_flat_shims_serve_the_reference_entry_point():
             "assert asr.ASR and ASRDataset.load_asr_dataset and preprocess.TOKENS == '<>$'" % flat)
     import subprocess
     subprocess.run([sys.executable, '-c', code], check=True, cwd=ROOT)
+
+
+def test_gpu_loader_plans_the_reference_batches_and_refuses_the_cpu(tmp_path):
+    from ss_asr_amd.gpu_loader import GpuResidentLoader, plan_batches
+    assert plan_batches(18, 8) == [0, 8]            # whole batches only (src/ASRDataset.py:63)
+    assert plan_batches(7, 8) == []
+    index, _ = make_corpus(str(tmp_path), n=9)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        GpuResidentLoader(index, 4, 'cpu')
