@@ -16,6 +16,16 @@ import torch.nn as nn
 
 from . import ops
 
+
+def _dev_i32(values, device):
+    """Host list of lengths -> int32 device tensor.  Staged through pinned memory and
+    copied asynchronously: a copy from pageable memory (torch.tensor(..., device=cuda))
+    waits for the stream to drain, which stalled the host 3.5 ms twice per train step."""
+    t = torch.tensor([int(v) for v in values], dtype=torch.int32)
+    if torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
 EOS_INDEX = 1   # '>' in TOKENS + ALL_CHARS (src/preprocess.py:17-27)
 
 
@@ -57,7 +67,7 @@ class pBLSTM(nn.Module):
             _check_lengths(state_len, input_x.shape[1])
             steps = state_len[0]
             if len_dev is None:
-                len_dev = torch.tensor(state_len, dtype=torch.int32, device=input_x.device)
+                len_dev = _dev_i32(state_len, input_x.device)
         else:
             steps, len_dev = input_x.shape[1], None
         output = ops.bilstm(input_x, len_dev, steps, True, _lstm_weights(self.layer))
@@ -95,7 +105,7 @@ class Listener(nn.Module):
     def forward(self, x, state_len, pack_input=True):
         len_dev = None
         if pack_input:
-            len_dev = torch.tensor([int(s) for s in state_len], dtype=torch.int32, device=x.device)
+            len_dev = _dev_i32(state_len, x.device)
         for layer in (self.blstm_1, self.blstm_2, self.blstm_3):
             x, _, state_len = layer(x, state_len=state_len, pack_input=pack_input, len_dev=len_dev)
             if len_dev is not None:
@@ -158,8 +168,7 @@ class Attention(nn.Module):
 
     def forward(self, decoder_state, listener_feature, state_len):
         if self.comp_listener_feature is None:
-            self.state_mask = torch.tensor([int(s) for s in state_len], dtype=torch.int32,
-                                           device=listener_feature.device)
+            self.state_mask = _dev_i32(state_len, listener_feature.device)
             self.comp_listener_feature = ops.attn_precompute(
                 listener_feature, self.psi.weight, self.psi.bias)
         return ops.attn_step(decoder_state, self.phi.weight, self.comp_listener_feature,
@@ -216,7 +225,7 @@ class ASR(nn.Module):
         attention [B,U,T'] on the host, detached) -- src/asr.py:52-110."""
         encode_feature, encode_len = self.encoder(audio_feature, state_len)
         dev = encode_feature.device
-        enc_len_dev = torch.tensor([int(s) for s in encode_len], dtype=torch.int32, device=dev)
+        enc_len_dev = _dev_i32(encode_len, dev)
         self.decoder.init_rnn(encode_feature.shape[0], dev)
         self.attention.reset_enc_mem()
         comp = ops.attn_precompute(encode_feature, self.attention.psi.weight,
