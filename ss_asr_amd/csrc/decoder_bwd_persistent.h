@@ -77,10 +77,26 @@ __global__ void chain_de_fixup_kernel(float* de, const float* att, const float* 
   }
 }
 
+// Per-wave pacing of a hand-off (cf. PersistPacer in rnn_kernels.h): polling delays the
+// stores it waits for, so a wave sleeps `delay` x 64 cycles before its first fetch and
+// adapts the delay to the producer stage: +12 when pieces were missing, -2 after 2 clean steps
+// (a decode loop has only ~50 steps to converge in).
+struct WavePacer {
+  int delay, clean;
+  __device__ __forceinline__ void sleep() const {
+    for (int k = 0; k < delay; ++k) __builtin_amdgcn_s_sleep(1);
+  }
+  __device__ __forceinline__ void update(bool missed) {
+    if (missed) { delay = min(delay + 12, 400); clean = 0; }
+    else if (++clean >= 2) { delay = max(delay - 2, 0); clean = 0; }
+  }
+};
+
 template <int NV, typename F>
-__device__ __forceinline__ void cb_fetch(u32x4 (&raw)[NV], F ld, int* status) {
+__device__ __forceinline__ bool cb_fetch(u32x4 (&raw)[NV], F ld, int* status) {
 #pragma unroll
   for (int j = 0; j < NV; ++j) raw[j] = ld(j);
+  bool missed = false;
   for (unsigned tries = 0;; ++tries) {
     bool anybad = false;
 #pragma unroll
@@ -93,9 +109,11 @@ __device__ __forceinline__ void cb_fetch(u32x4 (&raw)[NV], F ld, int* status) {
       }
     }
     if (!anybad) break;
+    missed = true;
     if (tries > PERSIST_MAX_SPINS) { if ((threadIdx.x & 63) == 0) *status = 1; break; }
     __builtin_amdgcn_s_sleep(2);
   }
+  return missed;
 }
 
 // grid: CB_NATTWG attention workgroups, then 16 tiles x 2 chunks x 2 halves = 64 cell workgroups; 320 threads
@@ -133,12 +151,32 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
     const int ct = tid >> 3, gq = (tid >> 1) & 3, jh = tid & 1;
     const int hw = tid >> 5, l32 = tid & 31;                 // 8 groups of 32 lanes for the frame loops
     const float* cb = p.comp + ((int64_t)b * T + tau0) * A + 4 * l32;
+    constexpr int RPG = 8;                                   // frame rows per 32-lane group: ceil(64 / 8)
+    // this group's rows of comp do not change over the steps: registers for the whole loop
+    float4 cvr[RPG];
+#pragma unroll
+    for (int k = 0; k < RPG; ++k) {
+      const int tl = hw + 8 * k;
+      cvr[k] = tl < nrow ? aload4(cb + (int64_t)tl * A) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    WavePacer pacer{120, 0};
     for (int t = U - 1; t >= 0; --t) {
+      SSASR_DTRACE(U - 1 - t, 0);
+      // alpha of this step's rows: independent of the hand-off, fetched while waiting for it
+      const float* ab = p.att + ((int64_t)b * U + t) * T + tau0;
+      float alr[RPG];
+#pragma unroll
+      for (int k = 0; k < RPG; ++k) {
+        const int tl = hw + 8 * k;
+        alr[k] = (t > 0 && tl < nrow) ? ab[tl] : 0.f;
+      }
       {
         const unsigned base = (unsigned)t * XC_STEP + (unsigned)c * (16 * 32 * TILE_B) +
                               (unsigned)ct * TILE_B + (unsigned)(gq * 16 + bl) * 16;
         u32x4 raw[8];
-        cb_fetch<8>(raw, [=](int j) { return pd_ld_raw(rxc, base + (unsigned)(jh * 8 + j) * (32 * TILE_B)); }, p.status);
+        if (t < U - 1) pacer.sleep();
+        pacer.update(cb_fetch<8>(raw, [=](int j) { return pd_ld_raw(rxc, base + (unsigned)(jh * 8 + j) * (32 * TILE_B)); },
+                                 p.status));
         f32x4 s0 = __builtin_bit_cast(f32x4, raw[0]), s1 = __builtin_bit_cast(f32x4, raw[1]);
 #pragma unroll
         for (int j = 2; j < 8; j += 2) {
@@ -154,40 +192,57 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
           if (th == 0) *reinterpret_cast<float4*>(p.dctx + ((int64_t)t * B + b) * E + 16 * ct + 4 * gq) = o;
         }
       }
+      SSASR_DTRACE(U - 1 - t, 1);
       __syncthreads();
       if (t == 0) break;          // step 0: q = 0, nothing flows through the energies
       // dalpha, alpha * dalpha, and this group's share of s and U
-      const float* ab = p.att + ((int64_t)b * U + t) * T + tau0;
       float4 uacc = make_float4(0.f, 0.f, 0.f, 0.f);
       float sacc = 0.f;
-      for (int tl = hw; tl < nrow; tl += 8) {
-        const float* fr = sF + (size_t)tl * E + 16 * l32;
-        const float* dr = sD + 16 * l32;
+      float4 dd[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dd[k] = *reinterpret_cast<const float4*>(sD + 128 * k + 4 * l32);   // lane-contiguous: no bank conflicts
+      float dal[RPG];
+#pragma unroll
+      for (int kr = 0; kr < RPG; ++kr) {
+        const int tl = hw + 8 * kr;
         float acc = 0.f;
+        if (tl < nrow) {
+          const float* fr = sF + (size_t)tl * E + 4 * l32;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 f = *reinterpret_cast<const float4*>(fr + 4 * k);
-          const float4 dd = *reinterpret_cast<const float4*>(dr + 4 * k);
-          acc = fmaf(f.x, dd.x, acc);
-          acc = fmaf(f.y, dd.y, acc);
-          acc = fmaf(f.z, dd.z, acc);
-          acc = fmaf(f.w, dd.w, acc);
+          for (int k = 0; k < 4; ++k) {
+            const float4 f = *reinterpret_cast<const float4*>(fr + 128 * k);
+            acc = fmaf(f.x, dd[k].x, acc);
+            acc = fmaf(f.y, dd[k].y, acc);
+            acc = fmaf(f.z, dd[k].z, acc);
+            acc = fmaf(f.w, dd[k].w, acc);
+          }
         }
+        dal[kr] = acc;
+      }
+      // the 8 rows' cross-lane sums are independent chains: stage by stage, not row by row
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);      // within the 32-lane group
-        const float ade = ab[tl] * acc;
-        if (l32 == 0) p.de[((int64_t)b * U + t) * T + tau0 + tl] = ade;
-        sacc += ade;
-        const float4 cv = aload4(cb + (int64_t)tl * A);
-        uacc.x = fmaf(ade, cv.x, uacc.x);
-        uacc.y = fmaf(ade, cv.y, uacc.y);
-        uacc.z = fmaf(ade, cv.z, uacc.z);
-        uacc.w = fmaf(ade, cv.w, uacc.w);
+      for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+        for (int kr = 0; kr < RPG; ++kr) dal[kr] += __shfl_xor(dal[kr], o, 64);      // within the 32-lane group
+      }
+#pragma unroll
+      for (int kr = 0; kr < RPG; ++kr) {
+        const int tl = hw + 8 * kr;
+        if (tl < nrow) {
+          const float ade = alr[kr] * dal[kr];
+          if (l32 == 0) p.de[((int64_t)b * U + t) * T + tau0 + tl] = ade;
+          sacc += ade;
+          uacc.x = fmaf(ade, cvr[kr].x, uacc.x);
+          uacc.y = fmaf(ade, cvr[kr].y, uacc.y);
+          uacc.z = fmaf(ade, cvr[kr].z, uacc.z);
+          uacc.w = fmaf(ade, cvr[kr].w, uacc.w);
+        }
       }
       // frames past the utterance get de = 0
       for (int tl = nrow + tid; tl < Th && tau0 + tl < T; tl += 256) p.de[((int64_t)b * U + t) * T + tau0 + tl] = 0.f;
       *reinterpret_cast<float4*>(sRed + hw * A + 4 * l32) = uacc;
       if (l32 == 0) sS[hw] = sacc;
+      SSASR_DTRACE(U - 1 - t, 2);
       __syncthreads();
       if (wave == 0 && lane < 40) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -203,6 +258,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
         }
         pd_st_sc1(rxu, (unsigned)(((((int64_t)t * B + b) * 2 + th) * CB_XU + 4 * lane) * 4), v);
       }
+      SSASR_DTRACE(U - 1 - t, 3);
       __syncthreads();            // sD / sRed / sS are rewritten next step
     }
     return;
@@ -268,31 +324,38 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
   const int nb = n < B ? n : B - 1;                  // clamped utterance for the attention results
   const int ablk = q + 4 * wave;                     // this thread's 8 attention columns: 8 * ablk ..
 
+  WavePacer pacer{100, 0};
   for (int i = 0; i < U; ++i) {
     const int t = U - 1 - i;
     f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+    SSASR_DTRACE(i, 0);
     if (i > 0) {
+      // saved forward quantities of step t + 1 (independent of the hand-off): fetched first
+      const float* vq = p.V + ((int64_t)(t + 1) * B + nb) * A + 8 * ablk;
+      const float* qq = p.q + ((int64_t)(t + 1) * B + nb) * A + 8 * ablk;
+      const float4 vv0 = aload4(vq), vv1 = aload4(vq + 4), qv0 = aload4(qq), qv1 = aload4(qq + 4);
       // results of step t + 1: partial dh1 tiles and the attention's U_h, s_h
       u32x4 raw[10];
       const unsigned xab = (unsigned)(t + 1) * XA_STEP + (unsigned)chunk * (16 * 16 * TILE_B) +
                            (unsigned)tile * (16 * TILE_B) + (unsigned)lane * 16;
       const unsigned xub = (unsigned)(((((int64_t)(t + 1) * B + nb) * 2) * CB_XU + 8 * ablk) * 4);
-      cb_fetch<10>(raw, [=](int j) {
+      pacer.sleep();
+      const bool missed = cb_fetch<10>(raw, [=](int j) {
         return j < 4 ? pd_ld_raw(rxa, xab + (unsigned)(wave + 4 * j) * TILE_B)
              : j < 6 ? pd_ld_raw(rxu, xub + (unsigned)(j - 4) * 16)                         // U_0
              : j < 8 ? pd_ld_raw(rxu, xub + (unsigned)(CB_XU * 4) + (unsigned)(j - 6) * 16)  // U_1
              : pd_ld_raw(rxu, (unsigned)(((((int64_t)(t + 1) * B + nb) * 2 + (j - 8)) * CB_XU + 128) * 4));   // s_h
       }, p.status);
+      pacer.update(missed);
+      SSASR_DTRACE(i, 1);
       part = (__builtin_bit_cast(f32x4, raw[0]) + __builtin_bit_cast(f32x4, raw[1])) +
              (__builtin_bit_cast(f32x4, raw[2]) + __builtin_bit_cast(f32x4, raw[3]));
       const float s = __builtin_bit_cast(f32x4, raw[8])[0] + __builtin_bit_cast(f32x4, raw[9])[0];
-      const float* vq = p.V + ((int64_t)(t + 1) * B + nb) * A + 8 * ablk;
-      const float* qq = p.q + ((int64_t)(t + 1) * B + nb) * A + 8 * ablk;
       float4 dq[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const f32x4 ua = __builtin_bit_cast(f32x4, raw[4 + k]), ub = __builtin_bit_cast(f32x4, raw[6 + k]);
-        const float4 vv = aload4(vq + 4 * k), qv = aload4(qq + 4 * k);
+        const float4 vv = k ? vv1 : vv0, qv = k ? qv1 : qv0;
         dq[k].x = col_ok ? (ua[0] + ub[0] - s * vv.x) * (1.f - qv.x * qv.x) : 0.f;
         dq[k].y = col_ok ? (ua[1] + ub[1] - s * vv.y) * (1.f - qv.y * qv.y) : 0.f;
         dq[k].z = col_ok ? (ua[2] + ub[2] - s * vv.z) * (1.f - qv.z * qv.z) : 0.f;
@@ -309,6 +372,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       }
     }
     __syncthreads();        // (1) dqpre in LDS
+    SSASR_DTRACE(i, 2);
     if (i > 0) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
       const float4 b0 = sQ[((2 * wave) * 4 + q) * 16 + r], b1 = sQ[((2 * wave + 1) * 4 + q) * 16 + r];
@@ -324,6 +388,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
     }
     red[wave * 64 + lane] = part;
     __syncthreads();        // (2) partial sums in LDS
+    SSASR_DTRACE(i, 3);
     if (wave == 0) {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 di = z4, df = z4, dg = z4, dov = z4;
@@ -368,6 +433,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       }
     }
     __syncthreads();        // (3) gate derivatives in LDS
+    SSASR_DTRACE(i, 4);
     {
       float4 bg[4];
 #pragma unroll
@@ -377,17 +443,13 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       for (int k = 0; k < 2; ++k) aa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 4; ++k) ac[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // dctx partial tiles first: the attention stage is next on the critical path
 #define CB_STEP(C)                                                                                   \
       _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                  \
-        ac[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[k][g].C, bg[g].C, ac[k], 0, 0, 0);           \
-      if (t > 0) {                                                                                   \
-        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                \
-          aa[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k][g].C, bg[g].C, aa[k], 0, 0, 0);         \
-      }
+        ac[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[k][g].C, bg[g].C, ac[k], 0, 0, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) { CB_STEP(x) CB_STEP(y) CB_STEP(z) CB_STEP(w) }
 #undef CB_STEP
-      // dctx partial tiles first: the attention stage is next on the critical path
       const unsigned xcb = (unsigned)t * XC_STEP + (unsigned)chunk * (16 * 32 * TILE_B) +
                            (unsigned)tile * (32 * TILE_B) + (unsigned)lane * 16;
 #pragma unroll
@@ -395,6 +457,18 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ac[k]), rxc,
                                                (int)(xcb + (unsigned)(half * 16 + 4 * wave + k) * TILE_B), 0, 16);
       if (t > 0) {
+        // two accumulators per tile: 2 tiles alone would chain each MFMA on the previous one
+        f32x4 ab2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#define CB_STEP(C)                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                              \
+          aa[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k][g].C, bg[g].C, aa[k], 0, 0, 0);         \
+          ab2[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k][g + 1].C, bg[g + 1].C, ab2[k], 0, 0, 0); \
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) { CB_STEP(x) CB_STEP(y) CB_STEP(z) CB_STEP(w) }
+#undef CB_STEP
+        aa[0] += ab2[0];
+        aa[1] += ab2[1];
         const unsigned xab = (unsigned)t * XA_STEP + (unsigned)chunk * (16 * 16 * TILE_B) + (unsigned)tile * TILE_B +
                              (unsigned)lane * 16;
 #pragma unroll
@@ -402,6 +476,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, aa[k]), rxa,
                                                  (int)(xab + (unsigned)(half * 8 + 2 * wave + k) * (16 * TILE_B)), 0, 16);
       }
+      SSASR_DTRACE(i, 5);
     }
   }
 }
