@@ -14,7 +14,9 @@ shapes = [  # name, ta, tb, M, N, K, splitk
  ('dX L2 NN', 0, 1, 7648, 1024, 1024, 1), ('dW_ih L2 TN sk2', 1, 1, 1024, 1024, 7648, 2),
  ('dW_ih L2 TN sk4', 1, 1, 1024, 1024, 7648, 4), ('dW_ih L2 TN sk8', 1, 1, 1024, 1024, 7648, 8),
  ('dW_hh L2 TN sk8', 1, 1, 1024, 256, 7616, 8), ('dW_hh L1 TN sk8', 1, 1, 1024, 256, 15264, 8),
- ('dW_ih L1 TN sk16', 1, 1, 1024, 80, 15296, 16), ('psi NT', 0, 0, 1920, 128, 512, 1),
+ ('dW_ih L1 TN sk16', 1, 1, 1024, 80, 15296, 16), ('dW_ih L1 TN sk32', 1, 1, 1024, 80, 15296, 32),
+ ('dW_hh L2 TN sk16', 1, 1, 1024, 256, 7616, 16), ('dW_hh L1 TN sk16', 1, 1, 1024, 256, 15264, 16), ('dW_hh L1 TN sk32', 1, 1, 1024, 256, 15264, 32),
+ ('dW_ih L2 TN sk16', 1, 1, 1024, 1024, 7648, 16), ('psi NT', 0, 0, 1920, 128, 512, 1),
  ('big NT 4096^3', 0, 0, 4096, 4096, 4096, 1)]
 for name, ta, tb, M, N, K, sk in shapes:
     a = torch.randn((K, M) if ta else (M, K), device=dev)
