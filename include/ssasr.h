@@ -77,6 +77,21 @@ int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x
                      float* dw_ih_r, float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc,
                      float* gx, int32_t* sync_ws, void* stream);
 
+/* ssasr_bilstm_bwd with the weight gradients accumulated (+=) into dw_* / db* (db2_*: optional
+ * second copy, b_ih and b_hh share theirs) on `side_stream`, overlapped with the recurrence:
+ * for layers that take the persistent K-split BPTT, the recurrence runs as `segments` (1..8)
+ * launches over consecutive step ranges and each range's weight-gradient products start on
+ * side_stream as soon as that launch has been enqueued.  The caller joins side_stream before
+ * it reads the gradients. */
+int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
+                                int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H,
+                                const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
+                                const float* w_ih_r, const float* w_hh_r, float* gates, const float* cs,
+                                const float* hs, float* dx, int64_t dxs_s, int64_t dxs_n, float* dw_ih_f,
+                                float* dw_hh_f, float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
+                                float* db_r, float* db2_r, float* ws_whhT, float* ws_dc, float* gx,
+                                int32_t* sync_ws, int segments, void* stream, void* side_stream);
+
 /* Weight gradients of a layer from the gate derivatives ssasr_bilstm_bwd left
  * in `gates`: dW_ih = dG^T X, dW_hh = sum_s dG[s]^T h[s_prev], db = column sums.
  * accumulate = 0 overwrites, 1 adds (e.g. straight into optimizer-zeroed

@@ -139,20 +139,32 @@ extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
   return gather > ring ? gather : ring;
 }
 
+bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
+  const int64_t chunks = (N + 15) / 16;
+  return S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 &&
+         getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr &&
+         getenv("SSASR_NO_PERSISTENT") == nullptr;
+}
+
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
-                                 int64_t N, int64_t H, int dirs, hipStream_t st) {
+                                 int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0, int64_t i1,
+                                 float* dc_state) {
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int kpw = (int)(H / 16);
   const bool ksplit = getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr;
+  if (i1 <= 0) i1 = S;
+  const bool ranged = i0 != 0 || i1 != S;
+  if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && (!ksplit || !dc_state))) return SSASR_EARG;
   // every workgroup must be resident: at most one (K-split) per CU; the gather form is kept to two chunks
   if (!gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
       (ksplit ? (H / 16) * dirs * chunks > 256 : chunks > 2) ||
       S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) || !aligned16(cs) ||
       !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
     return SSASR_EARG;
-  SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
+  if (i0 == 0) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
   EncPersistBwd p{};
+  p.i0 = (int)i0; p.i1 = (int)i1; p.dc_state = dc_state;
   p.whhT = whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens;
   p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
   p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 16);
@@ -162,7 +174,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
     const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
     p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
-    SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
+    if (i0 == 0) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
     const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
     if (halves) pgrid.z *= 2;
@@ -257,6 +269,61 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
 // second copy of the bias gradient (b_ih and b_hh have the same derivative).
 // Off the critical path of the backward pass: callers may enqueue it on a
 // second stream.
+static hipEvent_t overlap_event() {       // small ring of events that order the second stream after the first
+  static hipEvent_t pool[16];
+  static int next = -1;
+  if (next < 0) {
+    for (auto& e : pool)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    next = 0;
+  }
+  hipEvent_t e = pool[next];
+  next = (next + 1) % 16;
+  return e;
+}
+
+// Weight / bias gradients of direction d from the time steps [s_lo, s_hi) only, added to the
+// outputs (which the caller zeroed if needed).
+static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgates, const float* x, int64_t xs_s,
+                           int64_t xs_n, const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
+                           float* dwih, float* dwhh, float* db, float* db2, hipStream_t st) {
+  const int64_t rows = S * N;
+  const float* dG = dgates + d * rows * 4 * H;
+  int rc;
+  if (s_hi <= s_lo) return SSASR_OK;
+  {           // dW_ih += dG[s_lo:s_hi]^T . X[s_lo:s_hi]
+    GemmDesc g{};
+    g.A = dG + s_lo * N * 4 * H; g.ma = rm_dense(4 * H);
+    g.B = x + s_lo * xs_s; g.mb = RowMap{0, N, xs_s, xs_n};
+    g.C = dwih; g.mc = rm_dense(I);
+    g.M = (int)(4 * H); g.N = (int)I; g.K = (int)((s_hi - s_lo) * N);
+    g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
+    const int64_t tiles = ((4 * H + 63) / 64) * ((I + 63) / 64);
+    int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
+    if (g.K < 64 * sk) sk = 1;
+    g.splitk = sk;
+    if ((rc = ssasr_launch_gemm(g, st))) return rc;
+  }
+  {           // dW_hh += sum_s dG[s]^T . h[s_prev],  s_prev = s - 1 (forward direction) or s + 1 (reverse)
+    const int64_t a0 = d ? s_lo : (s_lo > 1 ? s_lo : 1);            // first s that has a predecessor in range
+    const int64_t a1 = d ? (s_hi < S - 1 ? s_hi : S - 1) : s_hi;
+    if (a1 > a0) {
+      GemmDesc g{};
+      g.A = dG + a0 * N * 4 * H; g.ma = rm_dense(4 * H);
+      g.B = hs + d * rows * H + (d ? a0 + 1 : a0 - 1) * N * H; g.mb = rm_dense(H);
+      g.C = dwhh; g.mc = rm_dense(H);
+      g.M = (int)(4 * H); g.N = (int)H; g.K = (int)((a1 - a0) * N);
+      g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
+      const int64_t tiles = ((4 * H + 63) / 64) * ((H + 63) / 64);
+      int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
+      if (g.K < 64 * sk) sk = 1;
+      g.splitk = sk;
+      if ((rc = ssasr_launch_gemm(g, st))) return rc;
+    }
+  }
+  return ssasr_launch_colsum(dG + s_lo * N * 4 * H, (s_hi - s_lo) * N, (int)(4 * H), 4 * H, db, st, db2);
+}
+
 extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t xs_s, int64_t xs_n,
                                   const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
                                   float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
@@ -265,49 +332,18 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dgates || !x || !hs) return SSASR_EARG;
   if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t rows = S * N;
   float* dwih[2] = {dw_ih_f, dw_ih_r};
   float* dwhh[2] = {dw_hh_f, dw_hh_r};
   float* db[2] = {db_f, db_r};
   float* db2[2] = {db2_f, db2_r};
-  int rc;
   for (int d = 0; d < 2; ++d) {
-    const float* dG = dgates + d * rows * 4 * H;
-    {           // dW_ih = dG^T . X
-      if (!accumulate) SSASR_HIP(hipMemsetAsync(dwih[d], 0, sizeof(float) * 4 * H * I, st));
-      GemmDesc g{};
-      g.A = dG; g.ma = rm_dense(4 * H);
-      g.B = x; g.mb = RowMap{0, N, xs_s, xs_n};
-      g.C = dwih[d]; g.mc = rm_dense(I);
-      g.M = (int)(4 * H); g.N = (int)I; g.K = (int)rows;
-      g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
-      const int64_t tiles = ((4 * H + 63) / 64) * ((I + 63) / 64);
-      int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
-      if (rows < 64 * sk) sk = 1;
-      g.splitk = sk;
-      rc = ssasr_launch_gemm(g, st);
-      if (rc) return rc;
+    if (!accumulate) {
+      SSASR_HIP(hipMemsetAsync(dwih[d], 0, sizeof(float) * 4 * H * I, st));
+      SSASR_HIP(hipMemsetAsync(dwhh[d], 0, sizeof(float) * 4 * H * H, st));
+      SSASR_HIP(hipMemsetAsync(db[d], 0, sizeof(float) * 4 * H, st));
+      if (db2[d]) SSASR_HIP(hipMemsetAsync(db2[d], 0, sizeof(float) * 4 * H, st));
     }
-    {           // dW_hh = sum_s dG[s]^T . h[s_prev]
-      if (!accumulate) SSASR_HIP(hipMemsetAsync(dwhh[d], 0, sizeof(float) * 4 * H * H, st));
-      if (S > 1) {
-        GemmDesc g{};
-        g.A = d ? dG : dG + N * 4 * H; g.ma = rm_dense(4 * H);
-        g.B = d ? hs + d * rows * H + N * H : hs; g.mb = rm_dense(H);
-        g.C = dwhh[d]; g.mc = rm_dense(H);
-        g.M = (int)(4 * H); g.N = (int)H; g.K = (int)((S - 1) * N);
-        g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
-        const int64_t tiles = ((4 * H + 63) / 64) * ((H + 63) / 64);
-        int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
-        if ((S - 1) * N < 64 * sk) sk = 1;
-        g.splitk = sk;
-        rc = ssasr_launch_gemm(g, st);
-        if (rc) return rc;
-      }
-    }
-    if (!accumulate) SSASR_HIP(hipMemsetAsync(db[d], 0, sizeof(float) * 4 * H, st));
-    if (!accumulate && db2[d]) SSASR_HIP(hipMemsetAsync(db2[d], 0, sizeof(float) * 4 * H, st));
-    rc = ssasr_launch_colsum(dG, rows, (int)(4 * H), 4 * H, db[d], st, db2[d]);
+    const int rc = wgrad_dir_range(d, 0, S, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[d], dwhh[d], db[d], db2[d], st);
     if (rc) return rc;
   }
   return SSASR_OK;
@@ -362,3 +398,75 @@ extern "C" int ssasr_lstm_cell_bwd(const float* dh, const float* dc, const float
   return SSASR_OK;
 }
 
+
+// ssasr_bilstm_bwd with the weight gradients ACCUMULATED into dw_* / db* on a second stream,
+// overlapped with the recurrence itself: when the layer takes the K-split persistent form,
+// its BPTT runs as `segments` launches over consecutive step ranges and the weight-gradient
+// products of a range are enqueued on `side_stream` as soon as its launch is (an event orders
+// them).  That matters for the first layer, whose weight gradients otherwise start only when
+// the backward pass has nothing left to run beside them.
+extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
+                                           int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
+                                           int64_t H, const int32_t* lens, const float* w_ih_f,
+                                           const float* w_hh_f, const float* w_ih_r, const float* w_hh_r,
+                                           float* gates, const float* cs, const float* hs, float* dx,
+                                           int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f,
+                                           float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
+                                           float* db_r, float* db2_r, float* ws_whhT, float* ws_dc, float* gx,
+                                           int32_t* sync_ws, int segments, void* stream, void* side_stream) {
+  if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r || !side_stream) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream, side = (hipStream_t)side_stream;
+  float* dwih[2] = {dw_ih_f, dw_ih_r};
+  float* dwhh[2] = {dw_hh_f, dw_hh_r};
+  float* db[2] = {db_f, db_r};
+  float* db2[2] = {db2_f, db2_r};
+  int nseg = segments;
+  if (nseg > 8) nseg = 8;
+  if (nseg < 1 || !gx || !sync_ws || !ssasr_bptt_ksplit_ok(S, N, H, 2) || S < 32 * nseg) nseg = 1;
+  int rc;
+  if (nseg == 1) {
+    // plain form: the whole backward on `stream`, then every weight gradient on the second stream
+    rc = ssasr_bilstm_bwd(dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates, cs,
+                          hs, dx, dxs_s, dxs_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws_whhT, ws_dc,
+                          gx, sync_ws, stream);
+    if (rc) return rc;
+    hipEvent_t ev = overlap_event();
+    if (!ev) return (int)hipErrorOutOfMemory;
+    SSASR_HIP(hipEventRecord(ev, st));
+    SSASR_HIP(hipStreamWaitEvent(side, ev, 0));
+    return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, db2_f, dw_ih_r, dw_hh_r,
+                              db_r, db2_r, 1, side_stream);
+  }
+  if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
+  const float* whh[2] = {w_hh_f, w_hh_r};
+  const float* wih[2] = {w_ih_f, w_ih_r};
+  for (int d = 0; d < 2; ++d)
+    if ((rc = ssasr_launch_transpose(whh[d], ws_whhT + d * 4 * H * H, (int)(4 * H), (int)H, st))) return rc;
+  for (int k = 0; k < nseg; ++k) {
+    const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
+    rc = ssasr_launch_bptt_persistent(ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
+                                      ws_dc);
+    if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
+    hipEvent_t ev = overlap_event();
+    if (!ev) return (int)hipErrorOutOfMemory;
+    SSASR_HIP(hipEventRecord(ev, st));
+    SSASR_HIP(hipStreamWaitEvent(side, ev, 0));
+    // iterations [i0, i1) cover steps S - i1 .. S - i0 - 1 of the forward direction and i0 .. i1 - 1 of the reverse
+    if ((rc = wgrad_dir_range(0, S - i1, S - i0, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[0], dwhh[0], db[0], db2[0],
+                              side)))
+      return rc;
+    if ((rc = wgrad_dir_range(1, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], side)))
+      return rc;
+  }
+  const int64_t rows = S * N;
+  for (int d = 0; d < 2 && dx; ++d) {        // input gradient (critical path: the layer below needs it)
+    GemmDesc g{};
+    g.A = gates + d * rows * 4 * H; g.ma = rm_dense(4 * H);
+    g.B = wih[d]; g.mb = rm_dense(I);
+    g.C = dx; g.mc = RowMap{0, N, dxs_s, dxs_n};
+    g.M = (int)rows; g.N = (int)I; g.K = (int)(4 * H);
+    g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = d ? 1.f : 0.f; g.splitk = 1; g.batch = 1;
+    if ((rc = ssasr_launch_gemm(g, st))) return rc;
+  }
+  return SSASR_OK;
+}

@@ -786,6 +786,11 @@ struct EncPersistBwd {
   int delay;             // initial pacing delay (PersistPacer)
   int ys_s, ys_n;
   int S, N, H;
+  // K-split form only: iterations [i0, i1) of the S steps in this launch (i1 = 0 means S).
+  // A launch that does not start at 0 resumes the cell-state derivative from dc_state
+  // [2][N][H] and the partial tiles from the ring; one that stops early leaves both.
+  int i0, i1;
+  float* dc_state;
 };
 
 template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
@@ -1099,7 +1104,7 @@ template <int TPW, int HV>   // TPW = unit tiles per wave = (H / 16) / 4; grid.z
 __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   if (SSASR_PERSIST_PRIO) __builtin_amdgcn_s_setprio(SSASR_PERSIST_PRIO);
   constexpr int OT = TPW / HV;                  // product tiles per wave
-  constexpr int LAG = HV == 2 ? 3 : 1;          // steps between consuming a slot and re-arming it
+  constexpr int LAG = HV >= 2 ? 3 : 1;          // steps between consuming a slot and re-arming it
   static_assert(TPW % HV == 0 && LAG + 2 <= BWD_RS_RING, "ring too short");
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
   __shared__ __attribute__((aligned(16))) float4 coef[2][7][64];   // [parity][A, O, I, G, F, C, dy][lane]
@@ -1112,6 +1117,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z / HV, half = blockIdx.z % HV;
   const int nchunk = gridDim.z / HV;
   const int S = e.S, N = e.N, H = e.H;
+  const int i0 = e.i0, i1 = e.i1 > 0 ? e.i1 : S;    // this launch's iterations
   constexpr int T = 4 * TPW;                    // unit tiles = H / 16
   const int n0 = chunk * 16;
   const int64_t rows = (int64_t)S * N;
@@ -1134,15 +1140,15 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
     BpttSaved sv;
     auto live = [&](int i) { return (d ? i : S - 1 - i) < len; };
     if (col_ok) {
-      sv.fetch(e, gbase, cbase, d, 0, n, u0);
-      sv.publish(&coef[0][0][lane], live(0));
-      if (S > 1) sv.fetch(e, gbase, cbase, d, 1, n, u0);
+      sv.fetch(e, gbase, cbase, d, i0, n, u0);
+      sv.publish(&coef[i0 & 1][0][lane], live(i0));
+      if (i0 + 1 < S) sv.fetch(e, gbase, cbase, d, i0 + 1, n, u0);
     }
     PersistPacer pacer{e.delay, 0};
     const u32x4 fill = {PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL};
-    for (int i = 0; i < S; ++i) {
+    for (int i = i0; i < i1; ++i) {
       if (i > 0) {
-        pacer.sleep();
+        if (i > i0) pacer.sleep();
         // the re-arm stores of the previous step must have landed before this
         // workgroup publishes again (see the ring argument above)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1153,7 +1159,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
         if (i + 2 < S) sv.fetch(e, gbase, cbase, d, i + 2, n, u0);
       }
       __syncthreads();      // partial tiles summed per wave (red), loads verified
-      if (i > 0) {
+      if (i > i0) {
         pacer.update(missed != 0);
         missed = 0;
       }
@@ -1183,8 +1189,10 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   }
   const bool epi = wave == 0 && col_ok;
   float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps
+  float* dcs = e.dc_state ? e.dc_state + ((int64_t)d * N + n) * H + u0 : nullptr;
+  if (epi && i0 > 0 && dcs) dcv = ld4(dcs);
 
-  for (int i = 0; i < S; ++i) {
+  for (int i = i0; i < i1; ++i) {
     const int s = d ? i : S - 1 - i;            // reverse of the forward order
     f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
     SSASR_PTRACE(i, 0);
@@ -1306,6 +1314,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       SSASR_PTRACE(i, 7);
     }
   }
+  if (epi && half == 0 && i1 < S && dcs) st4(dcs, dcv);
 }
 
 // out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:], plain store.  Used for the

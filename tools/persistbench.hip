@@ -145,6 +145,7 @@ int main(int argc, char** argv) {
                          rs ? (size_t)2 * chB * BWD_RS_RING * 256 * 256 : (size_t)(2 * S * 4 * H * NpB), st));
     CK(hipEventRecord(e0, st));
     if (rs && getenv("HALVES_OFF")) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
+    else if (rs && getenv("QUARTERS")) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 4>), dim3(H / 16, 2, chB * 4), dim3(320), 0, st, pb);
     else if (rs) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), dim3(H / 16, 2, chB * 2), dim3(320), 0, st, pb);
     else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
@@ -152,6 +153,6 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
     printf("bwd %s: %.3f us / step (status %d)\n", rs ? "K-split" : "gather", ms * 1e3 / S, status);
   }
-  if (report("bwd", (int)(H / 16) * 2 * chB * (rs && !getenv("HALVES_OFF") ? 2 : 1), us_per_tick, (int)(H / 16))) return 1;
+  if (report("bwd", (int)(H / 16) * 2 * chB * (rs && getenv("QUARTERS") ? 4 : rs && !getenv("HALVES_OFF") ? 2 : 1), us_per_tick, (int)(H / 16))) return 1;
   return 0;
 }
