@@ -25,8 +25,11 @@ def init_from_env(backend=None):
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
+        # SSASR_DIST_BACKEND=gloo rehearses the multi-rank path where RCCL cannot run
+        # (several ranks on one GPU; gloo reduces CUDA tensors through the host)
+        backend = os.environ.get('SSASR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

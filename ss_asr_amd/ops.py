@@ -16,12 +16,21 @@ _persist_status = []     # int32[8] workspaces of persistent launches not yet ch
 
 
 def check_persistent_status():
-    """Raises if any persistent recurrence launched since the last call timed
-    out waiting for its peers (synchronises the device)."""
+    """Raises if any persistent kernel launched since the last call timed out
+    waiting for its peers (synchronises the device).  Call it where the host
+    synchronises anyway (ASRTrainer does at its logging steps)."""
     global _persist_status
     pending, _persist_status = _persist_status, []
     if pending and any(int(v) for v in torch.stack([t[i] for t, i in pending]).cpu()):
-        raise RuntimeError('ssasr_bilstm_fwd: persistent recurrence timed out')
+        raise RuntimeError('ss_asr_amd: a persistent recurrence / decode loop timed out')
+
+
+def _track_status(sync, index):
+    """Remembers a status word for check_persistent_status(); checks by itself
+    before the list grows without bound (a caller that never checks)."""
+    _persist_status.append((sync, index))
+    if len(_persist_status) > 4096:
+        check_persistent_status()
 
 
 # ---- weight-gradient overlap ------------------------------------------------
@@ -140,7 +149,7 @@ class _BiLSTM(torch.autograd.Function):
                                    _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
                                    _stream()), 'ssasr_bilstm_fwd')
         if sync is not None:
-            _persist_status.append((sync, 4))
+            _track_status(sync, 4)
         ctx.save_for_backward(x, lens, gates, cs, hs, *w)
         ctx.geom = (S, N, I, H, xs_s, xs_n, ys_s, ys_n, bool(batch_first))
         return y
@@ -171,7 +180,7 @@ class _BiLSTM(torch.autograd.Function):
         gx = torch.empty(gx_floats, device=dev, dtype=torch.float32) if gx_floats else None
         sync = torch.empty(8, device=dev, dtype=torch.int32) if gx is not None else None
         if sync is not None:
-            _persist_status.append((sync, 4))
+            _track_status(sync, 4)
         if sinks is not None:
             # Weight gradients go to the side stream, accumulated into the flat gradient
             # buffer.  The BPTT is cut into 4 segments whose weight-gradient GEMMs start
@@ -364,7 +373,7 @@ class _DecoderLoop(torch.autograd.Function):
             bufs.update(ws_hx1=f(U, D // 4, 32, 4), ws_hx2=f(U, D // 4, 32, 4), ws_qx=f(U, A // 16, 32, 16),
                         ws_modes=torch.empty(U, device=dev, dtype=torch.int32),
                         ws_sync=torch.empty(8, device=dev, dtype=torch.int32))
-            _persist_status.append((bufs['ws_sync'], 5))
+            _track_status(bufs['ws_sync'], 5)
         modes = (C.c_int32 * U)(*[int(m) for m in step_mode])
         d = _lib.Decoder()
         d.B, d.T, d.E, d.A, d.D, d.V, d.U = B, T, E, A, D, V, U
@@ -415,8 +424,8 @@ class _DecoderLoop(torch.autograd.Function):
         if gx_floats:                     # persistent BPTT of the second cell
             ws['ws_gx'] = f(gx_floats)
             ws['ws_sync'] = torch.zeros(8, device=dev, dtype=torch.int32)
-            _persist_status.append((ws['ws_sync'], 4))
-            _persist_status.append((ws['ws_sync'], 5))
+            _track_status(ws['ws_sync'], 4)
+            _track_status(ws['ws_sync'], 5)
             chain_floats = int(lib.ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D))
             if chain_floats:              # persistent first-cell <-> attention chain
                 ws['ws_chain'] = f(chain_floats)

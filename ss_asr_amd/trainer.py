@@ -214,6 +214,8 @@ class ASRTrainer(Solver):
                 loss.backward()
                 self.step(self.asr_model.parameters(), self.optim)
 
+                if self.tr.step % self.logging_step == 0:
+                    ops.check_persistent_status()      # the host synchronises here anyway
                 if self.rank == 0:
                     if self.tr.step % self.logging_step == 0:
                         self.lg.scalar('train_loss', loss.item(), self.tr.step)
