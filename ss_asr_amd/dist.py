@@ -1,14 +1,22 @@
-"""Plain data parallelism for the ASR train step: one process per GPU, one
-collective per step.
+"""Plain data parallelism for the ASR train step: one process per GPU, the
+flat gradient summed across ranks once per step.
 
 The reference is single-process; this is the one
 parallel strategy the build adds.  Utterance batches shard naturally across
 ranks; the only exchange is a SUM all-reduce of the flat fp32 gradient buffer
-(10,269,874 values = 41 MB at the default sizes) issued once per step on RCCL
-(torch.distributed backend "nccl" on ROCm).  Averaging is folded into the
-clip + Adadelta kernel as ``grad_scale = 1 / world_size`` so the gradient is
-not touched a second time, and clipping / the NaN guard run after the
-reduction so every rank takes the same branch.
+(10,269,874 values = 41 MB at the default sizes) on RCCL (torch.distributed
+backend "nccl" on ROCm).  Averaging is folded into the clip + Adadelta kernel
+as ``grad_scale = 1 / world_size`` so the gradient is not touched a second
+time, and clipping / the NaN guard run after the reduction so every rank
+takes the same branch.
+
+GradReducer issues that sum as two collectives so that almost all of it
+overlaps the backward pass: the first encoder layer's parameters sit at the
+head of the flat buffer and are the last to receive their gradient; everything
+behind them is complete when the second layer's weight-gradient GEMMs have
+been enqueued, and is reduced from then on (on the second stream, behind
+those GEMMs) while the first layer's BPTT still runs.  Only the head, 1.4 MB,
+is reduced after the backward pass.
 """
 import os
 
@@ -61,3 +69,78 @@ def allreduce_grad(flat_grad):
         ops.join_side_stream()       # deferred weight-gradient GEMMs must have landed
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / dist.get_world_size()
+
+
+class GradReducer:
+    """Two-bucket all-reduce of FlatParameters.grad (see the module docstring).
+
+    ``head_params``: the parameters whose backward comes last (the first encoder
+    layer's); they must be a prefix of the flat buffer, else one collective is used.
+    Call ``begin()`` before backward and ``finish()`` after it (returns the scale for
+    the optimizer kernel); ``wgrad_enqueued`` is the listener for
+    ``ops.set_wgrad_listener``.
+    """
+
+    def __init__(self, flat, head_params):
+        ids = {id(p) for p in head_params}
+        n = 0
+        for p, o in zip(flat.params, flat.offsets):
+            if id(p) in ids:
+                n = max(n, o + (p.numel() + 3) // 4 * 4)
+        if any(id(p) in ids for p in flat.params[len(ids):]) or n == 0 or n >= flat.numel:
+            n = 0                      # head is not a proper prefix of the buffer: single collective
+        self.flat, self.split = flat, n
+        self.pending = None            # deferred tail gradients (data_ptr) still awaited this step
+        self.learned = None            # the set of deferred tail gradients, observed in the first step
+        self.seen = set()
+        self.work = None
+
+    def begin(self):
+        self.work = None
+        self.seen = set()
+        self.pending = None
+        if is_active() and self.split and self.learned and not os.environ.get('SSASR_DDP_NO_OVERLAP'):
+            self.pending = set(self.learned)
+
+    def wgrad_enqueued(self, sinks):
+        """Listener for ops: the gradients `sinks` (tensors) have just been enqueued on the
+        second stream.  Which gradients arrive that way is learned from the first step;
+        from then on, when the last of the tail's has arrived, the tail is reduced
+        right behind it."""
+        ptrs = [t.data_ptr() for t in sinks]
+        self.seen.update(ptrs)
+        if self.pending is None:
+            return
+        self.pending.difference_update(ptrs)
+        if not self.pending:
+            self.pending = None
+            self._reduce_tail()
+
+    def _reduce_tail(self):
+        tail = self.flat.grad[self.split:]
+        if tail.is_cuda:
+            from . import ops
+            side = ops.side_stream()
+            side.wait_stream(torch.cuda.current_stream())     # gradients accumulated by autograd on this stream
+            with torch.cuda.stream(side):
+                self.work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            self.work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        if not is_active():
+            return 1.0
+        if self.flat.grad.is_cuda:
+            from . import ops
+            ops.join_side_stream()
+        if self.work is None:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+        else:
+            self.work.wait()
+            self.work = None
+            dist.all_reduce(self.flat.grad[:self.split], op=dist.ReduceOp.SUM)
+        if self.learned is None and self.split:
+            head_end = self.flat.grad.data_ptr() + 4 * self.split
+            self.learned = frozenset(p for p in self.seen if p >= head_end)
+        self.pending = None
+        return 1.0 / dist.get_world_size()

@@ -18,6 +18,9 @@ class ASRTrainStep:
         sdist.broadcast_flat(self.flat.data)
         self.optim = FusedAdadelta(self.flat, lr=lr, rho=rho, eps=eps)
         self.grad_clip = grad_clip
+        # gradient all-reduce in two buckets, the large one overlapped with the last layer's BPTT
+        self.reducer = sdist.GradReducer(self.flat, list(model.encoder.blstm_1.parameters()))
+        ops.set_wgrad_listener(self.reducer.wgrad_enqueued)
 
     def forward_loss(self, x, y, x_lens, ans_len):
         _, logits, att = self.model(x, ans_len, teacher=y, state_len=x_lens)
@@ -28,9 +31,10 @@ class ASRTrainStep:
         (descending), ans_len = max label length - 1.  Returns the loss tensor
         (on the device; reading it synchronises)."""
         self.optim.zero_grad()
+        self.reducer.begin()
         loss, _, _ = self.forward_loss(x, y, x_lens, ans_len)
         loss.backward()
-        scale = sdist.allreduce_grad(self.flat.grad)
+        scale = self.reducer.finish()
         self.optim.clip_and_step(self.grad_clip, grad_scale=scale)
         return loss
 

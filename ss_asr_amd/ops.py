@@ -55,6 +55,22 @@ def join_side_stream():
         torch.cuda.current_stream().wait_stream(_side)
 
 
+_wgrad_listener = None
+
+
+def set_wgrad_listener(fn):
+    """fn(list of gradient tensors) is called whenever deferred weight gradients have
+    been enqueued on the side stream (dist.GradReducer overlaps its all-reduce with the
+    rest of the backward pass from that)."""
+    global _wgrad_listener
+    _wgrad_listener = fn
+
+
+def _notify_wgrad(sinks):
+    if _wgrad_listener is not None:
+        _wgrad_listener(sinks)
+
+
 def _grad_sinks(params):
     """The .grad tensors to accumulate into, or None if any parameter is not
     managed by a flat gradient buffer."""
@@ -197,6 +213,7 @@ class _BiLSTM(torch.autograd.Function):
                 'ssasr_bilstm_bwd_overlapped')
             for t in (gates, x, hs):
                 t.record_stream(side)
+            _notify_wgrad(sinks)
             return (dx,) + (None,) * 12
         check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
@@ -446,6 +463,7 @@ class _DecoderLoop(torch.autograd.Function):
                       'ssasr_decoder_wgrad')
             for t in list(bufs.values()) + list(ws.values()) + [dlogits]:
                 t.record_stream(side)
+            _notify_wgrad(sinks)
             return (out['dfeat'], out['dcomp']) + (None,) * 17
         o = out
         return (o['dfeat'], o['dcomp'], None, None, None, None, None,

@@ -50,6 +50,34 @@ def _worker(rank, world, port, out):
     # parameter views still alias the flat buffer after the collective
     p = next(model.parameters())
     assert p.grad.data_ptr() == flat.grad.data_ptr()
+
+    # two-bucket reduction (GradReducer): head = first encoder layer, tail reduced early
+    red = sdist.GradReducer(flat, list(model.encoder.blstm_1.parameters()))
+    assert 0 < red.split < flat.numel
+    params = list(model.parameters())
+    nhead = len(list(model.encoder.blstm_1.parameters()))
+    deferred = [q.grad for q in params[nhead:] if q.dim() >= 1][3:]        # some tail gradients arrive "late"
+    head_sinks = [q.grad for q in params[:nhead]]
+    for step in range(3):
+        g2 = torch.Generator().manual_seed(1000 * step + rank)
+        local = torch.randn(flat.numel, generator=g2)
+        red.begin()
+        flat.grad.copy_(local)                       # stands for the gradients autograd wrote directly
+        if step == 0:
+            assert red.pending is None               # nothing learned yet: one collective
+        else:
+            assert red.pending is not None and red.work is None
+        half = len(deferred) // 2
+        red.wgrad_enqueued(deferred[:half])
+        assert red.work is None
+        red.wgrad_enqueued(deferred[half:])
+        assert (red.work is not None) == (step > 0)  # tail goes out as soon as its last deferred part is in
+        red.wgrad_enqueued(head_sinks)               # the head's own gradients arrive last
+        sc = red.finish()
+        assert sc == 1.0 / world and red.work is None
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(flat.grad, sum(gathered), atol=1e-5), step
     if rank == 0:
         with open(out, 'w') as f:
             f.write('ok')
