@@ -192,3 +192,41 @@ def test_persistent_decode_loop_equals_multi_launch_loop():
     np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), atol=2e-6, rtol=0)
     for x, y in zip(a[3:], b[3:]):
         np.testing.assert_allclose(x.numpy(), y.numpy(), atol=5e-5 * max(1.0, float(y.abs().max())), rtol=0)
+
+
+@pytest.mark.slow
+def test_long_utterances_config4_shape_against_the_oracle():
+    """BASELINE.json configs[3] in miniature: 1,500+ frame utterances (T' = 192 > 128, so the
+    decode loop takes the per-step kernels while the encoder runs 1,536 / 768 / 384 persistent
+    steps with the exchange ring wrapping around hundreds of times and the BPTT cut into
+    segments).  One train step against the CPU oracle on the same seeded weights."""
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.engine import ASRTrainStep, label_geometry
+    from ss_asr_amd.synthetic import make_batch
+    from ss_asr_amd import ops
+    dims = (50, 256, 256, 128, 80)
+    frames = np.array([1536, 1400, 1111])
+    chars = np.array([60, 52, 41])
+    x, y, lens = make_batch(frames, chars, 80, seed=11)
+    _, ans_len = label_geometry(y)
+    torch.manual_seed(0)
+    ref = lo.OracleASR(*dims, 1.0)
+    lo.seeded_weights(ref, 9)
+    ropt = lo.make_optimizer(ref)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref_loss, ref_norm = lo.train_step(ref, ropt, x, y)
+    model = ASR(*dims, 1.0)
+    lo.seeded_weights(model, 9)
+    model = model.to('cuda:0')
+    step = ASRTrainStep(model)
+    random.seed(0)
+    loss = float(step(x.cuda(), y.cuda(), lens, ans_len))
+    norm, skipped = step.optim.poll(wait=True)
+    ops.check_persistent_status()
+    assert not skipped
+    assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)
+    assert abs(norm - ref_norm) < 2e-3 * max(1.0, ref_norm), (norm, ref_norm)
+    got = dict(model.named_parameters())
+    for k, v in ref.named_parameters():
+        if k in ('encoder.blstm_1.layer.weight_hh_l0', 'decoder.layer_1.weight_ih', 'attention.psi.weight'):
+            np.testing.assert_allclose(got[k].detach().cpu().numpy(), v.detach().numpy(), atol=2e-4, rtol=0, err_msg=k)
