@@ -12,11 +12,15 @@ int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hip
 
 int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st,
                         float* out2) {
+  if (rows <= 0 || cols <= 0) return SSASR_OK;
   int64_t gy64 = (rows + 255) / 256;
   int gy = gy64 > 64 ? 64 : (int)gy64;
   if (gy < 1) gy = 1;
   dim3 grid((cols + 63) / 64, gy), block(256);
-  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, m, rows, cols, ld, out, out2);
+  if (cols % 4 == 0 && ld % 4 == 0 && aligned16(m))
+    hipLaunchKernelGGL(colsum4_kernel, grid, block, 0, st, m, rows, cols, ld, out, out2);
+  else
+    hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, m, rows, cols, ld, out, out2);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
