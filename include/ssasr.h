@@ -50,7 +50,7 @@ int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
  * Saved for backward: gates [2][S*N][4H], cs [2][S*N][H], hs [2][S*N][H].
  * Optional workspaces that enable the single-launch persistent recurrence
  * (taken when H % 64 == 0 and N <= 128): hx [2][S][H/4][roundup(N,8)][4] floats
- * and sync_ws int32[8] (sync_ws[4] != 0 afterwards reports an exchange
+ * and sync_ws int32[8], ZERO ON ENTRY (sync_ws[4] != 0 afterwards reports an exchange
  * timeout); pass NULL for one launch per step.
  * Replaces: pBLSTM.forward / nn.LSTM, src/asr.py:406-427, :262. */
 int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
@@ -66,7 +66,7 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
  * dw_ih_f == NULL defers every weight gradient to ssasr_bilstm_wgrad.
  * Optional, enabling the single-launch persistent BPTT (H in {64,128,256},
  * N <= 128): gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats of exchange
- * workspace (contents irrelevant on entry), sync_ws int32[8]; NULL = one
+ * workspace (contents irrelevant on entry), sync_ws int32[8] zero on entry; NULL = one
  * launch per step. */
 int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);
 int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,

@@ -497,10 +497,19 @@ __global__ void teacher_chars_kernel(const int32_t* teacher, int64_t ld, int32_t
   chars[i] = (t && teacher) ? teacher[(int64_t)b * ld + t] : 0;
 }
 
-// out[row][:] = table[idx[row]][:]
-__global__ void embed_gather_kernel(const float* table, const int32_t* idx, float* out, int64_t rows, int D) {
+// out[row][:] = table[idx[row]][:].  With `modes` (device int32[U], rows = (U + 1) * B in step-major
+// order): the rows of step t + 1 after a step t that is not teacher forced (modes[t] != 0) are
+// produced later, by the persistent decode loop, and start as its fill pattern instead.
+__global__ void embed_gather_kernel(const float* table, const int32_t* idx, float* out, int64_t rows, int D,
+                                    const int32_t* modes, int B, int U) {
   const int64_t row = blockIdx.x;
   if (row >= rows) return;
+  const int64_t t = modes ? row / B : 0;
+  if (modes && t >= 1 && t < U && modes[t - 1] != 0) {
+    const float fill = __builtin_bit_cast(float, 0x7FC0DEADu);      // PERSIST_SENTINEL (rnn_kernels.h)
+    for (int k = threadIdx.x; k < D; k += blockDim.x) out[row * D + k] = fill;
+    return;
+  }
   const float* src = table + (int64_t)idx[row] * D;
   for (int k = threadIdx.x; k < D; k += blockDim.x) out[row * D + k] = src[k];
 }

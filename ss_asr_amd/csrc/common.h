@@ -93,7 +93,7 @@ int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hip
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0 = 0, int64_t i1 = 0,
-                                 float* dc_state = nullptr);
+                                 float* dc_state = nullptr, const float* whh_f = nullptr, const float* whh_r = nullptr);
 // true when the shape takes the K-split persistent form (which supports iteration ranges)
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs);
 extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);

@@ -177,17 +177,19 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   }
   // Embeddings of every known input character in one gather; rows of sampled
   // steps are overwritten inside the loop.
-  hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)((U + 1) * B)), dim3(64), 0, st, d.embed, d.chars,
-                     d.emb_in, (U + 1) * B, (int)D);
-  SSASR_LAUNCH_CHECK();
-
   // Single persistent launch for the production sizes (decoder_persistent.h).
   const bool persistent = d.ws_hx1 && d.ws_hx2 && d.ws_qx && d.ws_modes && d.ws_sync && A == PD_A &&
                           E == PD_E && D == PD_D && B <= 32 && T <= 128 && V <= 64 &&
                           !getenv("SSASR_NO_PERSISTENT") && !getenv("SSASR_NO_PERSISTENT_DECODER");
-  if (d.ws_sync) SSASR_HIP(hipMemsetAsync(d.ws_sync, 0, 8 * sizeof(int32_t), st));
+  const bool sentinel = persistent && getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
+  if (persistent) SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
+  // (self-verifying loop: rows the loop itself produces start as the fill pattern)
+  hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)((U + 1) * B)), dim3(64), 0, st, d.embed, d.chars,
+                     d.emb_in, (U + 1) * B, (int)D, sentinel ? d.ws_modes : nullptr, (int)B, (int)U);
+  SSASR_LAUNCH_CHECK();
+
+  if (d.ws_sync && getenv("SSASR_PERSISTENT_COUNTER")) SSASR_HIP(hipMemsetAsync(d.ws_sync, 0, 5 * sizeof(int32_t), st));
   if (persistent) {
-    SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
     DecPersist p{};
     p.feat = d.feat; p.comp = d.comp; p.enc_len = d.enc_len; p.w_phi = d.w_phi;
     p.w_ih1 = d.w_ih1; p.w_hh1 = d.w_hh1; p.b_ih1 = d.b_ih1; p.b_hh1 = d.b_hh1;
@@ -199,17 +201,18 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     p.cnt = reinterpret_cast<unsigned*>(d.ws_sync); p.status = d.ws_sync + 5;
     p.B = (int)B; p.T = (int)T; p.U = (int)U; p.V = (int)V;
     const size_t lds = decoder_persistent_lds((int)T);
-    if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
-      // self-verifying hand-offs: every exchanged buffer starts as the fill pattern
+    if (sentinel) {
+      // self-verifying hand-offs: every exchanged buffer starts as the fill pattern (one fill
+      // when the caller laid the three exchange images out back to back)
       const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4, img_q = (size_t)(PD_A / 16) * PD_BP * 16;   // floats per step
-      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, img_h * U, st));
-      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx2, (int)PERSIST_SENTINEL, img_h * U, st));
-      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_qx, (int)PERSIST_SENTINEL, img_q * U, st));
+      if (d.ws_hx2 == d.ws_hx1 + img_h * U && d.ws_qx == d.ws_hx2 + img_h * U) {
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, (2 * img_h + img_q) * U, st));
+      } else {
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, img_h * U, st));
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx2, (int)PERSIST_SENTINEL, img_h * U, st));
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_qx, (int)PERSIST_SENTINEL, img_q * U, st));
+      }
       SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ctx, (int)PERSIST_SENTINEL, (size_t)(U * B * E), st));
-      for (int64_t t = 0; t + 1 < U; ++t)        // embeddings the loop itself produces
-        if (d.step_mode[t] != 0)
-          SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)(d.emb_in + (t + 1) * B * D), (int)PERSIST_SENTINEL,
-                                      (size_t)(B * D), st));
       SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(decoder_fwd_persistent_kernel<true>, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);

@@ -84,7 +84,9 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
                       (H / 4) * 2 * chunks <= 512 && S * Np * H * 4 < (1ll << 31) &&   // <= 2 workgroups per CU
                       aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
                       ys_n % 4 == 0 && !getenv("SSASR_NO_PERSISTENT");
-    if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
+    // status words are zero on entry (caller's contract); only the arrival counters of the
+    // counter form need clearing per launch
+    if (sync_ws && getenv("SSASR_PERSISTENT_COUNTER")) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 4 * sizeof(int32_t), st));
     if (fits) {
       EncPersist p{};
       p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
@@ -153,7 +155,7 @@ bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0, int64_t i1,
-                                 float* dc_state) {
+                                 float* dc_state, const float* whh_f, const float* whh_r) {
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int kpw = (int)(H / 16);
   const bool ksplit = getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr;
@@ -161,14 +163,15 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
   const bool ranged = i0 != 0 || i1 != S;
   if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && (!ksplit || !dc_state))) return SSASR_EARG;
   // every workgroup must be resident: at most one (K-split) per CU; the gather form is kept to two chunks
-  if (!gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
+  if ((!whhT && !(ksplit && whh_f)) || !gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
       (ksplit ? (H / 16) * dirs * chunks > 256 : chunks > 2) ||
       S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) || !aligned16(cs) ||
       !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
     return SSASR_EARG;
-  if (i0 == 0) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
+  if (i0 == 0 && !ksplit) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 4 * sizeof(int32_t), st));   // arrival counters
   EncPersistBwd p{};
   p.i0 = (int)i0; p.i1 = (int)i1; p.dc_state = dc_state;
+  if (ksplit && whh_f && (dirs == 1 || whh_r)) { p.whh[0] = whh_f; p.whh[1] = whh_r; }
   p.whhT = whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens;
   p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
   p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 16);
@@ -234,7 +237,6 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
   // BPTT: one persistent launch when the grid is certain to be resident
   // (rnn_kernels.h, "persistent backward recurrence"), else one launch per step.
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31)) return SSASR_EARG;
-  if (sync_ws) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 8 * sizeof(int32_t), st));
   bool persistent = false;
   if (gx && sync_ws && !getenv("SSASR_NO_PERSISTENT")) {
     rc = ssasr_launch_bptt_persistent(ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st);
@@ -442,14 +444,13 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
                               db_r, db2_r, 1, side_stream);
   }
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
-  const float* whh[2] = {w_hh_f, w_hh_r};
   const float* wih[2] = {w_ih_f, w_ih_r};
-  for (int d = 0; d < 2; ++d)
-    if ((rc = ssasr_launch_transpose(whh[d], ws_whhT + d * 4 * H * H, (int)(4 * H), (int)H, st))) return rc;
+  if (!w_hh_f || !w_hh_r) return SSASR_EARG;
   for (int k = 0; k < nseg; ++k) {
     const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
-    rc = ssasr_launch_bptt_persistent(ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
-                                      ws_dc);
+    // the K-split kernel takes its weight slices straight from W_hh: no transposed copy
+    rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
+                                      ws_dc, w_hh_f, w_hh_r);
     if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
     hipEvent_t ev = overlap_event();
     if (!ev) return (int)hipErrorOutOfMemory;

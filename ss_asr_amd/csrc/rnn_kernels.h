@@ -791,6 +791,7 @@ struct EncPersistBwd {
   // [2][N][H] and the partial tiles from the ring; one that stops early leaves both.
   int i0, i1;
   float* dc_state;
+  const float* whh[2];   // K-split form: the untransposed [4H][H] weights per direction (whhT unused) or null
 };
 
 template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
@@ -1183,9 +1184,19 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
 #pragma unroll
   for (int t = 0; t < OT; ++t) {
     const int unit = 16 * (otile0 + t) + r;
-    const float* wp = e.whhT + ((int64_t)d * H + unit) * 4 * H + 16 * tile + 4 * q;
+    if (e.whh[d]) {
+      // straight from the [4H][H] weight: four strided scalars per register quad, once per launch
+      const float* wp = e.whh[d] + (int64_t)(16 * tile + 4 * q) * H + unit;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) wreg[t][g] = *reinterpret_cast<const float4*>(wp + (int64_t)g * H);
+      for (int g = 0; g < 4; ++g) {
+        const float* w = wp + (int64_t)g * H * H;
+        wreg[t][g] = make_float4(w[0], w[H], w[2 * (int64_t)H], w[3 * (int64_t)H]);
+      }
+    } else {
+      const float* wp = e.whhT + ((int64_t)d * H + unit) * 4 * H + 16 * tile + 4 * q;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wreg[t][g] = *reinterpret_cast<const float4*>(wp + (int64_t)g * H);
+    }
   }
   const bool epi = wave == 0 && col_ok;
   float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps

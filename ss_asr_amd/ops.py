@@ -25,6 +25,23 @@ def check_persistent_status():
         raise RuntimeError('ss_asr_amd: a persistent recurrence / decode loop timed out')
 
 
+_status_pools = {}
+
+
+def _status_words(device):
+    """int32[8] status / counter words for one persistent launch, zero on entry as the C ABI
+    asks.  Rows of one zero-initialised pool are handed out in turn, so that no fill kernel
+    runs per launch; a row is reused after 4096 launches and still holds zeros unless a
+    launch timed out (check_persistent_status() reports that, and it is fatal anyway)."""
+    key = str(device)
+    pool = _status_pools.get(key)
+    if pool is None:
+        pool = _status_pools[key] = [torch.zeros(4096, 8, device=device, dtype=torch.int32), 0]
+    row = pool[0][pool[1]]
+    pool[1] = (pool[1] + 1) % 4096
+    return row
+
+
 def _track_status(sync, index):
     """Remembers a status word for check_persistent_status(); checks by itself
     before the list grows without bound (a caller that never checks)."""
@@ -160,7 +177,7 @@ class _BiLSTM(torch.autograd.Function):
         # workspaces of the persistent recurrence (exchange image + counters)
         hx = torch.empty(2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4, device=x.device,
                          dtype=torch.float32) if N <= 128 and H % 64 == 0 else None
-        sync = torch.empty(8, device=x.device, dtype=torch.int32) if hx is not None else None
+        sync = _status_words(x.device) if hx is not None else None
         check(lib.ssasr_bilstm_fwd(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
                                    _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
                                    _stream()), 'ssasr_bilstm_fwd')
@@ -194,7 +211,7 @@ class _BiLSTM(torch.autograd.Function):
         # workspaces of the persistent BPTT (exchange image + counters)
         gx_floats = int(lib.ssasr_bilstm_bwd_gx_floats(S, N, H))
         gx = torch.empty(gx_floats, device=dev, dtype=torch.float32) if gx_floats else None
-        sync = torch.empty(8, device=dev, dtype=torch.int32) if gx is not None else None
+        sync = _status_words(dev) if gx is not None else None
         if sync is not None:
             _track_status(sync, 4)
         if sinks is not None:
@@ -387,9 +404,12 @@ class _DecoderLoop(torch.autograd.Function):
                     gates2=f(U, B, 4 * D), c2=f(U, B, D), h2=f(U, B, D))
         if A == 128 and E == 512 and D == 256 and B <= 32 and T <= 128 and V <= 64:
             # workspaces of the persistent decode loop
-            bufs.update(ws_hx1=f(U, D // 4, 32, 4), ws_hx2=f(U, D // 4, 32, 4), ws_qx=f(U, A // 16, 32, 16),
+            # (the three exchange images back to back: one fill instead of three)
+            img = f(U * (2 * (D // 4) * 32 * 4 + (A // 16) * 32 * 16))
+            nh = U * (D // 4) * 32 * 4
+            bufs.update(ws_hx1=img[:nh], ws_hx2=img[nh:2 * nh], ws_qx=img[2 * nh:],
                         ws_modes=torch.empty(U, device=dev, dtype=torch.int32),
-                        ws_sync=torch.empty(8, device=dev, dtype=torch.int32))
+                        ws_sync=_status_words(dev))
             _track_status(bufs['ws_sync'], 5)
         modes = (C.c_int32 * U)(*[int(m) for m in step_mode])
         d = _lib.Decoder()
@@ -440,7 +460,7 @@ class _DecoderLoop(torch.autograd.Function):
         gx_floats = int(lib.ssasr_bilstm_bwd_gx_floats(U, B, D))
         if gx_floats:                     # persistent BPTT of the second cell
             ws['ws_gx'] = f(gx_floats)
-            ws['ws_sync'] = torch.zeros(8, device=dev, dtype=torch.int32)
+            ws['ws_sync'] = _status_words(dev)
             _track_status(ws['ws_sync'], 4)
             _track_status(ws['ws_sync'], 5)
             chain_floats = int(lib.ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D))
