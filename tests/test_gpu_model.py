@@ -230,3 +230,37 @@ def test_long_utterances_config4_shape_against_the_oracle():
     for k, v in ref.named_parameters():
         if k in ('encoder.blstm_1.layer.weight_hh_l0', 'decoder.layer_1.weight_ih', 'attention.psi.weight'):
             np.testing.assert_allclose(got[k].detach().cpu().numpy(), v.detach().numpy(), atol=2e-4, rtol=0, err_msg=k)
+
+
+def test_four_train_steps_follow_the_oracle_trajectory():
+    """Several consecutive steps (optimizer state carried over, different batches, ragged
+    lengths): loss, clipped gradient norm and the weights after the last step against the CPU
+    oracle started from the same seeded weights."""
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.engine import ASRTrainStep, label_geometry
+    from ss_asr_amd.synthetic import make_batch
+    from ss_asr_amd import ops
+    dims = (50, 64, 64, 32, 80)
+    torch.manual_seed(0)
+    ref = lo.OracleASR(*dims, 1.0)
+    lo.seeded_weights(ref, 21)
+    ropt = lo.make_optimizer(ref)
+    model = ASR(*dims, 1.0)
+    lo.seeded_weights(model, 21)
+    model = model.to('cuda:0')
+    step = ASRTrainStep(model)
+    shapes = [([72, 64, 40, 17], [9, 7, 6, 3]), ([41, 33], [5, 4]), ([96, 95, 94, 50, 49, 8], [11, 10, 9, 6, 5, 2]),
+              ([56, 24, 16], [7, 3, 2])]
+    for k, (fr, ch) in enumerate(shapes):
+        x, y, lens = make_batch(np.array(fr), np.array(ch), 80, seed=30 + k)
+        _, ans_len = label_geometry(y)
+        ref_loss, ref_norm = lo.train_step(ref, ropt, x, y)
+        loss = float(step(x.cuda(), y.cuda(), lens, ans_len).detach())
+        norm, skipped = step.optim.poll(wait=True)
+        assert not skipped
+        assert abs(loss - ref_loss) < 2e-4, (k, loss, ref_loss)
+        assert abs(norm - ref_norm) < 2e-3 * max(1.0, ref_norm), (k, norm, ref_norm)
+    ops.check_persistent_status()
+    got = dict(model.named_parameters())
+    worst = max(float((got[k].detach().cpu() - v.detach()).abs().max()) for k, v in ref.named_parameters())
+    assert worst < 5e-4, worst
