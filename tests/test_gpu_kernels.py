@@ -112,6 +112,46 @@ def test_bilstm_packed_forward_backward(N, T, I, H, lens):
         close(a.grad, b.grad, 2e-4, 'd' + name)
 
 
+@pytest.mark.parametrize('N,S,I,H,segments', [(20, 150, 24, 64, 4), (9, 130, 16, 128, 3), (20, 150, 24, 64, 1)])
+def test_bilstm_segmented_bptt_with_overlapped_weight_gradients(N, S, I, H, segments, monkeypatch):
+    """The path the train step takes: gradients live in an optimizer-owned flat buffer, so the
+    BPTT runs in step-range segments (ring and dc state carried across launches) and the weight
+    gradients are accumulated from a second stream, range by range."""
+    from ss_asr_amd import ops
+    from ss_asr_amd.optim import FlatParameters
+    monkeypatch.setenv('SSASR_BPTT_SEGMENTS', str(segments))
+    lens = sorted(np.random.default_rng(3).integers(S // 3, S + 1, size=N).tolist(), reverse=True)
+    lens[0] = S
+    x = rnd(N, S, I, seed=51)
+    for i, l in enumerate(lens):
+        x[i, l:] = 0
+    w = lstm_weights(I, H, 60)
+    xr = x.clone().requires_grad_(True)
+    wr = [t.clone().requires_grad_(True) for t in w]
+    yr = lo.bilstm_explicit(xr.transpose(0, 1), lens, wr).transpose(0, 1)
+    gy = rnd(N, S, 2 * H, seed=52)
+    (yr * gy).sum().backward()
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(t.float().to(dev())) for t in w])
+    holder = Holder()
+    flat = FlatParameters(holder)
+    flat.grad.fill_(0.25)                                   # gradients are ACCUMULATED into the buffer
+    xd = x.float().to(dev()).requires_grad_(True)
+    ld = torch.tensor(lens, dtype=torch.int32, device=dev())
+    yd = ops.bilstm(xd, ld, S, True, list(holder.ps))
+    close(yd, yr, 2e-5, 'y')
+    (yd * gy.float().to(dev())).sum().backward()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    ops.check_persistent_status()
+    close(xd.grad, xr.grad, 5e-5, 'dx')
+    for name, a, b in zip(['w_ih', 'w_hh', 'b_ih', 'b_hh'] * 2, holder.ps, wr):
+        close(a.grad - 0.25, b.grad, 3e-4, 'd' + name)
+
+
 def test_bilstm_sequence_major_no_lengths():
     """blstm_4 form: recurrence over dim 0, every column full length."""
     from ss_asr_amd import ops
