@@ -472,21 +472,28 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
     }
     SSASR_DTRACE(t, 4);
 
-    // (F) cell 1 of step t: [emb_t | ctx_t | h1_{t-1}]
+    // (F) cell 1 of step t: [emb_t | ctx_t | h1_{t-1}].  The emb and h1 thirds do not depend on
+    // the attention: they are fetched and multiplied while ctx_t is still on its way.
     {
-      float4 b1[16];
-      {
-        const unsigned oe = (unsigned)((((int64_t)t * B + nc) * D + 16 * wave + 4 * q) * 4);
-        const unsigned oc = (unsigned)((((int64_t)t * B + nc) * E + 16 * wave + 4 * q) * 4);
-        const unsigned oh = (unsigned)((t > 0 ? t - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
-        pd_fetch<SEN, 16>(b1, [=](int j) {     // kb = wave + 4 j: 0..15 emb, 16..47 ctx, 48..63 h1
-          return j < 4 ? pd_ld_raw(re, oe + (unsigned)(64 * j) * 4)
-               : j < 12 ? pd_ld_raw(rc, oc + (unsigned)(64 * (j - 4)) * 4)
-                        : pd_ld_raw(rh1, oh + (unsigned)(4 * (j - 12)) * 4 * PD_BP * 16);
-        }, 0, t > 0 ? 16 : 12, p.status);
-      }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-      pd_mma<16>(acc, acc2, w1, b1, 0, t > 0 ? 16 : 12);
+      {
+        const float4 wA[8] = {w1[0], w1[1], w1[2], w1[3], w1[12], w1[13], w1[14], w1[15]};
+        float4 bA[8];
+        const unsigned oe = (unsigned)((((int64_t)t * B + nc) * D + 16 * wave + 4 * q) * 4);
+        const unsigned oh = (unsigned)((t > 0 ? t - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
+        pd_fetch<SEN, 8>(bA, [=](int j) {      // kb = wave + 4 j: 0..15 emb; then 48..63 h1
+          return j < 4 ? pd_ld_raw(re, oe + (unsigned)(64 * j) * 4)
+                       : pd_ld_raw(rh1, oh + (unsigned)(4 * (j - 4)) * 4 * PD_BP * 16);
+        }, 0, t > 0 ? 8 : 4, p.status);
+        pd_mma<8>(acc, acc2, wA, bA, 0, t > 0 ? 8 : 4);
+      }
+      {
+        const float4 wB[8] = {w1[4], w1[5], w1[6], w1[7], w1[8], w1[9], w1[10], w1[11]};
+        float4 bB[8];
+        const unsigned oc = (unsigned)((((int64_t)t * B + nc) * E + 16 * wave + 4 * q) * 4);
+        pd_fetch<SEN, 8>(bB, [=](int j) { return pd_ld_raw(rc, oc + (unsigned)(64 * j) * 4); }, 0, 8, p.status);   // kb 16..47
+        pd_mma<8>(acc, acc2, wB, bB, 0, 8);
+      }
       SSASR_DTRACE(t, 5);
       cell_finish(acc, acc2, bias1, cst1, t, p.gates1, p.c1, p.h1, rh1, PC_H1);
       SSASR_DTRACE(t, 6);
