@@ -191,12 +191,17 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
         float v = c[i].x * q4.x;
         v = fmaf(c[i].y, q4.y, v);
         v = fmaf(c[i].z, q4.z, v);
-        v = fmaf(c[i].w, q4.w, v);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        e[i] = v;
-        if (hw + 8 * i < len) m = fmaxf(m, v);
+        e[i] = fmaf(c[i].w, q4.w, v);
       }
+      // the 16 rows' cross-lane sums are independent chains: stage by stage, not row by row
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] += __shfl_xor(e[i], o, 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (hw + 8 * i < len) m = fmaxf(m, e[i]);
       float ssum = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += red[w * 64 + lane];
         // D fragment: rows 4q..4q+3 of this A tile, column = utterance 16*chunk + r
-        const float4 qv = make_float4(tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3]));
+        const float4 qv = make_float4(fast_tanh(v[0]), fast_tanh(v[1]), fast_tanh(v[2]), fast_tanh(v[3]));
         pd_st_sc1(rq, (unsigned)(t * img_q + ((atile * PD_BP + 16 * chunk + r) * 16 + 4 * q) * 4), qv);
         if (!SEN) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
