@@ -87,6 +87,9 @@ struct WavePacer {
     for (int k = 0; k < delay; ++k) __builtin_amdgcn_s_sleep(1);
   }
   __device__ __forceinline__ void update(bool missed) {
+#ifdef SSASR_CHAIN_NO_PACE
+    delay = 0; return;
+#endif
     if (missed) { delay = min(delay + 12, 400); clean = 0; }
     else if (++clean >= 2) { delay = max(delay - 2, 0); clean = 0; }
   }

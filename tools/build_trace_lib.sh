@@ -8,7 +8,7 @@ objs=""
 for f in ss_asr_amd/csrc/*.hip; do
   o=/tmp/ssasr_trace/$(basename $f .hip).o
   extra=""
-  [ "$(basename $f)" = "decoder.hip" ] && extra="-DSSASR_TRACE_BUILD"
+  [ "$(basename $f)" = "decoder.hip" ] && extra="-DSSASR_TRACE_BUILD $TRACE_EXTRA"
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC $extra -I ss_asr_amd/csrc -c $f -o $o &
   objs="$objs $o"
 done
