@@ -52,7 +52,7 @@ struct DecBwdChain {
   float* dqpre;           // [U][B][A]
   float* ssum;            // [U][B]
   float* xa;              // [U][2][16 dest][16 src][64][4]   partial dh1 tiles
-  float* xc;              // [U][2][16 src][32 col tile][64][4] partial dctx tiles
+  float* xc;              // [U][2][16 utterances][16 src][512] partial dctx rows (contiguous per utterance)
   float* xu;              // [U][B][2][CB_XU]
   int* status;
   int B, T, U;
@@ -150,8 +150,9 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       *reinterpret_cast<float4*>(sF + 4 * i) = aload4(fb + 4 * (int64_t)i);
     __syncthreads();
     const int c = b >> 4, bl = b & 15;
-    // dctx gather: thread -> (column tile ct, row quad q, source half jh); 8 source tiles each
-    const int ct = tid >> 3, gq = (tid >> 1) & 3, jh = tid & 1;
+    // dctx gather: the 16 sources' rows of this utterance are one contiguous 32 KB block
+    // [source][512 columns]; thread -> (column quad cq, source parity sh), 8 sources each
+    const int cq = tid & 127, sh = tid >> 7;
     const int hw = tid >> 5, l32 = tid & 31;                 // 8 groups of 32 lanes for the frame loops
     const float* cb = p.comp + ((int64_t)b * T + tau0) * A + 4 * l32;
     constexpr int RPG = 8;                                   // frame rows per 32-lane group: ceil(64 / 8)
@@ -174,25 +175,26 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
         alr[k] = (t > 0 && tl < nrow) ? ab[tl] : 0.f;
       }
       {
-        const unsigned base = (unsigned)t * XC_STEP + (unsigned)c * (16 * 32 * TILE_B) +
-                              (unsigned)ct * TILE_B + (unsigned)(gq * 16 + bl) * 16;
+        const unsigned base = (unsigned)t * XC_STEP + (unsigned)((c * 16 + bl) * 16) * (E * 4) +
+                              (unsigned)(sh * E + 4 * cq) * 4;
         u32x4 raw[8];
         if (t < U - 1) pacer.sleep();
-        pacer.update(cb_fetch<8>(raw, [=](int j) { return pd_ld_raw(rxc, base + (unsigned)(jh * 8 + j) * (32 * TILE_B)); },
-                                 p.status));
+        pacer.update(cb_fetch<8>(raw, [=](int j) { return pd_ld_raw(rxc, base + (unsigned)(2 * j) * (E * 4)); }, p.status));
         f32x4 s0 = __builtin_bit_cast(f32x4, raw[0]), s1 = __builtin_bit_cast(f32x4, raw[1]);
 #pragma unroll
         for (int j = 2; j < 8; j += 2) {
           s0 += __builtin_bit_cast(f32x4, raw[j]);
           s1 += __builtin_bit_cast(f32x4, raw[j + 1]);
         }
-        f32x4 v = s0 + s1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], 1, 64);
-        if (jh == 0) {
-          const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(sD + 16 * ct + 4 * gq) = o;
-          if (th == 0) *reinterpret_cast<float4*>(p.dctx + ((int64_t)t * B + b) * E + 16 * ct + 4 * gq) = o;
+        const f32x4 v = s0 + s1;
+        f32x4* sP = reinterpret_cast<f32x4*>(sRed);            // [2][128] partial sums (sRed is free here)
+        sP[sh * 128 + cq] = v;
+        __syncthreads();
+        if (tid < 128) {
+          const f32x4 w = sP[tid] + sP[128 + tid];
+          const float4 o = make_float4(w[0], w[1], w[2], w[3]);
+          *reinterpret_cast<float4*>(sD + 4 * tid) = o;
+          if (th == 0) *reinterpret_cast<float4*>(p.dctx + ((int64_t)t * B + b) * E + 4 * tid) = o;
         }
       }
       SSASR_DTRACE(U - 1 - t, 1);
@@ -453,12 +455,12 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) { CB_STEP(x) CB_STEP(y) CB_STEP(z) CB_STEP(w) }
 #undef CB_STEP
-      const unsigned xcb = (unsigned)t * XC_STEP + (unsigned)chunk * (16 * 32 * TILE_B) +
-                           (unsigned)tile * (32 * TILE_B) + (unsigned)lane * 16;
+      // [chunk][utterance r][source tile][512 columns]: lane (q, r) holds columns 16 ct + 4 q ..
+      const unsigned xcb = (unsigned)t * XC_STEP + (unsigned)(((chunk * 16 + r) * 16 + tile) * E + 4 * q) * 4;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ac[k]), rxc,
-                                               (int)(xcb + (unsigned)(half * 16 + 4 * wave + k) * TILE_B), 0, 16);
+                                               (int)(xcb + (unsigned)(16 * (half * 16 + 4 * wave + k)) * 4), 0, 16);
       if (t > 0) {
         // two accumulators per tile: 2 tiles alone would chain each MFMA on the previous one
         f32x4 ab2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
