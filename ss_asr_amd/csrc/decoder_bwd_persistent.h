@@ -32,7 +32,11 @@
 namespace {
 
 constexpr int CB_NATTWG = 64;                 // attention workgroups: utterance b = x >> 1, frame half = x & 1
-constexpr int CB_XU = 160;                    // floats per (step, utterance, half): U[128], s, padding to 5 lines
+// Attention results per step: [chunk 2][frame half 2][slot 34][utterance 16][4] floats; slots 0..31
+// hold U (slot = column quad), slot 32 holds s in .x.  Utterance-minor, so that the 16 lanes of
+// a cell workgroup that want the same slot for their 16 utterances read 256 contiguous bytes.
+constexpr int CB_XU_SLOTS = 34;
+constexpr int CB_XU_STEP = 2 * 2 * CB_XU_SLOTS * 16 * 4;      // floats per step
 
 struct DecBwdChain {
   float* gates1;          // [U][B][4D] activated gates in, gate derivatives out (row-major)
@@ -53,14 +57,14 @@ struct DecBwdChain {
   float* ssum;            // [U][B]
   float* xa;              // [U][2][16 dest][16 src][64][4]   partial dh1 tiles
   float* xc;              // [U][2][16 utterances][16 src][512] partial dctx rows (contiguous per utterance)
-  float* xu;              // [U][B][2][CB_XU]
+  float* xu;              // [U][CB_XU_STEP]
   int* status;
   int B, T, U;
 };
 
 __host__ __device__ inline size_t chain_xa_floats(int64_t U) { return (size_t)U * 2 * 16 * 16 * 256; }
 __host__ __device__ inline size_t chain_xc_floats(int64_t U) { return (size_t)U * 2 * 16 * 32 * 256; }
-__host__ __device__ inline size_t chain_xu_floats(int64_t U, int64_t B) { return (size_t)U * B * 2 * CB_XU; }
+__host__ __device__ inline size_t chain_xu_floats(int64_t U, int64_t) { return (size_t)U * CB_XU_STEP; }
 inline size_t chain_lds_bytes(int T) {
   const size_t att = ((size_t)((T + 1) / 2) * PD_E + PD_E + 8 * PD_A + 16) * sizeof(float);
   const size_t cell = (4 * 64 * 4 + 2 * 7 * 64 * 4 + 4 * 64 * 4 + 8 * 4 * 16 * 4) * sizeof(float);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       if (l32 == 0) sS[hw] = sacc;
       SSASR_DTRACE(U - 1 - t, 2);
       __syncthreads();
-      if (wave == 0 && lane < 40) {
+      if (wave == 0 && lane < 33) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane < 32) {
 #pragma unroll
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
 #pragma unroll
           for (int g = 0; g < 8; ++g) v.x += sS[g];
         }
-        pd_st_sc1(rxu, (unsigned)(((((int64_t)t * B + b) * 2 + th) * CB_XU + 4 * lane) * 4), v);
+        pd_st_sc1(rxu, (unsigned)(t * CB_XU_STEP + ((((c * 2 + th) * CB_XU_SLOTS + lane) * 16 + bl) * 4)) * 4u, v);
       }
       SSASR_DTRACE(U - 1 - t, 3);
       __syncthreads();            // sD / sRed / sS are rewritten next step
@@ -343,13 +347,15 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       u32x4 raw[10];
       const unsigned xab = (unsigned)(t + 1) * XA_STEP + (unsigned)chunk * (16 * 16 * TILE_B) +
                            (unsigned)tile * (16 * TILE_B) + (unsigned)lane * 16;
-      const unsigned xub = (unsigned)(((((int64_t)(t + 1) * B + nb) * 2) * CB_XU + 8 * ablk) * 4);
+      // slot s of frame half h for utterance nb: (((nb / 16) * 2 + h) * SLOTS + s) * 16 + nb % 16, in float4 units
+      const unsigned xub = (unsigned)((t + 1) * CB_XU_STEP) * 4u + (unsigned)(((nb >> 4) * 2 * CB_XU_SLOTS) * 16 + (nb & 15)) * 16u;
+      constexpr unsigned XU_SLOT = 16 * 16, XU_HALF = CB_XU_SLOTS * 16 * 16;      // bytes
       pacer.sleep();
       const bool missed = cb_fetch<10>(raw, [=](int j) {
         return j < 4 ? pd_ld_raw(rxa, xab + (unsigned)(wave + 4 * j) * TILE_B)
-             : j < 6 ? pd_ld_raw(rxu, xub + (unsigned)(j - 4) * 16)                         // U_0
-             : j < 8 ? pd_ld_raw(rxu, xub + (unsigned)(CB_XU * 4) + (unsigned)(j - 6) * 16)  // U_1
-             : pd_ld_raw(rxu, (unsigned)(((((int64_t)(t + 1) * B + nb) * 2 + (j - 8)) * CB_XU + 128) * 4));   // s_h
+             : j < 6 ? pd_ld_raw(rxu, xub + (unsigned)(2 * ablk + (j - 4)) * XU_SLOT)              // U_0
+             : j < 8 ? pd_ld_raw(rxu, xub + XU_HALF + (unsigned)(2 * ablk + (j - 6)) * XU_SLOT)    // U_1
+             : pd_ld_raw(rxu, xub + (unsigned)(j - 8) * XU_HALF + 32u * XU_SLOT);                  // s_h
       }, p.status);
       pacer.update(missed);
       SSASR_DTRACE(i, 1);
