@@ -70,7 +70,10 @@ extern "C" int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const 
     g.C = dw_psi; g.mc = rm_dense(E);
     g.M = (int)A; g.N = (int)E; g.K = (int)rows;
     g.ta = 1; g.tb = 1; g.alpha = 1.f; g.batch = 1;
-    g.splitk = rows >= 2048 ? 16 : 1;
+    {      // 16 output tiles only: split K until the chip is full (was one 56 us launch of 16 workgroups)
+      int sk = (int)(rows / 128);
+      g.splitk = sk < 1 ? 1 : (sk > 16 ? 16 : sk);
+    }
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   if (db_psi) {
@@ -362,6 +365,10 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     m.C = g.ws_dh2; m.mc = rm_dense(D);
     m.M = (int)rows; m.N = (int)D; m.K = (int)(4 * D); m.ta = 0; m.tb = 1;
     m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
+    if (((rows + 63) / 64) * ((D + 63) / 64) < 192) {        // too few tiles for the chip: split K (accumulating form)
+      SSASR_HIP(hipMemsetAsync(g.ws_dh2, 0, sizeof(float) * rows * D, st));
+      m.splitk = 4;
+    }
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
   // The remaining chain (first cell <-> attention) as one persistent launch
