@@ -185,11 +185,28 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
     const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
     if (halves) pgrid.z *= 2;
-    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, 0, st, p);
-    else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, 0, st, p);
-    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, 0, st, p);
-    else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, 0, st, p);
-    else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, 0, st, p);
+    // Placement: the weight-gradient GEMMs of the previous range / layer run beside this kernel on
+    // the second stream.  A GEMM workgroup that shares a CU with a recurrence workgroup slows every
+    // step of it (shared MFMA pipe, LDS and memory pipeline): 2.4 -> 3.3 us per step.  The launch
+    // therefore reserves dynamic LDS it never touches, so that its 23 KB + 132 KB leave no room for
+    // a GEMM workgroup (36 KB) on the same CU: the GEMMs get the other CUs, the recurrence runs at
+    // its standalone speed (+4-5 % on the train step).  SSASR_BPTT_SHARED_CU=1 turns it off.
+    static const int reserve = getenv("SSASR_BPTT_SHARED_CU") ? 0 : 132 * 1024;
+    static bool reserved = false;
+    if (reserve && !reserved) {
+      const void* fns[] = {reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<1, 1>),
+                           reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 2>),
+                           reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 1>),
+                           reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 2>),
+                           reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 1>)};
+      for (const void* f : fns) SSASR_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
+      reserved = true;
+    }
+    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, reserve, st, p);
+    else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, reserve, st, p);
+    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, reserve, st, p);
+    else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, reserve, st, p);
+    else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, reserve, st, p);
   } else if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
     SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(dirs * S * 4 * H * Np), st));
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
