@@ -27,7 +27,7 @@ extern "C" int64_t ssasr_decoder_bwd_chain_floats(int64_t U, int64_t B, int64_t 
   if (A != PD_A || E != PD_E || D != PD_D || B <= 0 || B > 32 || T <= 0 || T > 128 || U <= 0) return 0;
   if (chain_xc_floats(U) * sizeof(float) >= (1ull << 31)) return 0;        // 32-bit buffer offsets
   return (int64_t)(U * B * A + ((U * B + 63) & ~(int64_t)63) + chain_xa_floats(U) + chain_xc_floats(U) +
-                   chain_xu_floats(U, B));
+                   chain_xu_floats(U, B) + U * B * 4 * D);
 }
 
 // ------------------------------ attention ---------------------------------
@@ -340,10 +340,18 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   }
 
   // K-contiguous copies of the recurrent weights for the per-step products.
-  if ((rc = ssasr_launch_transpose(d.w_ih1, g.ws_t_ih1, (int)(4 * D), (int)(D + E), st))) return rc;
-  if ((rc = ssasr_launch_transpose(d.w_hh1, g.ws_t_hh1, (int)(4 * D), (int)D, st))) return rc;
-  if ((rc = ssasr_launch_transpose(d.w_ih2, g.ws_t_ih2, (int)(4 * D), (int)D, st))) return rc;
-  if ((rc = ssasr_launch_transpose(d.w_hh2, g.ws_t_hh2, (int)(4 * D), (int)D, st))) return rc;
+  // (only for the per-step kernels: the persistent forms read the weights as they are)
+  const bool cell2_first = g.ws_gx && g.ws_sync && ssasr_bilstm_bwd_gx_floats(U, B, D) > 0 &&
+                           !getenv("SSASR_NO_PERSISTENT") && !getenv("SSASR_NO_PERSISTENT_DECODER");
+  const bool cell2_direct = cell2_first && ssasr_bptt_ksplit_ok(U, B, D, 1);
+  const bool chain = cell2_first && g.ws_chain && ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D) > 0 &&
+                     !getenv("SSASR_NO_PERSISTENT_DECODER_BWD");
+  if (!chain) {
+    if ((rc = ssasr_launch_transpose(d.w_ih1, g.ws_t_ih1, (int)(4 * D), (int)(D + E), st))) return rc;
+    if ((rc = ssasr_launch_transpose(d.w_hh1, g.ws_t_hh1, (int)(4 * D), (int)D, st))) return rc;
+  }
+  if (!cell2_first && (rc = ssasr_launch_transpose(d.w_ih2, g.ws_t_ih2, (int)(4 * D), (int)D, st))) return rc;
+  if (!cell2_direct && (rc = ssasr_launch_transpose(d.w_hh2, g.ws_t_hh2, (int)(4 * D), (int)D, st))) return rc;
 
   dim3 cgrid = cell_bwd_grid(D, 1, B), cblock(256);
   float* dc1 = g.ws_dc;               // [2][B][D]
@@ -353,11 +361,10 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   // the ring workspace it runs first, as ONE persistent launch of the encoder's
   // K-split BPTT kernel (one direction), and its contribution dG2 . W_ih2 to dh1
   // becomes one GEMM over all steps (into ws_dh2, which is free by then).
-  const bool cell2_first = g.ws_gx && g.ws_sync && ssasr_bilstm_bwd_gx_floats(U, B, D) > 0 &&
-                           !getenv("SSASR_NO_PERSISTENT") && !getenv("SSASR_NO_PERSISTENT_DECODER");
   if (cell2_first) {
-    if ((rc = ssasr_launch_bptt_persistent(g.ws_t_hh2, d.gates2, d.c2, g.ws_dh2, B * D, D, nullptr, g.ws_gx,
-                                           g.ws_sync, U, B, D, 1, st)))
+    if ((rc = ssasr_launch_bptt_persistent(cell2_direct ? nullptr : g.ws_t_hh2, d.gates2, d.c2, g.ws_dh2, B * D, D,
+                                           nullptr, g.ws_gx, g.ws_sync, U, B, D, 1, st, 0, 0, nullptr,
+                                           cell2_direct ? d.w_hh2 : nullptr, nullptr)))
       return rc;
     GemmDesc m{};
     m.A = d.gates2; m.ma = rm_dense(4 * D);
@@ -373,14 +380,13 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   }
   // The remaining chain (first cell <-> attention) as one persistent launch
   // (decoder_bwd_persistent.h) when its workspace is given.
-  const bool chain = cell2_first && g.ws_chain && ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D) > 0 &&
-                     !getenv("SSASR_NO_PERSISTENT_DECODER_BWD");
   if (chain) {
     float* wsV = g.ws_chain;
     float* wsS = wsV + U * B * A;
     float* xa = wsS + ((U * B + 63) & ~(int64_t)63);
     float* xc = xa + chain_xa_floats(U);
     float* xu = xc + chain_xc_floats(U);
+    float* dg1 = xu + chain_xu_floats(U, B);
     {   // V[t][b][:] = att[b][t][:] . comp[b]      (all steps, one batched product)
       GemmDesc m{};
       m.A = d.att; m.ma = rm_dense(T); m.sa = U * T;
@@ -393,16 +399,17 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)xa, (int)PERSIST_SENTINEL,
                                 chain_xa_floats(U) + chain_xc_floats(U) + chain_xu_floats(U, B), st));
     DecBwdChain c{};
-    c.gates1 = d.gates1; c.c1 = d.c1; c.add1 = g.ws_dh2; c.att = d.att; c.q = d.q; c.feat = d.feat;
-    c.comp = d.comp; c.enc_len = d.enc_len; c.V = wsV; c.whh1T = g.ws_t_hh1; c.wih1T = g.ws_t_ih1;
-    c.wphiT = d.w_phi_t; c.dctx = g.ws_dctx; c.de = g.ws_de; c.dqpre = g.ws_dqpre; c.ssum = wsS;
+    c.gates1 = d.gates1; c.dg1 = dg1; c.c1 = d.c1; c.add1 = g.ws_dh2; c.att = d.att; c.q = d.q; c.feat = d.feat;
+    c.comp = d.comp; c.enc_len = d.enc_len; c.V = wsV; c.w_hh1 = d.w_hh1; c.w_ih1 = d.w_ih1;
+    c.w_phi = d.w_phi; c.dctx = g.ws_dctx; c.de = g.ws_de; c.dqpre = g.ws_dqpre; c.ssum = wsS;
     c.xa = xa; c.xc = xc; c.xu = xu; c.status = g.ws_sync + 5;
     c.B = (int)B; c.T = (int)T; c.U = (int)U;
     const size_t lds = chain_lds_bytes((int)T);
     SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_chain_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(decoder_bwd_chain_kernel, dim3(CB_NATTWG + 64), dim3(320), lds, st, c);
-    hipLaunchKernelGGL(chain_de_fixup_kernel, dim3(256), dim3(256), 0, st, g.ws_de, d.att, wsS, (int)B, (int)U, (int)T);
+    hipLaunchKernelGGL(chain_de_fixup_kernel, dim3(256), dim3(256), 0, st, g.ws_de, d.att, wsS, (int)B, (int)U, (int)T,
+                       reinterpret_cast<float4*>(d.gates1), reinterpret_cast<const float4*>(dg1), U * B * D);
     SSASR_LAUNCH_CHECK();
   }
   for (int64_t t = U - 1; t >= 0 && !chain; --t) {

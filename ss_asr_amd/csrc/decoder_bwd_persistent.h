@@ -39,7 +39,8 @@ constexpr int CB_XU_SLOTS = 34;
 constexpr int CB_XU_STEP = 2 * 2 * CB_XU_SLOTS * 16 * 4;      // floats per step
 
 struct DecBwdChain {
-  float* gates1;          // [U][B][4D] activated gates in, gate derivatives out (row-major)
+  const float* gates1;    // [U][B][4D] activated gates (read by BOTH halves of a tile: never written here)
+  float* dg1;             // [U][B][4D] gate derivatives; chain_de_fixup_kernel moves them over gates1
   const float* c1;        // [U][B][D]
   const float* add1;      // [U][B][D]   dG2 . W_ih2
   const float* att;       // [B][U][T]
@@ -48,9 +49,9 @@ struct DecBwdChain {
   const float* comp;      // [B][T][A]
   const int32_t* enc_len;
   const float* V;         // [U][B][A]   alpha_t^T comp
-  const float* whh1T;     // [D][4D]
-  const float* wih1T;     // [D+E][4D]
-  const float* wphiT;     // [D][A]
+  const float* w_hh1;     // [4D][D]
+  const float* w_ih1;     // [4D][D+E]
+  const float* w_phi;     // [A][D]
   float* dctx;            // [U][B][E]
   float* de;              // [B][U][T]   alpha * dalpha
   float* dqpre;           // [U][B][A]
@@ -71,8 +72,12 @@ inline size_t chain_lds_bytes(int T) {
   return att > cell ? att : cell;
 }
 
-// de[b][t][tau] -= att[b][t][tau] * s[t][b]   (t >= 1)
-__global__ void chain_de_fixup_kernel(float* de, const float* att, const float* ssum, int B, int U, int T) {
+// de[b][t][tau] -= att[b][t][tau] * s[t][b]   (t >= 1);  gates1 <- dg1 (the chain kernel must not
+// overwrite the saved gates itself: the two workgroups of a tile both read them, at their own pace)
+__global__ void chain_de_fixup_kernel(float* de, const float* att, const float* ssum, int B, int U, int T,
+                                      float4* gates1, const float4* dg1, int64_t ng4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ng4; i += (int64_t)gridDim.x * blockDim.x)
+    gates1[i] = dg1[i];
   const int64_t n = (int64_t)B * U * T;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = i / ((int64_t)U * T);
@@ -309,24 +314,32 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
   }
 
   // resident weight slices
+  // (straight from the [4D][D], [4D][D+E] and [A][D] weights: four strided scalars per register
+  // quad, once per launch -- no transposed copies needed for this kernel)
   float4 wa[2][4], wc[4][4], wp[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int unit = 16 * (half * 8 + 2 * wave + t) + r;                   // dh1 destination unit
-    const float* w = p.whh1T + (int64_t)unit * 4 * D + 16 * tile + 4 * q;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) wa[t][g] = aload4(w + g * D);
+    for (int g = 0; g < 4; ++g) {
+      const float* w = p.w_hh1 + (int64_t)(g * D + 16 * tile + 4 * q) * D + unit;
+      wa[t][g] = make_float4(w[0], w[D], w[2 * D], w[3 * D]);
+    }
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int col = 16 * (half * 16 + 4 * wave + t) + r;                   // ctx column
-    const float* w = p.wih1T + (int64_t)(D + col) * 4 * D + 16 * tile + 4 * q;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) wc[t][g] = aload4(w + g * D);
+    for (int g = 0; g < 4; ++g) {
+      const float* w = p.w_ih1 + (int64_t)(g * D + 16 * tile + 4 * q) * (D + E) + D + col;
+      wc[t][g] = make_float4(w[0], w[D + E], w[2 * (D + E)], w[3 * (D + E)]);
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 2; ++k)      // W_phi term: A[m = unit][k = a], k-blocks 2 * wave + k
-    wp[k] = aload4(p.wphiT + (int64_t)(16 * tile + r) * A + 16 * (2 * wave + k) + 4 * q);
+  for (int k = 0; k < 2; ++k) {    // W_phi term: A[m = unit][k = a], k-blocks 2 * wave + k
+    const float* w = p.w_phi + (int64_t)(16 * (2 * wave + k) + 4 * q) * D + 16 * tile + r;
+    wp[k] = make_float4(w[0], w[D], w[2 * D], w[3 * D]);
+  }
 
   const bool epi = wave == 0 && col_ok;
   float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       sG[2 * 64 + lane] = dg;
       sG[3 * 64 + lane] = dov;
       if (epi && half == 0) {
-        float* g0 = p.gates1 + ((int64_t)t * B + n) * 4 * D + u0;
+        float* g0 = p.dg1 + ((int64_t)t * B + n) * 4 * D + u0;
         st4(g0, di);
         st4(g0 + D, df);
         st4(g0 + 2 * D, dg);

@@ -141,7 +141,8 @@ extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
   if (S <= 0 || N <= 0 || N > 128 || (H != 64 && H != 128 && H != 256)) return 0;
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int64_t gather = 2 * S * 4 * H * Np;
-  const int64_t ring = 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;
+  // (+ the two-step tail of a two-workgroups-per-tile launch, [2 dirs][2][N][4H])
+  const int64_t ring = 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256 + 2 * 2 * N * 4 * H;
   return gather > ring ? gather : ring;
 }
 
@@ -185,13 +186,16 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
     const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
     if (halves) pgrid.z *= 2;
+    p.tail = gx + ring;
+    // (a range shorter than the hand-off distance between the two halves could rewrite dc_state early)
+    if (halves && ranged && i1 < S && i1 - i0 < 4) return SSASR_EARG;
     // Placement: the weight-gradient GEMMs of the previous range / layer run beside this kernel on
     // the second stream.  A GEMM workgroup that shares a CU with a recurrence workgroup slows every
     // step of it (shared MFMA pipe, LDS and memory pipeline): 2.4 -> 3.3 us per step.  The launch
-    // therefore reserves dynamic LDS it never touches, so that its 23 KB + 132 KB leave no room for
+    // therefore reserves dynamic LDS it never touches, so that its 22-31 KB + 124 KB leave no room for
     // a GEMM workgroup (36 KB) on the same CU: the GEMMs get the other CUs, the recurrence runs at
     // its standalone speed (+4-5 % on the train step).  SSASR_BPTT_SHARED_CU=1 turns it off.
-    static const int reserve = getenv("SSASR_BPTT_SHARED_CU") ? 0 : 132 * 1024;
+    static const int reserve = getenv("SSASR_BPTT_SHARED_CU") ? 0 : 124 * 1024;
     static bool reserved = false;
     if (reserve && !reserved) {
       const void* fns[] = {reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<1, 1>),
@@ -207,6 +211,9 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, reserve, st, p);
     else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, reserve, st, p);
     else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, reserve, st, p);
+    if (halves)
+      hipLaunchKernelGGL(bptt_tail_copy_kernel, dim3(2, (unsigned)dirs), dim3(1024), 0, st, p.tail, gates, (int)S, (int)N,
+                         (int)H, (int)i0, (int)i1);
   } else if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
     SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(dirs * S * 4 * H * Np), st));
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
@@ -246,20 +253,30 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
   float* db[2] = {db_f, db_r};
   int rc;
 
-  for (int d = 0; d < 2; ++d) {
-    rc = ssasr_launch_transpose(whh[d], ws_whhT + d * 4 * H * H, (int)(4 * H), (int)H, st);
-    if (rc) return rc;
-  }
+  // the K-split persistent kernel reads W_hh as it is; every other form wants the transposed copy
+  const bool direct = gx && sync_ws && w_hh_f && w_hh_r && ssasr_bptt_ksplit_ok(S, N, H, 2);
+  bool transposed = false;
+  auto transpose_whh = [&]() -> int {
+    for (int d = 0; d < 2 && !transposed; ++d) {
+      const int r = ssasr_launch_transpose(whh[d], ws_whhT + d * 4 * H * H, (int)(4 * H), (int)H, st);
+      if (r) return r;
+    }
+    transposed = true;
+    return SSASR_OK;
+  };
+  if (!direct && (rc = transpose_whh())) return rc;
 
   // BPTT: one persistent launch when the grid is certain to be resident
   // (rnn_kernels.h, "persistent backward recurrence"), else one launch per step.
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31)) return SSASR_EARG;
   bool persistent = false;
   if (gx && sync_ws && !getenv("SSASR_NO_PERSISTENT")) {
-    rc = ssasr_launch_bptt_persistent(ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st);
+    rc = ssasr_launch_bptt_persistent(direct ? nullptr : ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H,
+                                      2, st, 0, 0, nullptr, direct ? w_hh_f : nullptr, direct ? w_hh_r : nullptr);
     if (rc == SSASR_OK) persistent = true;
     else if (rc != SSASR_EARG) return rc;
   }
+  if (!persistent && (rc = transpose_whh())) return rc;
   EncBwd e{};
   e.whhT = ws_whhT; e.gates = gates; e.cs = cs; e.dy = dy; e.dc = ws_dc; e.lens = lens;
   e.ys_s = (int)ys_s; e.ys_n = (int)ys_n; e.S = (int)S; e.N = (int)N; e.H = (int)H;

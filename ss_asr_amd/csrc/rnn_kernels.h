@@ -792,6 +792,7 @@ struct EncPersistBwd {
   int i0, i1;
   float* dc_state;
   const float* whh[2];   // K-split form: the untransposed [4H][H] weights per direction (whhT unused) or null
+  float* tail;           // K-split form with two workgroups per tile: [dir][2][N][4H], last two steps of the launch
 };
 
 template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
@@ -1098,9 +1099,21 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
 // HV = 2: two workgroups per (unit tile, chunk).  Both sum the same partial
 // tiles and run the same gate epilogue (duplicated, deterministic), but each
 // multiplies its gate derivatives into only half of the H units, which halves
-// the product on the critical path.  Only half 0 writes the row-major copy and
-// re-arms the ring, and it does so three steps late: by then every workgroup
-// has consumed data that was published after the other half consumed the slot.
+// the product on the critical path.  Only half 0 re-arms the ring, and it does
+// so three steps late: by then every workgroup has consumed data that was
+// published after the other half consumed the slot.
+//
+// The row-major gate derivatives overwrite the saved gates IN PLACE, and with
+// HV = 2 the other half still reads those saved gates (its helper wave fetches
+// the rows of step i + 2 during step i, and of steps i0, i0 + 1 when it starts,
+// which can be long after half 0 started when other kernels occupy the CUs).
+// Half 0 therefore writes the rows of step r during step r + 2, from a ring of
+// three steps in LDS: reaching step j proves that every workgroup of the group
+// has published step j - 2, and a workgroup publishes step j - 2 only after its
+// helper wave has turned the saved gates of steps <= j - 1 into coefficients.
+// The last two steps of a launch have no later step to prove that; they go to
+// `tail` ([dir][2][N][4H]) and bptt_tail_copy_kernel, launched behind this
+// kernel, moves them into place.
 template <int TPW, int HV>   // TPW = unit tiles per wave = (H / 16) / 4; grid.z = chunks * HV
 __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   if (SSASR_PERSIST_PRIO) __builtin_amdgcn_s_setprio(SSASR_PERSIST_PRIO);
@@ -1109,7 +1122,8 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   static_assert(TPW % HV == 0 && LAG + 2 <= BWD_RS_RING, "ring too short");
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
   __shared__ __attribute__((aligned(16))) float4 coef[2][7][64];   // [parity][A, O, I, G, F, C, dy][lane]
-  __shared__ __attribute__((aligned(16))) float4 sG[4][64];        // gate derivatives of this step: [gate][lane (q, r)]
+  constexpr int NG = HV >= 2 ? 3 : 1;           // steps of gate derivatives kept in LDS
+  __shared__ __attribute__((aligned(16))) float4 sG[NG][4][64];    // gate derivatives: [step % NG][gate][lane (q, r)]
   __shared__ int missed;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) missed = 0;
@@ -1171,7 +1185,24 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
         for (int j = 0; j < T; ++j)
           __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
       }
+      if (HV >= 2 && half == 0 && col_ok && i - 2 >= i0) {
+        // row-major copy of step i - 2 (see the note on in-place rows above)
+        const int sr = d ? i - 2 : S - 1 - (i - 2);
+        float* g0 = gbase + ((int64_t)sr * N + n) * 4 * H + u0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[(i - 2) % NG][g][lane]);
+      }
       __syncthreads();      // gate derivatives in LDS
+    }
+    if (HV >= 2 && half == 0 && col_ok) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int ir = i1 - 2 + k;
+        if (ir < i0) continue;
+        float* g0 = e.tail + (((int64_t)d * 2 + k) * N + n) * 4 * H + u0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[ir % NG][g][lane]);
+      }
     }
     return;
   }
@@ -1271,11 +1302,11 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
         dov = make_float4(rdo[0], rdo[1], rdo[2], rdo[3]);
         dcv = make_float4(rdc[0], rdc[1], rdc[2], rdc[3]);
       }
-      sG[0][lane] = di;
-      sG[1][lane] = df;
-      sG[2][lane] = dg;
-      sG[3][lane] = dov;
-      if (epi && half == 0) {          // row-major copy for the dX and weight-gradient GEMMs
+      sG[i % NG][0][lane] = di;
+      sG[i % NG][1][lane] = df;
+      sG[i % NG][2][lane] = dg;
+      sG[i % NG][3][lane] = dov;
+      if (HV == 1 && epi) {            // row-major copy for the dX and weight-gradient GEMMs
         const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
         st4(gbase + g0, di);
         st4(gbase + g0 + H, df);
@@ -1289,7 +1320,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       // partial dh tiles of all units from this workgroup's 64 gate-derivative rows
       float4 b[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) b[g] = sG[g][lane];
+      for (int g = 0; g < 4; ++g) b[g] = sG[i % NG][g][lane];
       // two accumulators per tile: with OT = 1 a single chain would wait on its own result
       f32x4 acc[OT], acc2[OT];
 #pragma unroll
@@ -1326,6 +1357,19 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
     }
   }
   if (epi && half == 0 && i1 < S && dcs) st4(dcs, dcv);
+}
+
+// Moves the gate derivatives of the last two steps of a two-workgroups-per-tile launch
+// (iterations i1 - 2 and i1 - 1, those not below i0) from `tail` into the row-major image.
+// grid (2 steps, dirs), any block size.
+__global__ void bptt_tail_copy_kernel(const float* tail, float* gates, int S, int N, int H, int i0, int i1) {
+  const int k = blockIdx.x, d = blockIdx.y;
+  const int ir = i1 - 2 + k;
+  if (ir < i0) return;
+  const int s = d ? ir : S - 1 - ir;
+  const float4* src = reinterpret_cast<const float4*>(tail + ((int64_t)d * 2 + k) * N * 4 * H);
+  float4* dst = reinterpret_cast<float4*>(gates + ((int64_t)d * S * N + (int64_t)s * N) * 4 * H);
+  for (int j = threadIdx.x; j < N * H; j += blockDim.x) dst[j] = src[j];
 }
 
 // out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:], plain store.  Used for the

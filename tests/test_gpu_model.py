@@ -264,3 +264,40 @@ def test_four_train_steps_follow_the_oracle_trajectory():
     got = dict(model.named_parameters())
     worst = max(float((got[k].detach().cpu() - v.detach()).abs().max()) for k, v in ref.named_parameters())
     assert worst < 5e-4, worst
+
+
+def test_backward_is_reproducible_with_overlapped_streams(golden):
+    """The recurrences have no atomics, so repeated backward passes over the same batch may
+    differ only by the summation order of the weight-gradient accumulations (~1e-6).  Larger
+    run-to-run differences mean a race between the persistent kernels and the work that
+    shares the GPU with them (weight-gradient GEMMs on the second stream delay workgroup
+    starts by microseconds, which once let one workgroup of a tile overwrite saved gates the
+    other still had to read)."""
+    from ss_asr_amd import ops
+    from ss_asr_amd.optim import FlatParameters
+    fx = golden('full_b16_t400')
+    model = build(fx)
+    flat = FlatParameters(model)
+    names = [n for n, _ in model.named_parameters()]
+    first = None
+    worst = (0.0, '')
+    for _ in range(25):
+        flat.zero_grad()
+        _, _, _, loss = forward(fx, model)
+        loss.backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        grads = [p.grad.detach().clone() for p in model.parameters()]
+        if first is None:
+            first = grads
+            top = max(float(g.abs().max()) for g in grads)
+            continue
+        for n, a, b in zip(names, grads, first):
+            scale = float(b.abs().max())
+            if scale < 1e-4 * top:
+                continue            # gradients that are zero up to rounding (the psi bias)
+            dev = float((a - b).abs().max()) / scale
+            if dev > worst[0]:
+                worst = (dev, n)
+    ops.check_persistent_status()
+    assert worst[0] < 5e-5, worst
