@@ -141,8 +141,7 @@ extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
   if (S <= 0 || N <= 0 || N > 128 || (H != 64 && H != 128 && H != 256)) return 0;
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int64_t gather = 2 * S * 4 * H * Np;
-  // (+ the two-step tail of a two-workgroups-per-tile launch, [2 dirs][2][N][4H])
-  const int64_t ring = 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256 + 2 * 2 * N * 4 * H;
+  const int64_t ring = 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;
   return gather > ring ? gather : ring;
 }
 
@@ -184,18 +183,19 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
     if (i0 == 0) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
-    const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
+    // (not for launches of fewer than three steps: see the note on in-place rows in rnn_kernels.h)
+    const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && i1 - i0 >= 3 &&
+                        getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
     if (halves) pgrid.z *= 2;
-    p.tail = gx + ring;
     // (a range shorter than the hand-off distance between the two halves could rewrite dc_state early)
     if (halves && ranged && i1 < S && i1 - i0 < 4) return SSASR_EARG;
     // Placement: the weight-gradient GEMMs of the previous range / layer run beside this kernel on
     // the second stream.  A GEMM workgroup that shares a CU with a recurrence workgroup slows every
     // step of it (shared MFMA pipe, LDS and memory pipeline): 2.4 -> 3.3 us per step.  The launch
-    // therefore reserves dynamic LDS it never touches, so that its 22-31 KB + 124 KB leave no room for
+    // therefore reserves dynamic LDS it never touches, so that its 30-38 KB + 118 KB leave no room for
     // a GEMM workgroup (36 KB) on the same CU: the GEMMs get the other CUs, the recurrence runs at
     // its standalone speed (+4-5 % on the train step).  SSASR_BPTT_SHARED_CU=1 turns it off.
-    static const int reserve = getenv("SSASR_BPTT_SHARED_CU") ? 0 : 124 * 1024;
+    static const int reserve = getenv("SSASR_BPTT_SHARED_CU") ? 0 : 118 * 1024;
     static bool reserved = false;
     if (reserve && !reserved) {
       const void* fns[] = {reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<1, 1>),
@@ -211,9 +211,6 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, reserve, st, p);
     else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, reserve, st, p);
     else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, reserve, st, p);
-    if (halves)
-      hipLaunchKernelGGL(bptt_tail_copy_kernel, dim3(2, (unsigned)dirs), dim3(1024), 0, st, p.tail, gates, (int)S, (int)N,
-                         (int)H, (int)i0, (int)i1);
   } else if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
     SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(dirs * S * 4 * H * Np), st));
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);

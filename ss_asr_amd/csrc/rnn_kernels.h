@@ -792,7 +792,6 @@ struct EncPersistBwd {
   int i0, i1;
   float* dc_state;
   const float* whh[2];   // K-split form: the untransposed [4H][H] weights per direction (whhT unused) or null
-  float* tail;           // K-split form with two workgroups per tile: [dir][2][N][4H], last two steps of the launch
 };
 
 template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
@@ -1104,16 +1103,17 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
 // published after the other half consumed the slot.
 //
 // The row-major gate derivatives overwrite the saved gates IN PLACE, and with
-// HV = 2 the other half still reads those saved gates (its helper wave fetches
-// the rows of step i + 2 during step i, and of steps i0, i0 + 1 when it starts,
-// which can be long after half 0 started when other kernels occupy the CUs).
-// Half 0 therefore writes the rows of step r during step r + 2, from a ring of
-// three steps in LDS: reaching step j proves that every workgroup of the group
-// has published step j - 2, and a workgroup publishes step j - 2 only after its
-// helper wave has turned the saved gates of steps <= j - 1 into coefficients.
-// The last two steps of a launch have no later step to prove that; they go to
-// `tail` ([dir][2][N][4H]) and bptt_tail_copy_kernel, launched behind this
-// kernel, moves them into place.
+// HV = 2 the other half still reads those saved gates, at its own pace (it may
+// start microseconds later when other kernels hold its CU).  The helper waves
+// therefore turn saved gates into coefficients TWO steps ahead (fetch of step
+// i + 3 and coefficients of step i + 2 during step i, a ring of three in LDS):
+// a workgroup that reaches step j has consumed data that every workgroup of the
+// group published in step j - 2, i.e. after their helper waves had finished with
+// the saved gates of steps <= j, so row j may be overwritten during step j.
+// Only the first two steps of a launch are not covered by that argument (the
+// other half may not have started): half 0 keeps their rows in LDS and writes
+// them during the third step.  A launch of fewer than three steps must not use
+// HV = 2 (the launcher falls back to HV = 1).
 template <int TPW, int HV>   // TPW = unit tiles per wave = (H / 16) / 4; grid.z = chunks * HV
 __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   if (SSASR_PERSIST_PRIO) __builtin_amdgcn_s_setprio(SSASR_PERSIST_PRIO);
@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   constexpr int LAG = HV >= 2 ? 3 : 1;          // steps between consuming a slot and re-arming it
   static_assert(TPW % HV == 0 && LAG + 2 <= BWD_RS_RING, "ring too short");
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
-  __shared__ __attribute__((aligned(16))) float4 coef[2][7][64];   // [parity][A, O, I, G, F, C, dy][lane]
+  __shared__ __attribute__((aligned(16))) float4 coef[3][7][64];   // [step % 3][A, O, I, G, F, C, dy][lane]
   constexpr int NG = HV >= 2 ? 3 : 1;           // steps of gate derivatives kept in LDS
   __shared__ __attribute__((aligned(16))) float4 sG[NG][4][64];    // gate derivatives: [step % NG][gate][lane (q, r)]
   __shared__ int missed;
@@ -1156,8 +1156,12 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
     auto live = [&](int i) { return (d ? i : S - 1 - i) < len; };
     if (col_ok) {
       sv.fetch(e, gbase, cbase, d, i0, n, u0);
-      sv.publish(&coef[i0 & 1][0][lane], live(i0));
-      if (i0 + 1 < S) sv.fetch(e, gbase, cbase, d, i0 + 1, n, u0);
+      sv.publish(&coef[i0 % 3][0][lane], live(i0));
+      if (i0 + 1 < S) {
+        sv.fetch(e, gbase, cbase, d, i0 + 1, n, u0);
+        sv.publish(&coef[(i0 + 1) % 3][0][lane], live(i0 + 1));
+      }
+      if (i0 + 2 < S) sv.fetch(e, gbase, cbase, d, i0 + 2, n, u0);
     }
     PersistPacer pacer{e.delay, 0};
     const u32x4 fill = {PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL};
@@ -1169,9 +1173,9 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();    // operand loads released
       }
-      if (col_ok && i + 1 < S) {
-        sv.publish(&coef[(i + 1) & 1][0][lane], live(i + 1));
-        if (i + 2 < S) sv.fetch(e, gbase, cbase, d, i + 2, n, u0);
+      if (col_ok && i + 2 < S) {
+        sv.publish(&coef[(i + 2) % 3][0][lane], live(i + 2));
+        if (i + 3 < S) sv.fetch(e, gbase, cbase, d, i + 3, n, u0);
       }
       __syncthreads();      // partial tiles summed per wave (red), loads verified
       if (i > i0) {
@@ -1185,24 +1189,17 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
         for (int j = 0; j < T; ++j)
           __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
       }
-      if (HV >= 2 && half == 0 && col_ok && i - 2 >= i0) {
-        // row-major copy of step i - 2 (see the note on in-place rows above)
-        const int sr = d ? i - 2 : S - 1 - (i - 2);
-        float* g0 = gbase + ((int64_t)sr * N + n) * 4 * H + u0;
+      if (HV >= 2 && half == 0 && col_ok && i == i0 + 2) {
+        // row-major copies of the launch's first two steps (see the note on in-place rows above)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[(i - 2) % NG][g][lane]);
+        for (int k = 0; k < 2; ++k) {
+          const int sr = d ? i0 + k : S - 1 - (i0 + k);
+          float* g0 = gbase + ((int64_t)sr * N + n) * 4 * H + u0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[(i0 + k) % NG][g][lane]);
+        }
       }
       __syncthreads();      // gate derivatives in LDS
-    }
-    if (HV >= 2 && half == 0 && col_ok) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int ir = i1 - 2 + k;
-        if (ir < i0) continue;
-        float* g0 = e.tail + (((int64_t)d * 2 + k) * N + n) * 4 * H + u0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[ir % NG][g][lane]);
-      }
     }
     return;
   }
@@ -1275,7 +1272,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 di = z4, df = z4, dg = z4, dov = z4;
       if (epi) {
-        const float4* c = &coef[i & 1][0][lane];
+        const float4* c = &coef[i % 3][0][lane];
         const float4 cA = c[0 * 64], cO = c[1 * 64], cI = c[2 * 64], cG = c[3 * 64], cF = c[4 * 64],
                      cC = c[5 * 64], ad1 = c[6 * 64];
         f32x4 dhv = red[lane];
@@ -1306,7 +1303,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       sG[i % NG][1][lane] = df;
       sG[i % NG][2][lane] = dg;
       sG[i % NG][3][lane] = dov;
-      if (HV == 1 && epi) {            // row-major copy for the dX and weight-gradient GEMMs
+      if (epi && half == 0 && (HV == 1 || i >= i0 + 2)) {   // row-major copy for the dX and weight-gradient GEMMs
         const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
         st4(gbase + g0, di);
         st4(gbase + g0 + H, df);
@@ -1357,19 +1354,6 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
     }
   }
   if (epi && half == 0 && i1 < S && dcs) st4(dcs, dcv);
-}
-
-// Moves the gate derivatives of the last two steps of a two-workgroups-per-tile launch
-// (iterations i1 - 2 and i1 - 1, those not below i0) from `tail` into the row-major image.
-// grid (2 steps, dirs), any block size.
-__global__ void bptt_tail_copy_kernel(const float* tail, float* gates, int S, int N, int H, int i0, int i1) {
-  const int k = blockIdx.x, d = blockIdx.y;
-  const int ir = i1 - 2 + k;
-  if (ir < i0) return;
-  const int s = d ? ir : S - 1 - ir;
-  const float4* src = reinterpret_cast<const float4*>(tail + ((int64_t)d * 2 + k) * N * 4 * H);
-  float4* dst = reinterpret_cast<float4*>(gates + ((int64_t)d * S * N + (int64_t)s * N) * 4 * H);
-  for (int j = threadIdx.x; j < N * H; j += blockDim.x) dst[j] = src[j];
 }
 
 // out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:], plain store.  Used for the
