@@ -179,6 +179,8 @@ typedef struct ssasr_decoder {
   float* ws_qx;                          /* [U][A/16][32][16]                    */
   int32_t* ws_modes;                     /* device int32[U]                      */
   int32_t* ws_sync;                      /* int32[8]; [5] != 0 reports a timeout */
+  int32_t modes_ready;                   /* != 0: ws_modes already holds step_mode (the caller
+                                          * uploaded it with its other per-step integers)   */
 } ssasr_decoder;
 
 int ssasr_decoder_fwd(const ssasr_decoder* d, void* stream);
@@ -228,24 +230,28 @@ int ssasr_decoder_bwd(const ssasr_decoder* d, const ssasr_decoder_grads* g, void
  * critical path of the backward pass.  accumulate = 0 overwrites the outputs, 1 adds. */
 int ssasr_decoder_wgrad(const ssasr_decoder* d, const ssasr_decoder_grads* g, int accumulate, void* stream);
 
-/* Masked cross entropy of src/trainer.py:426-434.  logits [B][U][V]; labels
- * int32 [B][U] (0 = ignore); denom [B] = count(y != 0) per row as float.
- * loss is one float; lse [B][U] is saved for backward. */
-int ssasr_ce_loss_fwd(const float* logits, const int32_t* labels, const float* denom, int64_t B,
+/* Masked cross entropy of src/trainer.py:426-434 on the label matrix itself.
+ * logits [B][U][V]; y int32 [B][y_cols] with row stride y_ld (0 = padding):
+ * the label of step t is y[b][t + 1] (src/trainer.py:427, the <sos> column is
+ * skipped) and a row's denominator is count(y[b][:] != 0) (src/trainer.py:431).
+ * loss is one float; lse (B * U + 2 * B floats: log-sum-exp per step, then the
+ * per-row terms, then the denominators) is saved for backward. */
+int ssasr_ce_loss_fwd(const float* logits, const int32_t* y, int64_t y_ld, int64_t y_cols, int64_t B,
                       int64_t U, int64_t V, float* lse, float* loss, void* stream);
-int ssasr_ce_loss_bwd(const float* logits, const int32_t* labels, const float* denom,
-                      const float* lse, const float* dloss, int64_t B, int64_t U, int64_t V,
-                      float* dlogits, void* stream);
+int ssasr_ce_loss_bwd(const float* logits, const int32_t* y, int64_t y_ld, const float* lse,
+                      const float* dloss, int64_t B, int64_t U, int64_t V, float* dlogits, void* stream);
 
 /* Solver.step (src/trainer.py:131-148) with torch.optim.Adadelta
  * (src/trainer.py:401-403) on flat buffers of n floats: total L2 norm of
  * grad * grad_scale, NaN guard, clip to max_norm, Adadelta update.
  * stats: float[2] = {grad_norm, skipped (1 if the norm was NaN)}.
- * ws: float[1 + blocks] scratch, blocks = ssasr_clip_adadelta_ws(n) - 1. */
+ * ws: float[1 + blocks] scratch, blocks = ssasr_clip_adadelta_ws(n) - 1.
+ * zero_grad != 0 leaves grad zeroed (the next step's optimizer.zero_grad(),
+ * src/trainer.py:419, without a pass of its own). */
 int64_t ssasr_clip_adadelta_ws(int64_t n);
 int ssasr_clip_adadelta(float* param, const float* grad, float* square_avg, float* acc_delta,
                         int64_t n, float grad_scale, float max_norm, float lr, float rho,
-                        float eps, float* ws, float* stats, void* stream);
+                        float eps, float* ws, float* stats, int zero_grad, void* stream);
 
 /* Frame lengths of zero-padded fbanks, prepare_x (src/ASRDataset.py:314):
  * lens[b] = number of frames whose feature sum is non-zero. */

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -29,7 +29,8 @@ class Decoder(C.Structure):
          ('logits', P), ('att', P),
          ('w_phi_t', P), ('q', P), ('ctx', P), ('emb_in', P), ('chars', P),
          ('gates1', P), ('c1', P), ('h1', P), ('gates2', P), ('c2', P), ('h2', P),
-         ('ws_hx1', P), ('ws_hx2', P), ('ws_qx', P), ('ws_modes', P), ('ws_sync', P)])
+         ('ws_hx1', P), ('ws_hx2', P), ('ws_qx', P), ('ws_modes', P), ('ws_sync', P),
+         ('modes_ready', C.c_int32)])
 
 
 class DecoderGrads(C.Structure):
@@ -61,10 +62,10 @@ SIGNATURES = {
     'ssasr_decoder_fwd': (I32, [C.POINTER(Decoder), P]),
     'ssasr_decoder_bwd': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), P]),
     'ssasr_decoder_wgrad': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), I32, P]),
-    'ssasr_ce_loss_fwd': (I32, [P, P, P, I64, I64, I64, P, P, P]),
-    'ssasr_ce_loss_bwd': (I32, [P, P, P, P, P, I64, I64, I64, P, P]),
+    'ssasr_ce_loss_fwd': (I32, [P, P, I64, I64, I64, I64, I64, P, P, P]),
+    'ssasr_ce_loss_bwd': (I32, [P, P, I64, P, P, I64, I64, I64, P, P]),
     'ssasr_clip_adadelta_ws': (I64, [I64]),
-    'ssasr_clip_adadelta': (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, P, P, P]),
+    'ssasr_clip_adadelta': (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, P, P, I32, P]),
     'ssasr_bilstm_bwd_gx_floats': (I64, [I64, I64, I64]),
     'ssasr_decoder_bwd_chain_floats': (I64, [I64] * 6),
     'ssasr_frame_lengths': (I32, [P, I64, I64, I64, P, P]),

@@ -102,14 +102,23 @@ class Listener(nn.Module):
     def get_outdim(self):
         return self.out_dim
 
-    def forward(self, x, state_len, pack_input=True):
-        len_dev = None
-        if pack_input:
-            len_dev = _dev_i32(state_len, x.device)
-        for layer in (self.blstm_1, self.blstm_2, self.blstm_3):
-            x, _, state_len = layer(x, state_len=state_len, pack_input=pack_input, len_dev=len_dev)
-            if len_dev is not None:
-                len_dev = torch.div(len_dev, 2, rounding_mode='floor').to(torch.int32)
+    @staticmethod
+    def layer_lengths(state_len):
+        """Frame counts seen by blstm_1..3 and by the decoder (each pBLSTM halves them,
+        src/asr.py:425)."""
+        out = [[int(s) for s in state_len]]
+        for _ in range(3):
+            out.append([int(s / 2) for s in out[-1]])
+        return out
+
+    def forward(self, x, state_len, pack_input=True, len_devs=None):
+        """len_devs: the first three lists of layer_lengths(state_len) as int32 device
+        tensors when the caller has uploaded them already."""
+        if pack_input and len_devs is None:
+            len_devs = ops.upload_i32(x.device, *self.layer_lengths(state_len)[:3])
+        for k, layer in enumerate((self.blstm_1, self.blstm_2, self.blstm_3)):
+            x, _, state_len = layer(x, state_len=state_len, pack_input=pack_input,
+                                    len_dev=len_devs[k] if pack_input else None)
         x = ops.bilstm(x, None, x.shape[0], False, _lstm_weights(self.blstm_4))   # src/asr.py:262
         return x, state_len
 
@@ -121,14 +130,43 @@ class Speller(nn.Module):
         super().__init__()
         self.layer_1 = nn.LSTMCell(input_size=encoder_out_size + state_size, hidden_size=state_size)
         self.layer_2 = nn.LSTMCell(input_size=state_size, hidden_size=state_size)
-        self.state_list = []
-        self.cell_list = []
+        self._zero_state = None
+        self._state_list = []
+        self._cell_list = []
         self.state_size = state_size
         self.num_layers = 2
 
     def init_rnn(self, batch_size, device):
-        self.state_list = [torch.zeros(batch_size, self.state_size, device=device)] * self.num_layers
-        self.cell_list = [torch.zeros(batch_size, self.state_size, device=device)] * self.num_layers
+        """Zero states (src/asr.py:284-290).  Allocated on first use: the fused decode loop
+        never reads them, only step-by-step callers do."""
+        self._zero_state = (batch_size, device)
+        self._state_list = self._cell_list = None
+
+    def _materialise(self):
+        if self._state_list is None and self._zero_state is not None:
+            b, dev = self._zero_state
+            self._state_list = [torch.zeros(b, self.state_size, device=dev)] * self.num_layers
+            self._cell_list = [torch.zeros(b, self.state_size, device=dev)] * self.num_layers
+
+    @property
+    def state_list(self):
+        self._materialise()
+        return self._state_list
+
+    @state_list.setter
+    def state_list(self, v):
+        self._materialise()
+        self._state_list = v
+
+    @property
+    def cell_list(self):
+        self._materialise()
+        return self._cell_list
+
+    @cell_list.setter
+    def cell_list(self, v):
+        self._materialise()
+        self._cell_list = v
 
     @property
     def hidden_state(self):
@@ -193,6 +231,8 @@ class ASR(nn.Module):
         # or self.att_event.synchronize() before reading it.  eval() mode
         # always returns a finished copy.
         self.async_att = True
+        # False: the attention map stays on the device (ASRTrainStep sets this around a train step)
+        self.att_on_host = True
         self.att_event = None
         self.last_chars = None
         self.init_parameters()
@@ -223,30 +263,34 @@ class ASR(nn.Module):
     def forward(self, audio_feature, decode_step, teacher=None, state_len=None):
         """Returns (encode_len: list[int], logits [B,U,V] on the device,
         attention [B,U,T'] on the host, detached) -- src/asr.py:52-110."""
-        encode_feature, encode_len = self.encoder(audio_feature, state_len)
-        dev = encode_feature.device
-        enc_len_dev = _dev_i32(encode_len, dev)
+        dev = audio_feature.device
+        # One host coin flip per step, as the reference draws them (src/asr.py:94).
+        if teacher is not None:
+            modes = [0 if random.random() <= self.tf_rate else 1 for _ in range(decode_step)]
+            teacher_i32 = ops.as_i32(teacher)
+        else:
+            modes = [2] * decode_step
+            teacher_i32 = None
+        # every per-step integer the device needs, in one upload
+        lens = Listener.layer_lengths(state_len)
+        l1, l2, l3, enc_len_dev, modes_dev = ops.upload_i32(dev, lens[0], lens[1], lens[2], lens[3], modes)
+        encode_feature, encode_len = self.encoder(audio_feature, state_len, len_devs=(l1, l2, l3))
         self.decoder.init_rnn(encode_feature.shape[0], dev)
         self.attention.reset_enc_mem()
         comp = ops.attn_precompute(encode_feature, self.attention.psi.weight,
                                    self.attention.psi.bias)
-
-        # One host coin flip per step, as the reference draws them (src/asr.py:94).
-        if teacher is not None:
-            modes = [0 if random.random() <= self.tf_rate else 1 for _ in range(decode_step)]
-            teacher_i32 = teacher.to(torch.int32)
-        else:
-            modes = [2] * decode_step
-            teacher_i32 = None
         uniforms = None
         if 1 in modes:
             # Categorical(...).sample() of the reference (src/asr.py:97): one
             # uniform per (step, utterance), inverse-CDF draw inside the kernel.
             uniforms = torch.rand(decode_step, encode_feature.shape[0], device=dev)
         logits, att, chars = ops.decoder_loop(encode_feature, comp, enc_len_dev, teacher_i32,
-                                              modes, uniforms, self._decoder_params())
+                                              modes, uniforms, self._decoder_params(),
+                                              modes_dev=modes_dev if decode_step else None)
         self.last_chars = chars
-        if self.training and self.async_att:
+        if not self.att_on_host:
+            host = att.detach()         # left on the device (train steps never look at it)
+        elif self.training and self.async_att:
             host = torch.empty(att.shape, dtype=att.dtype, pin_memory=True)
             host.copy_(att.detach(), non_blocking=True)
             self.att_event = torch.cuda.Event()

@@ -15,7 +15,7 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 5; }
+extern "C" int ssasr_abi_version(void) { return 6; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
@@ -168,7 +168,6 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   if (any_teacher && (!d.teacher || d.teacher_ld < U + 1)) return SSASR_EARG;
   if (any_sample && !d.uniforms) return SSASR_EARG;
 
-  if ((rc = ssasr_launch_transpose(d.w_phi, d.w_phi_t, (int)A, (int)D, st))) return rc;   // for backward
   SSASR_HIP(hipMemsetAsync(d.q, 0, sizeof(float) * B * A, st));                            // q_0 = 0
 
   // chars[0] = <sos> = 0 (src/asr.py:73); chars[t] = teacher[:, t] (src/asr.py:95).
@@ -185,7 +184,8 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
                           E == PD_E && D == PD_D && B <= 32 && T <= 128 && V <= 64 &&
                           !getenv("SSASR_NO_PERSISTENT") && !getenv("SSASR_NO_PERSISTENT_DECODER");
   const bool sentinel = persistent && getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
-  if (persistent) SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
+  if (persistent && !d.modes_ready)
+    SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
   // (self-verifying loop: rows the loop itself produces start as the fill pattern)
   hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)((U + 1) * B)), dim3(64), 0, st, d.embed, d.chars,
                      d.emb_in, (U + 1) * B, (int)D, sentinel ? d.ws_modes : nullptr, (int)B, (int)U);
@@ -347,6 +347,7 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   const bool chain = cell2_first && g.ws_chain && ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D) > 0 &&
                      !getenv("SSASR_NO_PERSISTENT_DECODER_BWD");
   if (!chain) {
+    if ((rc = ssasr_launch_transpose(d.w_phi, d.w_phi_t, (int)A, (int)D, st))) return rc;
     if ((rc = ssasr_launch_transpose(d.w_ih1, g.ws_t_ih1, (int)(4 * D), (int)(D + E), st))) return rc;
     if ((rc = ssasr_launch_transpose(d.w_hh1, g.ws_t_hh1, (int)(4 * D), (int)D, st))) return rc;
   }

@@ -8,11 +8,15 @@ namespace {
 
 // One workgroup per utterance, one wave per (b, t) row of V logits.
 // lse[b*U+t] = logsumexp(row); tail[b] = sum_t tok(b,t) / denom[b].
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const int32_t* labels,
-                                                     const float* denom, int U, int V, float* lse,
-                                                     float* tail) {
+// One block per utterance: log-sum-exp of every step, the row's summed token loss and its
+// denominator count(y != 0).  Labels are read in place: step t's label is y[b][t + 1].
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const int32_t* y, int64_t y_ld,
+                                                     int y_cols, int U, int V, float* lse, float* tail,
+                                                     float* denom) {
   __shared__ float sm[4];
+  __shared__ int sn[4];
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int32_t* yr = y + (int64_t)b * y_ld;
   float tok = 0.f;
   for (int t = wave; t < U; t += 4) {
     const float* row = logits + ((int64_t)b * U + t) * V;
@@ -23,15 +27,23 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const 
     for (int v = lane; v < V; v += 64) s += expf(row[v] - m);
     s = wave_sum(s);
     const float l = m + logf(s);
-    const int lab = labels[(int64_t)b * U + t];
+    const int lab = t + 1 < y_cols ? yr[t + 1] : 0;
     if (lane == 0) {
       lse[(int64_t)b * U + t] = l;
       if (lab != 0) tok += l - row[lab];
     }
   }
-  if (lane == 0) sm[wave] = tok;
+  int cnt = 0;
+  for (int j = threadIdx.x; j < y_cols; j += 256) cnt += yr[j] != 0 ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0) { sm[wave] = tok; sn[wave] = cnt; }
   __syncthreads();
-  if (threadIdx.x == 0) tail[b] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / denom[b];
+  if (threadIdx.x == 0) {
+    const float dn = (float)((sn[0] + sn[1]) + (sn[2] + sn[3]));
+    denom[b] = dn;
+    tail[b] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / dn;
+  }
 }
 
 __global__ void ce_mean_kernel(const float* tail, int B, float* loss) {
@@ -42,7 +54,7 @@ __global__ void ce_mean_kernel(const float* tail, int B, float* loss) {
   }
 }
 
-__global__ void ce_bwd_kernel(const float* logits, const int32_t* labels, const float* denom,
+__global__ void ce_bwd_kernel(const float* logits, const int32_t* y, int64_t y_ld, const float* denom,
                               const float* lse, const float* dloss, int B, int U, int V,
                               float* dlogits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,7 +63,8 @@ __global__ void ce_bwd_kernel(const float* logits, const int32_t* labels, const 
   const int64_t row = i / V;
   const int v = (int)(i - row * V);
   const int b = (int)(row / U);
-  const int lab = labels[row];
+  const int t = (int)(row - (int64_t)b * U);
+  const int lab = y[(int64_t)b * y_ld + t + 1];
   float g = 0.f;
   if (lab != 0) {
     const float p = expf(logits[i] - lse[row]);
@@ -115,11 +128,15 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(float* ws, int nblk, flo
 // torch.optim.Adadelta single-tensor update (weight_decay = 0).
 __global__ __launch_bounds__(256) void adadelta_kernel(float* p, const float* g, float* sq, float* ad,
                                                        int64_t n, const float* ws, const float* stats,
-                                                       float lr, float rho, float eps) {
-  if (stats[1] != 0.f) return;                        // NaN guard: skip the step
-  const float mul = ws[0];
+                                                       float lr, float rho, float eps, float* zero) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (stats[1] != 0.f) {                              // NaN guard: skip the step
+    if (zero)
+      for (int64_t j = i; j < n; j += stride) zero[j] = 0.f;
+    return;
+  }
+  const float mul = ws[0];
   for (int64_t j = i; j < n; j += stride) {
     const float gr = g[j] * mul;
     const float s = sq[j] * rho + gr * gr * (1.f - rho);
@@ -128,6 +145,7 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* p, const float* g,
     sq[j] = s;
     ad[j] = a * rho + delta * delta * (1.f - rho);
     p[j] -= lr * delta;
+    if (zero) zero[j] = 0.f;                          // zero == g: the next step's zero_grad()
   }
 }
 
@@ -173,26 +191,25 @@ extern "C" int ssasr_gather_batch(const float* frames, const int64_t* offsets, c
   return SSASR_OK;
 }
 
-extern "C" int ssasr_ce_loss_fwd(const float* logits, const int32_t* labels, const float* denom,
-                                 int64_t B, int64_t U, int64_t V, float* lse, float* loss,
-                                 void* stream) {
-  if (!logits || !labels || !denom || !lse || !loss || B <= 0 || U <= 0 || V <= 0) return SSASR_EARG;
+extern "C" int ssasr_ce_loss_fwd(const float* logits, const int32_t* y, int64_t y_ld, int64_t y_cols,
+                                 int64_t B, int64_t U, int64_t V, float* lse, float* loss, void* stream) {
+  if (!logits || !y || !lse || !loss || B <= 0 || U <= 0 || V <= 0 || y_cols < U + 1 || y_ld < y_cols)
+    return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
-  // lse holds B*U values followed by B per-utterance partial losses.
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, st, logits, labels, denom, (int)U, (int)V,
-                     lse, lse + B * U);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, st, logits, y, y_ld, (int)y_cols, (int)U, (int)V,
+                     lse, lse + B * U, lse + B * U + B);
   hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, st, lse + B * U, (int)B, loss);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
 
-extern "C" int ssasr_ce_loss_bwd(const float* logits, const int32_t* labels, const float* denom,
-                                 const float* lse, const float* dloss, int64_t B, int64_t U,
-                                 int64_t V, float* dlogits, void* stream) {
-  if (!logits || !labels || !denom || !lse || !dloss || !dlogits || B <= 0 || U <= 0 || V <= 0) return SSASR_EARG;
+extern "C" int ssasr_ce_loss_bwd(const float* logits, const int32_t* y, int64_t y_ld, const float* lse,
+                                 const float* dloss, int64_t B, int64_t U, int64_t V, float* dlogits,
+                                 void* stream) {
+  if (!logits || !y || !lse || !dloss || !dlogits || B <= 0 || U <= 0 || V <= 0 || y_ld < U + 1) return SSASR_EARG;
   const int64_t n = B * U * V;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits,
-                     labels, denom, lse, dloss, (int)B, (int)U, (int)V, dlogits);
+                     y, y_ld, lse + B * U + B, lse, dloss, (int)B, (int)U, (int)V, dlogits);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
@@ -204,7 +221,7 @@ extern "C" int64_t ssasr_clip_adadelta_ws(int64_t n) {
 extern "C" int ssasr_clip_adadelta(float* param, const float* grad, float* square_avg,
                                    float* acc_delta, int64_t n, float grad_scale, float max_norm,
                                    float lr, float rho, float eps, float* ws, float* stats,
-                                   void* stream) {
+                                   int zero_grad, void* stream) {
   if (!param || !grad || !square_avg || !acc_delta || !ws || !stats || n <= 0) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (int)((n + NORM_PER_BLOCK - 1) / NORM_PER_BLOCK);
@@ -213,7 +230,7 @@ extern "C" int ssasr_clip_adadelta(float* param, const float* grad, float* squar
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adadelta_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, square_avg, acc_delta,
-                     n, ws, stats, lr, rho, eps);
+                     n, ws, stats, lr, rho, eps, zero_grad ? const_cast<float*>(grad) : nullptr);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }

@@ -21,6 +21,8 @@ class ASRTrainStep:
         # gradient all-reduce in two buckets, the large one overlapped with the last layer's BPTT
         self.reducer = sdist.GradReducer(self.flat, list(model.encoder.blstm_1.parameters()))
         ops.set_wgrad_listener(self.reducer.wgrad_enqueued)
+        self._one = torch.ones((), device=self.flat.data.device)
+        self._grads_clean = False      # True right after a step that zeroed them in its update kernel
 
     def forward_loss(self, x, y, x_lens, ans_len):
         _, logits, att = self.model(x, ans_len, teacher=y, state_len=x_lens)
@@ -30,12 +32,20 @@ class ASRTrainStep:
         """x [B,T,F] float32, y [B,L] int64 (both on the GPU), x_lens host list
         (descending), ans_len = max label length - 1.  Returns the loss tensor
         (on the device; reading it synchronises)."""
-        self.optim.zero_grad()
+        if not self._grads_clean:
+            self.optim.zero_grad()
+        self._grads_clean = False
         self.reducer.begin()
-        loss, _, _ = self.forward_loss(x, y, x_lens, ans_len)
-        loss.backward()
+        # the attention map is only looked at by valid(): no device-to-host copy per train step
+        keep, self.model.att_on_host = getattr(self.model, 'att_on_host', True), False
+        try:
+            loss, _, _ = self.forward_loss(x, y, x_lens, ans_len)
+        finally:
+            self.model.att_on_host = keep
+        loss.backward(self._one)
         scale = self.reducer.finish()
-        self.optim.clip_and_step(self.grad_clip, grad_scale=scale)
+        self.optim.clip_and_step(self.grad_clip, grad_scale=scale, zero_grad=True)
+        self._grads_clean = True
         return loss
 
 

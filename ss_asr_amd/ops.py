@@ -72,6 +72,23 @@ def join_side_stream():
         torch.cuda.current_stream().wait_stream(_side)
 
 
+def upload_i32(device, *seqs):
+    """Host integer sequences -> int32 device tensors, all through ONE pinned staging buffer
+    and one asynchronous copy (a copy from pageable memory waits for the stream to drain;
+    one copy per sequence costs a dispatch each).  Returns one tensor per sequence."""
+    flat = [int(v) for s in seqs for v in s]
+    t = torch.tensor(flat, dtype=torch.int32)
+    if torch.device(device).type == 'cuda':
+        t = t.pin_memory().to(device, non_blocking=True)
+    else:
+        t = t.to(device)
+    out, o = [], 0
+    for s in seqs:
+        out.append(t[o:o + len(s)])
+        o += len(s)
+    return out
+
+
 _wgrad_listener = None
 
 
@@ -384,7 +401,7 @@ _DEC_PARAMS = ('w_phi', 'w_ih1', 'w_hh1', 'b_ih1', 'b_hh1', 'w_ih2', 'w_hh2', 'b
 
 class _DecoderLoop(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, comp, enc_len, teacher, step_mode, uniforms, sinks, *params):
+    def forward(ctx, feat, comp, enc_len, teacher, step_mode, uniforms, sinks, modes_dev, *params):
         lib = _lib.load()
         ctx.sinks = sinks
         _need_gpu(feat, comp, enc_len, *params)
@@ -408,7 +425,8 @@ class _DecoderLoop(torch.autograd.Function):
             img = f(U * (2 * (D // 4) * 32 * 4 + (A // 16) * 32 * 16))
             nh = U * (D // 4) * 32 * 4
             bufs.update(ws_hx1=img[:nh], ws_hx2=img[nh:2 * nh], ws_qx=img[2 * nh:],
-                        ws_modes=torch.empty(U, device=dev, dtype=torch.int32),
+                        ws_modes=modes_dev if modes_dev is not None else
+                        torch.empty(U, device=dev, dtype=torch.int32),
                         ws_sync=_status_words(dev))
             _track_status(bufs['ws_sync'], 5)
         modes = (C.c_int32 * U)(*[int(m) for m in step_mode])
@@ -419,6 +437,7 @@ class _DecoderLoop(torch.autograd.Function):
             teacher = teacher.contiguous()
             d.teacher, d.teacher_ld = teacher.data_ptr(), teacher.stride(0)
         d.step_mode = C.cast(modes, C.c_void_p)
+        d.modes_ready = 1 if modes_dev is not None else 0
         if uniforms is not None:
             d.uniforms = uniforms.data_ptr()
         for k, t in pw.items():
@@ -484,23 +503,26 @@ class _DecoderLoop(torch.autograd.Function):
             for t in list(bufs.values()) + list(ws.values()) + [dlogits]:
                 t.record_stream(side)
             _notify_wgrad(sinks)
-            return (out['dfeat'], out['dcomp']) + (None,) * 17
+            return (out['dfeat'], out['dcomp']) + (None,) * 18
         o = out
-        return (o['dfeat'], o['dcomp'], None, None, None, None, None,
+        return (o['dfeat'], o['dcomp'], None, None, None, None, None, None,
                 o['dw_phi'], o['dw_ih1'], o['dw_hh1'], o['db1'], o['db1'].clone(),
                 o['dw_ih2'], o['dw_hh2'], o['db2'], o['db2'].clone(),
                 o['dembed'], o['dw_ct'], o['db_ct'])
 
 
-def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params):
+def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params, modes_dev=None):
     """The decode loop of ASR.forward (src/asr.py:67-110).
 
-    step_mode: host sequence of U ints (0 teacher forced, 1 sample, 2 argmax).
+    step_mode: host sequence of U ints (0 teacher forced, 1 sample, 2 argmax);
+    modes_dev: the same values as an int32 device tensor when the caller has already
+    uploaded them (with its other per-step integers), else None.
     teacher: int32 [B, L] device tensor of character ids or None.
     params: dict with the keys of ``_DEC_PARAMS``.
     Returns (logits [B,U,V], att [B,U,T] (no grad), chars [U+1,B] int32)."""
     plist = [params[k] for k in _DEC_PARAMS]
-    return _DecoderLoop.apply(feat, comp, enc_len, teacher, list(step_mode), uniforms, _grad_sinks(plist), *plist)
+    return _DecoderLoop.apply(feat, comp, enc_len, teacher, list(step_mode), uniforms, _grad_sinks(plist),
+                              modes_dev, *plist)
 
 
 # ---------------------------------------------------------------------------
@@ -508,37 +530,51 @@ def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params):
 # ---------------------------------------------------------------------------
 class _CELoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, denom):
+    def forward(ctx, logits, y32):
         lib = _lib.load()
-        _need_gpu(logits, labels, denom)
+        _need_gpu(logits, y32)
         logits = _f32c(logits)
         B, U, V = logits.shape
-        lse = torch.empty(B * U + B, device=logits.device, dtype=torch.float32)
+        lse = torch.empty(B * U + 2 * B, device=logits.device, dtype=torch.float32)
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
-        check(lib.ssasr_ce_loss_fwd(_p(logits), _p(labels), _p(denom), B, U, V, _p(lse), _p(loss),
-                                    _stream()), 'ssasr_ce_loss_fwd')
-        ctx.save_for_backward(logits, labels, denom, lse)
+        check(lib.ssasr_ce_loss_fwd(_p(logits), _p(y32), y32.stride(0), y32.shape[1], B, U, V, _p(lse),
+                                    _p(loss), _stream()), 'ssasr_ce_loss_fwd')
+        ctx.save_for_backward(logits, y32, lse)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         lib = _lib.load()
-        logits, labels, denom, lse = ctx.saved_tensors
+        logits, y32, lse = ctx.saved_tensors
         B, U, V = logits.shape
         dloss = dloss.to(torch.float32).contiguous()
         dlogits = torch.empty_like(logits)
-        check(lib.ssasr_ce_loss_bwd(_p(logits), _p(labels), _p(denom), _p(lse), _p(dloss), B, U, V,
+        check(lib.ssasr_ce_loss_bwd(_p(logits), _p(y32), y32.stride(0), _p(lse), _p(dloss), B, U, V,
                                     _p(dlogits), _stream()), 'ssasr_ce_loss_bwd')
-        return dlogits, None, None
+        return dlogits, None
+
+
+_i32_cache = (None, None)
+
+
+def as_i32(t):
+    """int32 copy of an integer device tensor, remembered for the tensor it was made from: the
+    label matrix of a step is needed twice (teacher forcing and the loss)."""
+    global _i32_cache
+    if t.dtype == torch.int32 and t.stride(-1) == 1:
+        return t
+    key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+    if _i32_cache[0] != key:
+        _i32_cache = (key, t.to(torch.int32).contiguous())
+    return _i32_cache[1]
 
 
 def masked_ce_loss(logits, y, ans_len):
-    """src/trainer.py:426-434.  logits [B,U,V] (U >= ans_len), y [B,L] int."""
-    label = y[:, 1:ans_len + 1].to(torch.int32).contiguous()
-    denom = (y != 0).sum(-1).to(torch.float32)
+    """src/trainer.py:426-434.  logits [B,U,V] (U >= ans_len), y [B,L] int, L > ans_len: the
+    labels are y[:, 1:ans_len + 1], read in place; rows are normalised by count(y != 0)."""
     if logits.shape[1] != ans_len:
         logits = logits[:, :ans_len].contiguous()
-    return _CELoss.apply(logits, label, denom)
+    return _CELoss.apply(logits, as_i32(y))
 
 
 # ---------------------------------------------------------------------------
@@ -568,13 +604,13 @@ def gather_batch(frames, offsets, lens, T):
 
 
 def clip_adadelta_(param, grad, square_avg, acc_delta, ws, stats, grad_scale=1.0, max_norm=5.0,
-                   lr=1.0, rho=0.9, eps=1e-8):
+                   lr=1.0, rho=0.9, eps=1e-8, zero_grad=False):
     """Solver.step on flat buffers (src/trainer.py:131-148).  stats <- [norm, skipped]."""
     lib = _lib.load()
     _need_gpu(param, grad, square_avg, acc_delta, ws, stats)
     check(lib.ssasr_clip_adadelta(_p(param), _p(grad), _p(square_avg), _p(acc_delta), param.numel(),
                                   grad_scale, float(max_norm), lr, rho, eps, _p(ws), _p(stats),
-                                  _stream()), 'ssasr_clip_adadelta')
+                                  1 if zero_grad else 0, _stream()), 'ssasr_clip_adadelta')
 
 
 def clip_adadelta_ws(n, device):

@@ -67,12 +67,14 @@ class FusedAdadelta(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
-    def clip_and_step(self, max_norm=5.0, grad_scale=1.0):
+    def clip_and_step(self, max_norm=5.0, grad_scale=1.0, zero_grad=False):
+        """zero_grad=True leaves the flat gradient zeroed (the next step's zero_grad()
+        folded into the update kernel)."""
         ops.join_side_stream()       # weight gradients enqueued on the side stream
         g = self.param_groups[0]
         ops.clip_adadelta_(self.flat.data, self.flat.grad, self.square_avg, self.acc_delta,
                            self._ws, self.stats, grad_scale=grad_scale, max_norm=max_norm,
-                           lr=g['lr'], rho=g['rho'], eps=g['eps'])
+                           lr=g['lr'], rho=g['rho'], eps=g['eps'], zero_grad=zero_grad)
         # the norm / NaN flag reach the host asynchronously; see poll()
         self._host_stats.copy_(self.stats, non_blocking=True)
         self._pending = torch.cuda.Event()
