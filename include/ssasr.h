@@ -125,6 +125,11 @@ int ssasr_attn_precompute_fwd(const float* feat, const float* w_psi, const float
 int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const float* feat,
                               const float* w_psi, int64_t rows, int64_t E, int64_t A, float* dfeat,
                               float* dw_psi, float* db_psi, void* stream);
+/* The psi weight gradients alone, from the pre-activation derivative that
+ * ssasr_attn_precompute_bwd left in dcomp: dW_psi (+)= dpre^T feat, db_psi (+)= column sums.
+ * accumulate = 1 adds into the outputs (optimizer-owned gradient buffers, any stream). */
+int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat, int64_t rows, int64_t E, int64_t A,
+                                float* dw_psi, float* db_psi, int accumulate, void* stream);
 
 /* One Attention.forward call after the cache exists (src/asr.py:383-390).
  * state [B][D], w_phi [A][D] (phi.weight), comp [B][T][A], feat [B][T][E],

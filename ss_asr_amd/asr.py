@@ -277,16 +277,16 @@ class ASR(nn.Module):
         encode_feature, encode_len = self.encoder(audio_feature, state_len, len_devs=(l1, l2, l3))
         self.decoder.init_rnn(encode_feature.shape[0], dev)
         self.attention.reset_enc_mem()
-        comp = ops.attn_precompute(encode_feature, self.attention.psi.weight,
-                                   self.attention.psi.bias)
         uniforms = None
         if 1 in modes:
             # Categorical(...).sample() of the reference (src/asr.py:97): one
             # uniform per (step, utterance), inverse-CDF draw inside the kernel.
             uniforms = torch.rand(decode_step, encode_feature.shape[0], device=dev)
-        logits, att, chars = ops.decoder_loop(encode_feature, comp, enc_len_dev, teacher_i32,
+        # (the cached projection tanh(psi(h)) of src/asr.py:381 is computed inside the loop's node)
+        logits, att, chars = ops.decoder_loop(encode_feature, None, enc_len_dev, teacher_i32,
                                               modes, uniforms, self._decoder_params(),
-                                              modes_dev=modes_dev if decode_step else None)
+                                              modes_dev=modes_dev if decode_step else None,
+                                              psi=(self.attention.psi.weight, self.attention.psi.bias))
         self.last_chars = chars
         if not self.att_on_host:
             host = att.detach()         # left on the device (train steps never look at it)

@@ -15,7 +15,7 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 6; }
+extern "C" int ssasr_abi_version(void) { return 7; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
@@ -62,14 +62,27 @@ extern "C" int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const 
     g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.batch = 1;
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
+  if (dw_psi || db_psi) return ssasr_attn_precompute_wgrad(dcomp, feat, rows, E, A, dw_psi, db_psi, 0, stream);
+  return SSASR_OK;
+}
+
+// dW_psi (+)= dpre^T . feat, db_psi (+)= column sums of dpre (dpre: what ssasr_attn_precompute_bwd
+// left in dcomp).  accumulate = 1 adds into the outputs: may run on another stream, straight
+// into optimizer-owned gradient buffers.
+extern "C" int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat, int64_t rows, int64_t E,
+                                           int64_t A, float* dw_psi, float* db_psi, int accumulate,
+                                           void* stream) {
+  if (!dcomp || !feat || rows <= 0 || E <= 0 || A <= 0) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
   if (dw_psi) {  // dW_psi = dpre^T . feat
-    SSASR_HIP(hipMemsetAsync(dw_psi, 0, sizeof(float) * A * E, st));
+    if (!accumulate) SSASR_HIP(hipMemsetAsync(dw_psi, 0, sizeof(float) * A * E, st));
     GemmDesc g{};
     g.A = dcomp; g.ma = rm_dense(A);
     g.B = feat; g.mb = rm_dense(E);
     g.C = dw_psi; g.mc = rm_dense(E);
     g.M = (int)A; g.N = (int)E; g.K = (int)rows;
-    g.ta = 1; g.tb = 1; g.alpha = 1.f; g.batch = 1;
+    g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
     {      // 16 output tiles only: split K until the chip is full (was one 56 us launch of 16 workgroups)
       int sk = (int)(rows / 128);
       g.splitk = sk < 1 ? 1 : (sk > 16 ? 16 : sk);
@@ -77,7 +90,7 @@ extern "C" int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const 
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   if (db_psi) {
-    SSASR_HIP(hipMemsetAsync(db_psi, 0, sizeof(float) * A, st));
+    if (!accumulate) SSASR_HIP(hipMemsetAsync(db_psi, 0, sizeof(float) * A, st));
     if ((rc = ssasr_launch_colsum(dcomp, rows, (int)A, A, db_psi, st))) return rc;
   }
   return SSASR_OK;

@@ -404,13 +404,26 @@ class _DecoderLoop(torch.autograd.Function):
     def forward(ctx, feat, comp, enc_len, teacher, step_mode, uniforms, sinks, modes_dev, *params):
         lib = _lib.load()
         ctx.sinks = sinks
-        _need_gpu(feat, comp, enc_len, *params)
-        feat, comp = _f32c(feat), _f32c(comp)
+        ctx.set_materialize_grads(False)      # no zero tensors for the att / chars outputs
+        _need_gpu(feat, enc_len, *params)
+        feat = _f32c(feat)
         params = [_f32c(t) for t in params]
         pw = dict(zip(_DEC_PARAMS, params))
         dev = feat.device
         B, T, E = feat.shape
         A, D = pw['w_phi'].shape
+        ctx.psi = len(params) == len(_DEC_PARAMS) + 2
+        if ctx.psi:
+            # comp = tanh(psi(feat)) (src/asr.py:381) belongs to this node: its backward then
+            # adds into the decoder's dfeat and into the flat gradients instead of going
+            # through three autograd accumulations
+            w_psi, b_psi = params[-2:]
+            comp = torch.empty(B, T, A, device=dev, dtype=torch.float32)
+            check(lib.ssasr_attn_precompute_fwd(_p(feat), _p(w_psi), _p(b_psi), B * T, E, A, _p(comp),
+                                                _stream()), 'ssasr_attn_precompute_fwd')
+        else:
+            _need_gpu(comp)
+            comp = _f32c(comp)
         V = pw['w_ct'].shape[0]
         U = len(step_mode)
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
@@ -453,6 +466,8 @@ class _DecoderLoop(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits, _datt, _dchars):
         lib = _lib.load()
+        if dlogits is None:
+            raise RuntimeError('decoder_loop: no gradient reached the logits')
         d = ctx.dec
         feat, comp, enc_len, teacher, modes, uniforms, params, bufs = ctx.keep
         pw = dict(zip(_DEC_PARAMS, params))
@@ -493,6 +508,18 @@ class _DecoderLoop(torch.autograd.Function):
             g.db1_2, g.db2_2 = sk['b_hh1'].data_ptr(), sk['b_hh2'].data_ptr()
             g.defer_wgrad = 1
         check(lib.ssasr_decoder_bwd(C.byref(d), C.byref(g), _stream()), 'ssasr_decoder_bwd')
+        dpsi = ()
+        if ctx.psi:
+            # dcomp -> d(pre-activation) in place, dfeat += dpre . W_psi; the psi weight gradients
+            # are left to the weight-gradient pass below
+            w_psi = params[-2]
+            check(lib.ssasr_attn_precompute_bwd(_p(out['dcomp']), _p(comp), _p(feat), _p(w_psi), B * T, E, A,
+                                                _p(out['dfeat']), None, None, _stream()),
+                  'ssasr_attn_precompute_bwd')
+            if sinks is None:
+                dpsi = (f(A, E), f(A))
+                check(lib.ssasr_attn_precompute_wgrad(_p(out['dcomp']), _p(feat), B * T, E, A, _p(dpsi[0]),
+                                                      _p(dpsi[1]), 0, _stream()), 'ssasr_attn_precompute_wgrad')
         if sinks is not None:
             main = torch.cuda.current_stream()
             side = side_stream()
@@ -500,27 +527,36 @@ class _DecoderLoop(torch.autograd.Function):
             with torch.cuda.stream(side):
                 check(lib.ssasr_decoder_wgrad(C.byref(d), C.byref(g), 1, C.c_void_p(side.cuda_stream)),
                       'ssasr_decoder_wgrad')
-            for t in list(bufs.values()) + list(ws.values()) + [dlogits]:
+                if ctx.psi:
+                    check(lib.ssasr_attn_precompute_wgrad(_p(out['dcomp']), _p(feat), B * T, E, A, _p(sinks[-2]),
+                                                          _p(sinks[-1]), 1, C.c_void_p(side.cuda_stream)),
+                          'ssasr_attn_precompute_wgrad')
+            for t in list(bufs.values()) + list(ws.values()) + [dlogits, out['dcomp'], feat]:
                 t.record_stream(side)
             _notify_wgrad(sinks)
-            return (out['dfeat'], out['dcomp']) + (None,) * 18
+            return (out['dfeat'], None if ctx.psi else out['dcomp']) + (None,) * (6 + len(params))
         o = out
-        return (o['dfeat'], o['dcomp'], None, None, None, None, None, None,
+        return (o['dfeat'], None if ctx.psi else o['dcomp'], None, None, None, None, None, None,
                 o['dw_phi'], o['dw_ih1'], o['dw_hh1'], o['db1'], o['db1'].clone(),
                 o['dw_ih2'], o['dw_hh2'], o['db2'], o['db2'].clone(),
-                o['dembed'], o['dw_ct'], o['db_ct'])
+                o['dembed'], o['dw_ct'], o['db_ct']) + dpsi
 
 
-def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params, modes_dev=None):
+def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params, modes_dev=None, psi=None):
     """The decode loop of ASR.forward (src/asr.py:67-110).
 
     step_mode: host sequence of U ints (0 teacher forced, 1 sample, 2 argmax);
     modes_dev: the same values as an int32 device tensor when the caller has already
     uploaded them (with its other per-step integers), else None.
+    psi: (weight, bias) of Attention.psi with comp=None: the projection comp = tanh(psi(feat))
+    (src/asr.py:381) is then computed and differentiated inside this node.
     teacher: int32 [B, L] device tensor of character ids or None.
     params: dict with the keys of ``_DEC_PARAMS``.
     Returns (logits [B,U,V], att [B,U,T] (no grad), chars [U+1,B] int32)."""
     plist = [params[k] for k in _DEC_PARAMS]
+    if psi is not None:
+        assert comp is None
+        plist += list(psi)
     return _DecoderLoop.apply(feat, comp, enc_len, teacher, list(step_mode), uniforms, _grad_sinks(plist),
                               modes_dev, *plist)
 
