@@ -69,6 +69,19 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
  * workspace (contents irrelevant on entry), sync_ws int32[8] zero on entry; NULL = one
  * launch per step. */
 int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);
+/* Floats of the K-split BPTT's exchange ring alone (dirs = 1 or 2 directions), 0 when the
+ * shape or the environment does not take that form.  A caller that arms several exchange
+ * workspaces with one fill (ssasr_exchange_armed) reserves this instead of gx_floats. */
+int64_t ssasr_bilstm_bwd_ring_floats(int64_t S, int64_t N, int64_t H, int64_t dirs);
+
+/* One-shot declaration about the NEXT call made on this thread: armed != 0 says that the
+ * exchange workspaces that call receives (hx of ssasr_bilstm_fwd; the ring in gx of
+ * ssasr_bilstm_bwd[_overlapped]; ws_hx1.. and ctx of ssasr_decoder_fwd; the ring in ws_gx and
+ * all of ws_chain of ssasr_decoder_bwd) already hold the fill pattern 0x7FC0DEAD, written on
+ * the same stream, so the call skips its own fill.  Lets a caller arm the workspaces of a
+ * whole pass with one fill (a dependent launch costs ~6 us however small).  The call
+ * consumes the declaration.  Only valid for the sentinel exchange (the default). */
+int ssasr_exchange_armed(int armed);
 int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
                      int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H, const int32_t* lens,
                      const float* w_ih_f, const float* w_hh_f, const float* w_ih_r,

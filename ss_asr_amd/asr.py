@@ -57,7 +57,7 @@ class pBLSTM(nn.Module):
         super().__init__()
         self.layer = nn.LSTM(in_dim, out_dim, bidirectional=True, batch_first=True)
 
-    def forward(self, input_x, state=None, state_len=None, pack_input=False, len_dev=None):
+    def forward(self, input_x, state=None, state_len=None, pack_input=False, len_dev=None, slots=None):
         if state is not None:
             raise NotImplementedError('initial states are always zero on the hot path')
         if pack_input:
@@ -70,7 +70,7 @@ class pBLSTM(nn.Module):
                 len_dev = _dev_i32(state_len, input_x.device)
         else:
             steps, len_dev = input_x.shape[1], None
-        output = ops.bilstm(input_x, len_dev, steps, True, _lstm_weights(self.layer))
+        output = ops.bilstm(input_x, len_dev, steps, True, _lstm_weights(self.layer), slots=slots)
         output = self.downsample(output)
         if state_len is not None:
             return output, None, [int(s / 2) for s in state_len]
@@ -111,15 +111,26 @@ class Listener(nn.Module):
             out.append([int(s / 2) for s in out[-1]])
         return out
 
-    def forward(self, x, state_len, pack_input=True, len_devs=None):
+    def forward(self, x, state_len, pack_input=True, len_devs=None, arenas=None):
         """len_devs: the first three lists of layer_lengths(state_len) as int32 device
-        tensors when the caller has uploaded them already."""
+        tensors when the caller has uploaded them already.  arenas: (forward, backward)
+        ops.ExchangeArena of this pass; the four layers' exchange workspaces are reserved in
+        them so that one fill arms all of them."""
         if pack_input and len_devs is None:
             len_devs = ops.upload_i32(x.device, *self.layer_lengths(state_len)[:3])
+        slots = [None] * 4
+        if arenas is not None and pack_input:
+            lens = self.layer_lengths(state_len)
+            B, H = x.shape[0], self.state_size
+            shapes = [(lens[0][0], B), (lens[1][0], B), (lens[2][0], B), (B, lens[3][0])]   # (steps, columns)
+            for k, (S, N) in enumerate(shapes):
+                hx, ring = ops.bilstm_exchange_floats(S, N, H)
+                slots[k] = (arenas[0], arenas[0].reserve(hx) if hx else None,
+                            arenas[1], arenas[1].reserve(ring) if ring else None)
         for k, layer in enumerate((self.blstm_1, self.blstm_2, self.blstm_3)):
             x, _, state_len = layer(x, state_len=state_len, pack_input=pack_input,
-                                    len_dev=len_devs[k] if pack_input else None)
-        x = ops.bilstm(x, None, x.shape[0], False, _lstm_weights(self.blstm_4))   # src/asr.py:262
+                                    len_dev=len_devs[k] if pack_input else None, slots=slots[k])
+        x = ops.bilstm(x, None, x.shape[0], False, _lstm_weights(self.blstm_4), slots=slots[3])   # src/asr.py:262
         return x, state_len
 
 
@@ -274,7 +285,12 @@ class ASR(nn.Module):
         # every per-step integer the device needs, in one upload
         lens = Listener.layer_lengths(state_len)
         l1, l2, l3, enc_len_dev, modes_dev = ops.upload_i32(dev, lens[0], lens[1], lens[2], lens[3], modes)
-        encode_feature, encode_len = self.encoder(audio_feature, state_len, len_devs=(l1, l2, l3))
+        # exchange workspaces of the whole pass: two allocations, each armed by one fill
+        arenas = (ops.ExchangeArena(dev), ops.ExchangeArena(dev))
+        dec_slots = ops.decoder_reserve(arenas[0], arenas[1], audio_feature.shape[0], lens[3][0], decode_step,
+                                        A=self.attention.phi.weight.shape[0], E=self.encoder.out_dim,
+                                        D=self.decoder.state_size, V=self.char_trans.weight.shape[0])
+        encode_feature, encode_len = self.encoder(audio_feature, state_len, len_devs=(l1, l2, l3), arenas=arenas)
         self.decoder.init_rnn(encode_feature.shape[0], dev)
         self.attention.reset_enc_mem()
         uniforms = None
@@ -286,7 +302,8 @@ class ASR(nn.Module):
         logits, att, chars = ops.decoder_loop(encode_feature, None, enc_len_dev, teacher_i32,
                                               modes, uniforms, self._decoder_params(),
                                               modes_dev=modes_dev if decode_step else None,
-                                              psi=(self.attention.psi.weight, self.attention.psi.bias))
+                                              psi=(self.attention.psi.weight, self.attention.psi.bias),
+                                              slots=dec_slots)
         self.last_chars = chars
         if not self.att_on_host:
             host = att.detach()         # left on the device (train steps never look at it)

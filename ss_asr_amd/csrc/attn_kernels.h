@@ -489,28 +489,25 @@ __global__ __launch_bounds__(256) void char_select_kernel(CharSelect p) {
   for (int k = tid; k < p.D; k += 256) p.emb_next[(int64_t)b * p.D + k] = er[k];
 }
 
-// chars[t][b] = t ? teacher[b][t] : 0 for t in [0, U]  (teacher may be null)
-__global__ void teacher_chars_kernel(const int32_t* teacher, int64_t ld, int32_t* chars, int B, int U1) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * U1) return;
-  const int t = i / B, b = i - t * B;
-  chars[i] = (t && teacher) ? teacher[(int64_t)b * ld + t] : 0;
-}
-
-// out[row][:] = table[idx[row]][:].  With `modes` (device int32[U], rows = (U + 1) * B in step-major
-// order): the rows of step t + 1 after a step t that is not teacher forced (modes[t] != 0) are
-// produced later, by the persistent decode loop, and start as its fill pattern instead.
-__global__ void embed_gather_kernel(const float* table, const int32_t* idx, float* out, int64_t rows, int D,
-                                    const int32_t* modes, int B, int U) {
+// The characters fed to the decode steps and their embeddings in one pass, rows = (U + 1) * B in
+// step-major order: chars[t][b] = t ? teacher[b][t] : 0 (<sos>; teacher may be null) and
+// out[row][:] = table[chars[row]][:].  With `modes` (device int32[U]): the rows of step t + 1
+// after a step t that is not teacher forced (modes[t] != 0) are produced later, by the
+// persistent decode loop, and start as its fill pattern instead.
+__global__ void embed_chars_kernel(const float* table, const int32_t* teacher, int64_t ld, int32_t* chars,
+                                   float* out, int64_t rows, int D, const int32_t* modes, int B, int U) {
   const int64_t row = blockIdx.x;
   if (row >= rows) return;
-  const int64_t t = modes ? row / B : 0;
+  const int64_t t = row / B;
+  const int b = (int)(row - t * B);
+  const int ch = (t && teacher) ? teacher[(int64_t)b * ld + t] : 0;
+  if (threadIdx.x == 0) chars[row] = ch;
   if (modes && t >= 1 && t < U && modes[t - 1] != 0) {
     const float fill = __builtin_bit_cast(float, 0x7FC0DEADu);      // PERSIST_SENTINEL (rnn_kernels.h)
     for (int k = threadIdx.x; k < D; k += blockDim.x) out[row * D + k] = fill;
     return;
   }
-  const float* src = table + (int64_t)idx[row] * D;
+  const float* src = table + (int64_t)ch * D;
   for (int k = threadIdx.x; k < D; k += blockDim.x) out[row * D + k] = src[k];
 }
 

@@ -88,12 +88,17 @@ int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hip
 // gates [dirs][S*N][4H] activated gates in / gate derivatives out, whhT [dirs][H][4H],
 // dy[s * ys_s + n * ys_n + d * H + u], gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats.
 // Returns SSASR_EARG when the shape has no persistent form.
+// armed: gx already holds the fill pattern (no fill here).
 // i0 / i1 / dc_state: iterations [i0, i1) of the S steps (K-split form only; i1 = 0 means S);
 // successive launches over one layer carry the recurrence through gx and dc_state [dirs][N][H].
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0 = 0, int64_t i1 = 0,
-                                 float* dc_state = nullptr, const float* whh_f = nullptr, const float* whh_r = nullptr);
+                                 float* dc_state = nullptr, const float* whh_f = nullptr, const float* whh_r = nullptr,
+                                 bool armed = false);
+// ssasr_exchange_armed (include/ssasr.h): reads and clears the caller's declaration that the exchange
+// workspaces of the call in progress already hold the fill pattern.
+bool ssasr_take_armed();
 // true when the shape takes the K-split persistent form (which supports iteration ranges)
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs);
 extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);

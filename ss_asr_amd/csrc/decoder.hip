@@ -15,7 +15,7 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 7; }
+extern "C" int ssasr_abi_version(void) { return 8; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
@@ -163,6 +163,7 @@ extern "C" int ssasr_attn_step_bwd(const float* dctx, const float* datt, const f
 
 // ------------------------------ decode loop --------------------------------
 extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
+  const bool armed = ssasr_take_armed();
   if (!dp) return SSASR_EARG;
   const ssasr_decoder& d = *dp;
   const int64_t B = d.B, T = d.T, E = d.E, A = d.A, D = d.D, V = d.V, U = d.U;
@@ -181,15 +182,9 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   if (any_teacher && (!d.teacher || d.teacher_ld < U + 1)) return SSASR_EARG;
   if (any_sample && !d.uniforms) return SSASR_EARG;
 
-  SSASR_HIP(hipMemsetAsync(d.q, 0, sizeof(float) * B * A, st));                            // q_0 = 0
 
   // chars[0] = <sos> = 0 (src/asr.py:73); chars[t] = teacher[:, t] (src/asr.py:95).
   // Steps that are not teacher forced overwrite their successor's entry in the loop.
-  {
-    const int n = (int)(B * (U + 1));
-    hipLaunchKernelGGL(teacher_chars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d.teacher,
-                       d.teacher_ld, d.chars, (int)B, (int)(U + 1));
-  }
   // Embeddings of every known input character in one gather; rows of sampled
   // steps are overwritten inside the loop.
   // Single persistent launch for the production sizes (decoder_persistent.h).
@@ -200,8 +195,9 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   if (persistent && !d.modes_ready)
     SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
   // (self-verifying loop: rows the loop itself produces start as the fill pattern)
-  hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)((U + 1) * B)), dim3(64), 0, st, d.embed, d.chars,
-                     d.emb_in, (U + 1) * B, (int)D, sentinel ? d.ws_modes : nullptr, (int)B, (int)U);
+  hipLaunchKernelGGL(embed_chars_kernel, dim3((unsigned)((U + 1) * B)), dim3(64), 0, st, d.embed, d.teacher,
+                     d.teacher_ld, d.chars, d.emb_in, (U + 1) * B, (int)D, sentinel ? d.ws_modes : nullptr, (int)B,
+                     (int)U);
   SSASR_LAUNCH_CHECK();
 
   if (d.ws_sync && getenv("SSASR_PERSISTENT_COUNTER")) SSASR_HIP(hipMemsetAsync(d.ws_sync, 0, 5 * sizeof(int32_t), st));
@@ -221,14 +217,20 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
       // self-verifying hand-offs: every exchanged buffer starts as the fill pattern (one fill
       // when the caller laid the three exchange images out back to back)
       const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4, img_q = (size_t)(PD_A / 16) * PD_BP * 16;   // floats per step
-      if (d.ws_hx2 == d.ws_hx1 + img_h * U && d.ws_qx == d.ws_hx2 + img_h * U) {
-        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, (2 * img_h + img_q) * U, st));
+      const size_t n_ctx = (size_t)(U * B * E);
+      bool ctx_filled = false;
+      if (armed) {
+        ctx_filled = true;          // the caller armed the images and the context rows
+      } else if (d.ws_hx2 == d.ws_hx1 + img_h * U && d.ws_qx == d.ws_hx2 + img_h * U) {
+        ctx_filled = d.ctx == d.ws_qx + img_q * U;         // ... and the context rows behind them
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL,
+                                    (2 * img_h + img_q) * U + (ctx_filled ? n_ctx : 0), st));
       } else {
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, img_h * U, st));
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx2, (int)PERSIST_SENTINEL, img_h * U, st));
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_qx, (int)PERSIST_SENTINEL, img_q * U, st));
       }
-      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ctx, (int)PERSIST_SENTINEL, (size_t)(U * B * E), st));
+      if (!ctx_filled) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ctx, (int)PERSIST_SENTINEL, n_ctx, st));
       SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(decoder_fwd_persistent_kernel<true>, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
@@ -241,6 +243,8 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   }
   const int nch = attn_pick_nch((int)E);
   dim3 cgrid = cell_fwd_grid(D, 1, B), cblock(256);
+  // q_0 = 0 (the persistent loop writes every q_t itself)
+  if (!persistent) SSASR_HIP(hipMemsetAsync(d.q, 0, sizeof(float) * B * A, st));
   for (int64_t t = 0; t < U && !persistent; ++t) {
     // q_t = tanh(phi(h1_{t-1})); the state is zero at t = 0 and phi has no bias
     if (t) launch_phi(d.h1 + (t - 1) * B * D, d.w_phi, d.q + t * B * A, B, A, D, st);
@@ -326,6 +330,7 @@ int gemm_tn_acc(const float* A, RowMap ma, const float* B, RowMap mb, float* C, 
 }  // namespace
 
 extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_grads* gp, void* stream) {
+  const bool armed = ssasr_take_armed();
   if (!dp || !gp) return SSASR_EARG;
   const ssasr_decoder& d = *dp;
   const ssasr_decoder_grads& g = *gp;
@@ -378,7 +383,7 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   if (cell2_first) {
     if ((rc = ssasr_launch_bptt_persistent(cell2_direct ? nullptr : g.ws_t_hh2, d.gates2, d.c2, g.ws_dh2, B * D, D,
                                            nullptr, g.ws_gx, g.ws_sync, U, B, D, 1, st, 0, 0, nullptr,
-                                           cell2_direct ? d.w_hh2 : nullptr, nullptr)))
+                                           cell2_direct ? d.w_hh2 : nullptr, nullptr, armed && cell2_direct)))
       return rc;
     GemmDesc m{};
     m.A = d.gates2; m.ma = rm_dense(4 * D);
@@ -410,8 +415,9 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
       m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = (int)B;
       if ((rc = ssasr_launch_gemm(m, st))) return rc;
     }
-    SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)xa, (int)PERSIST_SENTINEL,
-                                chain_xa_floats(U) + chain_xc_floats(U) + chain_xu_floats(U, B), st));
+    if (!armed)
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)xa, (int)PERSIST_SENTINEL,
+                                  chain_xa_floats(U) + chain_xc_floats(U) + chain_xu_floats(U, B), st));
     DecBwdChain c{};
     c.gates1 = d.gates1; c.dg1 = dg1; c.c1 = d.c1; c.add1 = g.ws_dh2; c.att = d.att; c.q = d.q; c.feat = d.feat;
     c.comp = d.comp; c.enc_len = d.enc_len; c.V = wsV; c.w_hh1 = d.w_hh1; c.w_ih1 = d.w_ih1;
@@ -423,7 +429,8 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(decoder_bwd_chain_kernel, dim3(CB_NATTWG + 64), dim3(320), lds, st, c);
     hipLaunchKernelGGL(chain_de_fixup_kernel, dim3(256), dim3(256), 0, st, g.ws_de, d.att, wsS, (int)B, (int)U, (int)T,
-                       reinterpret_cast<float4*>(d.gates1), reinterpret_cast<const float4*>(dg1), U * B * D);
+                       reinterpret_cast<float4*>(d.gates1), reinterpret_cast<const float4*>(dg1), U * B * D,
+                       g.ws_dqpre, (int)(B * A));
     SSASR_LAUNCH_CHECK();
   }
   for (int64_t t = U - 1; t >= 0 && !chain; --t) {
@@ -491,9 +498,11 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     }
   }
   SSASR_LAUNCH_CHECK();
-  // step 0 contributes nothing through the energies
-  SSASR_HIP(hipMemset2DAsync(g.ws_de, sizeof(float) * U * T, 0, sizeof(float) * T, B, st));
-  SSASR_HIP(hipMemsetAsync(g.ws_dqpre, 0, sizeof(float) * B * A, st));
+  // step 0 contributes nothing through the energies (the chain's fix-up kernel has done this)
+  if (!chain) {
+    SSASR_HIP(hipMemset2DAsync(g.ws_de, sizeof(float) * U * T, 0, sizeof(float) * T, B, st));
+    SSASR_HIP(hipMemsetAsync(g.ws_dqpre, 0, sizeof(float) * B * A, st));
+  }
 
   // ---- products over all steps ----
   {   // dfeat[b] = att[b]^T . dctx[:, b, :]        [T][E] per utterance

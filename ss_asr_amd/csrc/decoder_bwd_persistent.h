@@ -73,16 +73,18 @@ inline size_t chain_lds_bytes(int T) {
 }
 
 // de[b][t][tau] -= att[b][t][tau] * s[t][b]   (t >= 1);  gates1 <- dg1 (the chain kernel must not
-// overwrite the saved gates itself: the two workgroups of a tile both read them, at their own pace)
+// overwrite the saved gates itself: the two workgroups of a tile both read them, at their own pace);
+// step 0 contributes nothing through the energies: de[b][0][:] = 0, dqpre[0] = 0 (nq floats).
 __global__ void chain_de_fixup_kernel(float* de, const float* att, const float* ssum, int B, int U, int T,
-                                      float4* gates1, const float4* dg1, int64_t ng4) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ng4; i += (int64_t)gridDim.x * blockDim.x)
-    gates1[i] = dg1[i];
+                                      float4* gates1, const float4* dg1, int64_t ng4, float* dqpre0, int nq) {
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = tid; i < ng4; i += nth) gates1[i] = dg1[i];
+  for (int64_t i = tid; i < nq; i += nth) dqpre0[i] = 0.f;
   const int64_t n = (int64_t)B * U * T;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = tid; i < n; i += nth) {
     const int64_t b = i / ((int64_t)U * T);
     const int64_t t = (i / T) % U;
-    if (t > 0) de[i] -= att[i] * ssum[t * B + b];
+    de[i] = t > 0 ? de[i] - att[i] * ssum[t * B + b] : 0.f;
   }
 }
 

@@ -25,6 +25,18 @@ int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, floa
   return SSASR_OK;
 }
 
+// ssasr_exchange_armed (include/ssasr.h): a one-shot declaration about the next call
+static thread_local int g_exchange_armed = 0;
+extern "C" int ssasr_exchange_armed(int armed) {
+  g_exchange_armed = armed;
+  return SSASR_OK;
+}
+bool ssasr_take_armed() {
+  const bool a = g_exchange_armed != 0;
+  g_exchange_armed = 0;
+  return a;
+}
+
 // Initial pacing delay of a persistent recurrence (PersistPacer, rnn_kernels.h),
 // in units of 64 cycles; the kernel adapts it from there.
 static int persist_delay(const char* env, int dflt) {
@@ -44,6 +56,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
                                 const float* b_ih_r, const float* b_hh_r, float* y, int64_t ys_s,
                                 int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
                                 int32_t* sync_ws, void* stream) {
+  const bool armed = ssasr_take_armed();
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
   if (!x || !y || !gates || !cs || !hs) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
@@ -97,7 +110,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
       // exchange by sentinel (default) or by arrival counter (SSASR_PERSISTENT_COUNTER=1, for A/B)
       const bool sentinel = getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
-      if (sentinel)
+      if (sentinel && !armed)
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * Np * H), st));
 #define SSASR_FWD_LAUNCH(K, SEN, NBT) \
       hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<K, SEN, NBT>), pgrid, pblock, 0, st, p)
@@ -145,6 +158,13 @@ extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
   return gather > ring ? gather : ring;
 }
 
+// Floats of the K-split form's ring alone, 0 when the shape (or the environment) does not take
+// that form: what a caller that arms several exchange workspaces with one fill has to reserve.
+extern "C" int64_t ssasr_bilstm_bwd_ring_floats(int64_t S, int64_t N, int64_t H, int64_t dirs) {
+  if (dirs < 1 || dirs > 2 || !ssasr_bptt_ksplit_ok(S, N, H, (int)dirs)) return 0;
+  return dirs * ((N + 15) / 16) * BWD_RS_RING * (H / 16) * (H / 16) * 256;
+}
+
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
   const int64_t chunks = (N + 15) / 16;
   return S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 &&
@@ -155,7 +175,7 @@ bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0, int64_t i1,
-                                 float* dc_state, const float* whh_f, const float* whh_r) {
+                                 float* dc_state, const float* whh_f, const float* whh_r, bool armed) {
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int kpw = (int)(H / 16);
   const bool ksplit = getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr;
@@ -181,7 +201,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
     const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
     p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
-    if (i0 == 0) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
+    if (i0 == 0 && !armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
     // (not for launches of fewer than three steps: see the note on in-place rows in rnn_kernels.h)
     const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && i1 - i0 >= 3 &&
@@ -227,7 +247,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
 
 // Backward of the layer.  `gates` is consumed: on return it holds the gate
 // pre-activation derivatives.  dw_* / db_* are overwritten.
-extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
+static int bilstm_bwd_impl(bool armed, const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
                                 int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
                                 int64_t H, const int32_t* lens, const float* w_ih_f,
                                 const float* w_hh_f, const float* w_ih_r, const float* w_hh_r,
@@ -269,7 +289,8 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
   bool persistent = false;
   if (gx && sync_ws && !getenv("SSASR_NO_PERSISTENT")) {
     rc = ssasr_launch_bptt_persistent(direct ? nullptr : ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H,
-                                      2, st, 0, 0, nullptr, direct ? w_hh_f : nullptr, direct ? w_hh_r : nullptr);
+                                      2, st, 0, 0, nullptr, direct ? w_hh_f : nullptr, direct ? w_hh_r : nullptr,
+                                      armed && direct);
     if (rc == SSASR_OK) persistent = true;
     else if (rc != SSASR_EARG) return rc;
   }
@@ -297,6 +318,18 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
   if (!dw_ih_f) return SSASR_OK;      // weight gradients deferred to ssasr_bilstm_wgrad
   return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, nullptr, dw_ih_r,
                             dw_hh_r, db_r, nullptr, 0, stream);
+}
+
+extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
+                                int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H, const int32_t* lens,
+                                const float* w_ih_f, const float* w_hh_f, const float* w_ih_r, const float* w_hh_r,
+                                float* gates, const float* cs, const float* hs, float* dx, int64_t dxs_s,
+                                int64_t dxs_n, float* dw_ih_f, float* dw_hh_f, float* db_f, float* dw_ih_r,
+                                float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc, float* gx,
+                                int32_t* sync_ws, void* stream) {
+  return bilstm_bwd_impl(ssasr_take_armed(), dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r,
+                         w_hh_r, gates, cs, hs, dx, dxs_s, dxs_n, dw_ih_f, dw_hh_f, db_f, dw_ih_r, dw_hh_r, db_r,
+                         ws_whhT, ws_dc, gx, sync_ws, stream);
 }
 
 // Weight gradients of a layer from the gate derivatives left in `gates` by
@@ -451,6 +484,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
                                            float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
                                            float* db_r, float* db2_r, float* ws_whhT, float* ws_dc, float* gx,
                                            int32_t* sync_ws, int segments, void* stream, void* side_stream) {
+  const bool armed = ssasr_take_armed();
   if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r || !side_stream) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream, side = (hipStream_t)side_stream;
   float* dwih[2] = {dw_ih_f, dw_ih_r};
@@ -463,9 +497,9 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
   int rc;
   if (nseg == 1) {
     // plain form: the whole backward on `stream`, then every weight gradient on the second stream
-    rc = ssasr_bilstm_bwd(dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates, cs,
-                          hs, dx, dxs_s, dxs_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws_whhT, ws_dc,
-                          gx, sync_ws, stream);
+    rc = bilstm_bwd_impl(armed, dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates,
+                         cs, hs, dx, dxs_s, dxs_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws_whhT, ws_dc,
+                         gx, sync_ws, stream);
     if (rc) return rc;
     hipEvent_t ev = overlap_event();
     if (!ev) return (int)hipErrorOutOfMemory;
@@ -481,7 +515,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
     // the K-split kernel takes its weight slices straight from W_hh: no transposed copy
     rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
-                                      ws_dc, w_hh_f, w_hh_r);
+                                      ws_dc, w_hh_f, w_hh_r, armed);
     if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
     hipEvent_t ev = overlap_event();
     if (!ev) return (int)hipErrorOutOfMemory;

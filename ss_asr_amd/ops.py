@@ -72,6 +72,40 @@ def join_side_stream():
         torch.cuda.current_stream().wait_stream(_side)
 
 
+_SENTINEL_I32 = 0x7FC0DEAD        # PERSIST_SENTINEL (csrc/rnn_kernels.h): the exchange fill pattern
+
+
+class ExchangeArena:
+    """Exchange workspaces of one pass over the model (all forward images, or all BPTT rings),
+    laid out back to back and armed with ONE fill: every slot is reserved before the first one
+    is taken; the calls that receive a slot are told so with ssasr_exchange_armed."""
+
+    def __init__(self, device):
+        self.device, self.sizes, self.offsets, self.buf = device, [], None, None
+
+    def reserve(self, floats):
+        assert self.buf is None, 'reserve every slot before taking the first'
+        self.sizes.append((int(floats) + 63) & ~63)
+        return len(self.sizes) - 1
+
+    def take(self, slot):
+        if self.buf is None:
+            self.offsets = [0]
+            for n in self.sizes:
+                self.offsets.append(self.offsets[-1] + n)
+            self.buf = torch.empty(self.offsets[-1], device=self.device, dtype=torch.float32)
+            self.buf.view(torch.int32).fill_(_SENTINEL_I32)
+        return self.buf[self.offsets[slot]:self.offsets[slot] + self.sizes[slot]]
+
+
+def bilstm_exchange_floats(S, N, H):
+    """(forward image floats, BPTT ring floats) of a BiLSTM layer; 0 where the layer has no
+    persistent form that an ExchangeArena can serve."""
+    lib = _lib.load()
+    hx = 2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4 if N <= 128 and H % 64 == 0 else 0
+    return hx, int(lib.ssasr_bilstm_bwd_ring_floats(S, N, H, 2))
+
+
 def upload_i32(device, *seqs):
     """Host integer sequences -> int32 device tensors, all through ONE pinned staging buffer
     and one asynchronous copy (a copy from pageable memory waits for the stream to drain;
@@ -170,10 +204,11 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, act=0, alpha=1.0, beta=0
 # ---------------------------------------------------------------------------
 class _BiLSTM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, lens, steps, batch_first, sinks, *w):
+    def forward(ctx, x, lens, steps, batch_first, sinks, slots, *w):
         lib = _lib.load()
         _need_gpu(x, *w)
         ctx.sinks = sinks
+        ctx.slots = slots
         x = _f32c(x)
         w = [_f32c(t) for t in w]
         H = w[1].shape[1]
@@ -192,8 +227,13 @@ class _BiLSTM(torch.autograd.Function):
         cs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         hs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         # workspaces of the persistent recurrence (exchange image + counters)
-        hx = torch.empty(2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4, device=x.device,
-                         dtype=torch.float32) if N <= 128 and H % 64 == 0 else None
+        hx_floats = 2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4 if N <= 128 and H % 64 == 0 else 0
+        if slots is not None and slots[1] is not None and hx_floats:
+            hx = slots[0].take(slots[1])              # armed with the arena's one fill
+            assert hx.numel() >= hx_floats
+            lib.ssasr_exchange_armed(1)
+        else:
+            hx = torch.empty(hx_floats, device=x.device, dtype=torch.float32) if hx_floats else None
         sync = _status_words(x.device) if hx is not None else None
         check(lib.ssasr_bilstm_fwd(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
                                    _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
@@ -226,11 +266,18 @@ class _BiLSTM(torch.autograd.Function):
         ws_t = torch.empty(2, H, 4 * H, device=dev)
         ws_dc = torch.empty(2, 2, N, H, device=dev)
         # workspaces of the persistent BPTT (exchange image + counters)
-        gx_floats = int(lib.ssasr_bilstm_bwd_gx_floats(S, N, H))
-        gx = torch.empty(gx_floats, device=dev, dtype=torch.float32) if gx_floats else None
+        slots = ctx.slots
+        armed = slots is not None and slots[3] is not None and int(lib.ssasr_bilstm_bwd_ring_floats(S, N, H, 2)) > 0
+        if armed:
+            gx = slots[2].take(slots[3])              # the K-split ring, armed with the arena's one fill
+        else:
+            gx_floats = int(lib.ssasr_bilstm_bwd_gx_floats(S, N, H))
+            gx = torch.empty(gx_floats, device=dev, dtype=torch.float32) if gx_floats else None
         sync = _status_words(dev) if gx is not None else None
         if sync is not None:
             _track_status(sync, 4)
+        if armed:
+            lib.ssasr_exchange_armed(1)               # consumed by the backward call below
         if sinks is not None:
             # Weight gradients go to the side stream, accumulated into the flat gradient
             # buffer.  The BPTT is cut into 4 segments whose weight-gradient GEMMs start
@@ -248,22 +295,24 @@ class _BiLSTM(torch.autograd.Function):
             for t in (gates, x, hs):
                 t.record_stream(side)
             _notify_wgrad(sinks)
-            return (dx,) + (None,) * 12
+            return (dx,) + (None,) * 13
         check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
                                    _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
                                    _p(ws_dc), _p(gx), _p(sync), _stream()), 'ssasr_bilstm_bwd')
         # inputs: x, lens, steps, batch_first, sinks, then w_ih,w_hh,b_ih,b_hh per direction
-        return (dx, None, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
+        return (dx, None, None, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
                 dw[3], dw[4], dw[5], dw[5].clone())
 
 
-def bilstm(x, lens, steps, batch_first, weights):
+def bilstm(x, lens, steps, batch_first, weights, slots=None):
     """weights = (w_ih, w_hh, b_ih, b_hh) forward then the same four reverse.
     batch_first: x [N, T, I], the first ``steps`` frames are processed and the
     result is [N, steps, 2H]; otherwise x is [S, N, I] -> [S, N, 2H].
-    lens: int32 device tensor [N] or None."""
-    return _BiLSTM.apply(x, lens, steps, batch_first, _grad_sinks(weights), *weights)
+    lens: int32 device tensor [N] or None.
+    slots: (forward ExchangeArena, slot, backward ExchangeArena, slot) reserved with the sizes of
+    bilstm_exchange_floats, or None (the layer allocates and arms its own workspaces)."""
+    return _BiLSTM.apply(x, lens, steps, batch_first, _grad_sinks(weights), slots, *weights)
 
 
 # ---------------------------------------------------------------------------
@@ -401,7 +450,7 @@ _DEC_PARAMS = ('w_phi', 'w_ih1', 'w_hh1', 'b_ih1', 'b_hh1', 'w_ih2', 'w_hh2', 'b
 
 class _DecoderLoop(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, comp, enc_len, teacher, step_mode, uniforms, sinks, modes_dev, *params):
+    def forward(ctx, feat, comp, enc_len, teacher, step_mode, uniforms, sinks, modes_dev, slots, *params):
         lib = _lib.load()
         ctx.sinks = sinks
         ctx.set_materialize_grads(False)      # no zero tensors for the att / chars outputs
@@ -428,20 +477,31 @@ class _DecoderLoop(torch.autograd.Function):
         U = len(step_mode)
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         bufs = dict(logits=f(B, U, V), att=f(B, U, T), w_phi_t=f(D, A), q=f(U, B, A),
-                    ctx=f(U, B, E), emb_in=f(U + 1, B, D),
+                    emb_in=f(U + 1, B, D),
                     chars=torch.empty(U + 1, B, device=dev, dtype=torch.int32),
                     gates1=f(U, B, 4 * D), c1=f(U, B, D), h1=f(U, B, D),
                     gates2=f(U, B, 4 * D), c2=f(U, B, D), h2=f(U, B, D))
         if A == 128 and E == 512 and D == 256 and B <= 32 and T <= 128 and V <= 64:
             # workspaces of the persistent decode loop
             # (the three exchange images back to back: one fill instead of three)
-            img = f(U * (2 * (D // 4) * 32 * 4 + (A // 16) * 32 * 16))
+            # (... and the context rows behind them: all four start as the fill pattern)
+            nimg = U * (2 * (D // 4) * 32 * 4 + (A // 16) * 32 * 16)
+            if slots is not None and slots.get('fwd') is not None:
+                img = slots['fwd_arena'].take(slots['fwd'])[:nimg + U * B * E]     # armed by the arena
+                assert img.numel() == nimg + U * B * E
+                ctx_armed = True
+            else:
+                img = f(nimg + U * B * E)
+                ctx_armed = False
             nh = U * (D // 4) * 32 * 4
-            bufs.update(ws_hx1=img[:nh], ws_hx2=img[nh:2 * nh], ws_qx=img[2 * nh:],
+            bufs.update(ws_hx1=img[:nh], ws_hx2=img[nh:2 * nh], ws_qx=img[2 * nh:nimg],
+                        ctx=img[nimg:].view(U, B, E),
                         ws_modes=modes_dev if modes_dev is not None else
                         torch.empty(U, device=dev, dtype=torch.int32),
                         ws_sync=_status_words(dev))
             _track_status(bufs['ws_sync'], 5)
+        if 'ctx' not in bufs:
+            bufs['ctx'] = f(U, B, E)
         modes = (C.c_int32 * U)(*[int(m) for m in step_mode])
         d = _lib.Decoder()
         d.B, d.T, d.E, d.A, d.D, d.V, d.U = B, T, E, A, D, V, U
@@ -457,8 +517,11 @@ class _DecoderLoop(torch.autograd.Function):
             setattr(d, k, t.data_ptr())
         for k, t in bufs.items():
             setattr(d, k, t.data_ptr())
+        if 'ws_hx1' in bufs and ctx_armed:
+            lib.ssasr_exchange_armed(1)
         check(lib.ssasr_decoder_fwd(C.byref(d), _stream()), 'ssasr_decoder_fwd')
         ctx.dec = d
+        ctx.slots = slots
         ctx.keep = (feat, comp, enc_len, teacher, modes, uniforms, params, bufs)
         ctx.mark_non_differentiable(bufs['att'])
         return bufs['logits'], bufs['att'], bufs['chars']
@@ -492,14 +555,22 @@ class _DecoderLoop(torch.autograd.Function):
                   ws_de=f(B, U, T), ws_dqpre=f(U, B, A), ws_dc=f(2, 2, B, D),
                   ws_demb=f(U, B, D))
         gx_floats = int(lib.ssasr_bilstm_bwd_gx_floats(U, B, D))
+        armed = False
         if gx_floats:                     # persistent BPTT of the second cell
-            ws['ws_gx'] = f(gx_floats)
+            chain_floats = int(lib.ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D))
+            slots = ctx.slots
+            armed = (slots is not None and slots.get('ring') is not None and chain_floats > 0 and
+                     int(lib.ssasr_bilstm_bwd_ring_floats(U, B, D, 1)) > 0)
+            if armed:                     # ring and chain workspace from the backward arena, armed by its one fill
+                ws['ws_gx'] = slots['bwd_arena'].take(slots['ring'])
+                ws['ws_chain'] = slots['bwd_arena'].take(slots['chain'])
+            else:
+                ws['ws_gx'] = f(gx_floats)
+                if chain_floats:          # persistent first-cell <-> attention chain
+                    ws['ws_chain'] = f(chain_floats)
             ws['ws_sync'] = _status_words(dev)
             _track_status(ws['ws_sync'], 4)
             _track_status(ws['ws_sync'], 5)
-            chain_floats = int(lib.ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D))
-            if chain_floats:              # persistent first-cell <-> attention chain
-                ws['ws_chain'] = f(chain_floats)
         g = _lib.DecoderGrads()
         g.dlogits = dlogits.data_ptr()
         for k, t in list(out.items()) + list(ws.items()):
@@ -507,6 +578,8 @@ class _DecoderLoop(torch.autograd.Function):
         if sinks is not None:
             g.db1_2, g.db2_2 = sk['b_hh1'].data_ptr(), sk['b_hh2'].data_ptr()
             g.defer_wgrad = 1
+        if armed:
+            lib.ssasr_exchange_armed(1)
         check(lib.ssasr_decoder_bwd(C.byref(d), C.byref(g), _stream()), 'ssasr_decoder_bwd')
         dpsi = ()
         if ctx.psi:
@@ -534,15 +607,16 @@ class _DecoderLoop(torch.autograd.Function):
             for t in list(bufs.values()) + list(ws.values()) + [dlogits, out['dcomp'], feat]:
                 t.record_stream(side)
             _notify_wgrad(sinks)
-            return (out['dfeat'], None if ctx.psi else out['dcomp']) + (None,) * (6 + len(params))
+            return (out['dfeat'], None if ctx.psi else out['dcomp']) + (None,) * (7 + len(params))
         o = out
-        return (o['dfeat'], None if ctx.psi else o['dcomp'], None, None, None, None, None, None,
+        return (o['dfeat'], None if ctx.psi else o['dcomp'], None, None, None, None, None, None, None,
                 o['dw_phi'], o['dw_ih1'], o['dw_hh1'], o['db1'], o['db1'].clone(),
                 o['dw_ih2'], o['dw_hh2'], o['db2'], o['db2'].clone(),
                 o['dembed'], o['dw_ct'], o['db_ct']) + dpsi
 
 
-def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params, modes_dev=None, psi=None):
+def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params, modes_dev=None, psi=None,
+                 slots=None):
     """The decode loop of ASR.forward (src/asr.py:67-110).
 
     step_mode: host sequence of U ints (0 teacher forced, 1 sample, 2 argmax);
@@ -550,6 +624,7 @@ def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params, mode
     uploaded them (with its other per-step integers), else None.
     psi: (weight, bias) of Attention.psi with comp=None: the projection comp = tanh(psi(feat))
     (src/asr.py:381) is then computed and differentiated inside this node.
+    slots: what decoder_reserve returned for this call's sizes, or None.
     teacher: int32 [B, L] device tensor of character ids or None.
     params: dict with the keys of ``_DEC_PARAMS``.
     Returns (logits [B,U,V], att [B,U,T] (no grad), chars [U+1,B] int32)."""
@@ -558,7 +633,24 @@ def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params, mode
         assert comp is None
         plist += list(psi)
     return _DecoderLoop.apply(feat, comp, enc_len, teacher, list(step_mode), uniforms, _grad_sinks(plist),
-                              modes_dev, *plist)
+                              modes_dev, slots, *plist)
+
+
+def decoder_reserve(fwd_arena, bwd_arena, B, T, U, A=128, E=512, D=256, V=64):
+    """Reserves the decode loop's exchange workspaces in the two arenas of a pass (forward
+    images + context rows; cell-2 ring + chain workspace).  Returns the `slots` argument of
+    decoder_loop, or None when the sizes have no persistent form."""
+    lib = _lib.load()
+    if not (A == 128 and E == 512 and D == 256 and B <= 32 and T <= 128 and V <= 64 and U > 0):
+        return None
+    slots = dict(fwd_arena=fwd_arena, bwd_arena=bwd_arena, fwd=None, ring=None, chain=None)
+    slots['fwd'] = fwd_arena.reserve(U * (2 * (D // 4) * 32 * 4 + (A // 16) * 32 * 16) + U * B * E)
+    ring = int(lib.ssasr_bilstm_bwd_ring_floats(U, B, D, 1))
+    chain = int(lib.ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D))
+    if ring and chain:
+        slots['ring'] = bwd_arena.reserve(ring)
+        slots['chain'] = bwd_arena.reserve(chain)
+    return slots
 
 
 # ---------------------------------------------------------------------------
