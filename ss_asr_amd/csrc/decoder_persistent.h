@@ -6,14 +6,20 @@
 // 8.4 MB of listener features plus 6.5 MB of cell weights.  Here
 //   * 64 "attention" workgroups (utterance b, 256-column half of E) keep
 //     their slice of feat in LDS for the whole loop (102 KB at T = 100) and
-//     prefetch their rows of comp while they wait for the query;
+//     W_phi in registers: from the published h1_{t-1} of their utterance they
+//     form the query q_t = tanh(W_phi h1_{t-1}) themselves (a 128 x 256
+//     matrix-vector product split over the 8 frame groups), then the energies,
+//     the softmax and their half of the context; they prefetch their rows of
+//     comp while they wait for h1;
 //   * 128 "compute" workgroups (4 hidden units x 16 utterances) keep their
-//     slices of W_phi, [W_ih1 | W_hh1] and [W_ih2 | W_hh2] in registers and
-//     time-share three roles per step: phi_t, cell 2 of step t-1 (off the
-//     critical path: it overlaps the attention workgroups' work) and cell 1
-//     of step t; the first 32 also draw the next character on steps that are
-//     not teacher forced.
-// Stage hand-offs (h1 -> q -> ctx -> h1, h1 -> h2, h2 -> char -> emb) use the
+//     slices of [W_ih1 | W_hh1] and [W_ih2 | W_hh2] in registers and time-share
+//     two roles per step: cell 2 of step t-1 (off the critical path: it overlaps
+//     the attention workgroups' work) and cell 1 of step t; the first 32 also
+//     draw the next character on steps that are not teacher forced.
+// The critical loop has two hand-offs per step (h1 -> ctx -> h1); the query used
+// to be a third (computed by 16 compute workgroups and handed to the attention
+// workgroups): 10.9 -> 9.x us per step without it.
+// Stage hand-offs (h1 -> ctx -> h1, h1 -> h2, h2 -> char -> emb) use the
 // protocol of the persistent recurrences (rnn_kernels.h): write-through (sc1)
 // stores that cover whole 128-byte lines per store instruction into buffers the
 // host pre-filled with the NaN pattern PERSIST_SENTINEL; consumers read with sc1
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
   const int B = p.B, T = p.T, U = p.U;
   PdWaiter wt{false, p.status};
   const unsigned n_att = (unsigned)(B * PD_NATT);     // ctx publishers per step
-  const unsigned n_cmp = 128u, n_phi = 16u, n_chr = (unsigned)B;
+  const unsigned n_cmp = 128u, n_chr = (unsigned)B;
   const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4 * sizeof(float);      // bytes per step
   const size_t img_q = (size_t)(PD_A / 16) * PD_BP * 16 * sizeof(float);
 
@@ -163,8 +169,18 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
     }
     __syncthreads();
     const float* cb = p.comp + (int64_t)b * T * PD_A + 4 * l32;
-    const __amdgpu_buffer_rsrc_t rq = pd_rsrc(p.qx, img_q * U);
+    const __amdgpu_buffer_rsrc_t rh = pd_rsrc(p.hx1, img_h * U);
     const __amdgpu_buffer_rsrc_t rc = pd_rsrc(p.ctx, (size_t)U * B * PD_E * sizeof(float));
+    // q_t = tanh(W_phi h1_{t-1}) is computed HERE, from the published h1 of this utterance, instead
+    // of in compute workgroups that would hand it over: one hand-off less per decode step.
+    // Thread (hw, l32) keeps rows 4*l32.. of W_phi for the 32 k's of its frame group: 128 registers.
+    float* sHq = sM + 128;                  // [256] h1_{t-1} of this utterance
+    float4 wq[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        wq[i][j] = aload4(p.w_phi + (int64_t)(4 * l32 + i) * PD_D + 32 * hw + 4 * j);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = 0; t < U; ++t) {
       SSASR_DTRACE(t, 0);
@@ -176,12 +192,33 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
       }
       float4 q4 = z4;
       if (t > 0) {
-        if (!SEN) wt.wait_ge(p.cnt + PC_Q, n_phi * (unsigned)t);
-        const unsigned qoff = (unsigned)(t * img_q + (((l32 >> 2) * PD_BP + b) * 16 + (l32 & 3) * 4) * 4);
-        float4 qv[1];
-        pd_fetch<SEN, 1>(qv, [=](int) { return pd_ld_raw(rq, qoff); }, 0, 1, p.status);
-        q4 = qv[0];
+        if (!SEN) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
+        if (wave == 0) {        // the 64 16-byte pieces of h1_{t-1}[b] (image [D/4][BP][4])
+          const unsigned hoff = (unsigned)((t - 1) * img_h + ((lane * PD_BP + b) * 4) * 4);
+          float4 hv[1];
+          pd_fetch<SEN, 1>(hv, [=](int) { return pd_ld_raw(rh, hoff); }, 0, 1, p.status);
+          *reinterpret_cast<float4*>(sHq + 4 * lane) = hv[0];
+        }
         SSASR_DTRACE(t, 1);
+        __syncthreads();
+        float4 part = z4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 h = *reinterpret_cast<const float4*>(sHq + 32 * hw + 4 * j);
+          part.x = fmaf(wq[0][j].x, h.x, fmaf(wq[0][j].y, h.y, fmaf(wq[0][j].z, h.z, fmaf(wq[0][j].w, h.w, part.x))));
+          part.y = fmaf(wq[1][j].x, h.x, fmaf(wq[1][j].y, h.y, fmaf(wq[1][j].z, h.z, fmaf(wq[1][j].w, h.w, part.y))));
+          part.z = fmaf(wq[2][j].x, h.x, fmaf(wq[2][j].y, h.y, fmaf(wq[2][j].z, h.z, fmaf(wq[2][j].w, h.w, part.z))));
+          part.w = fmaf(wq[3][j].x, h.x, fmaf(wq[3][j].y, h.y, fmaf(wq[3][j].z, h.z, fmaf(wq[3][j].w, h.w, part.w))));
+        }
+        *reinterpret_cast<float4*>(sRed + hw * 256 + 4 * l32) = part;
+        __syncthreads();
+        float4 v = *reinterpret_cast<const float4*>(sRed + 4 * l32);
+#pragma unroll
+        for (int g = 1; g < 8; ++g) {
+          const float4 a = *reinterpret_cast<const float4*>(sRed + g * 256 + 4 * l32);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        q4 = make_float4(fast_tanh(v.x), fast_tanh(v.y), fast_tanh(v.z), fast_tanh(v.w));
       }
       if (chunk == 0 && hw == 0) *reinterpret_cast<float4*>(p.q + ((int64_t)t * B + b) * PD_A + 4 * l32) = q4;
       float e[16];
@@ -281,11 +318,10 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
   f32x4* red = reinterpret_cast<f32x4*>(smem);     // [4][64]
   float* sH = smem + 4 * 64 * 4;                   // [16][4] transpose buffer, then [256] for the char role
   const int D = PD_D, E = PD_E;
-  const bool is_phi = c < 16, is_chr = c < B;
-  const int atile = c >> 1;                        // phi role: 16 rows of A, same 16-utterance chunk
+  const bool is_chr = c < B;
 
   // resident weight slices (this wave's k-blocks: kb = wave + 4 j)
-  float4 w1[16], w2[8], wp[4];
+  float4 w1[16], w2[8];
   {
     const int rowA = (r & 3) * D + 4 * tile + (r >> 2);
 #pragma unroll
@@ -299,10 +335,6 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
       const int k = 16 * (wave + 4 * j) + 4 * q;                 // 0 .. 511 over [h1 | h2]
       w2[j] = k < D ? aload4(p.w_ih2 + (int64_t)rowA * D + k) : aload4(p.w_hh2 + (int64_t)rowA * D + (k - D));
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      wp[j] = is_phi ? aload4(p.w_phi + (int64_t)(16 * atile + r) * D + 16 * (wave + 4 * j) + 4 * q)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int u = 4 * tile + q;                      // epilogue (wave 0): unit u, utterance n
   const bool epi = wave == 0 && n < B;
@@ -317,7 +349,6 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
   float cst1 = 0.f, cst2 = 0.f;
   const __amdgpu_buffer_rsrc_t rh1 = pd_rsrc(p.hx1, img_h * U);
   const __amdgpu_buffer_rsrc_t rh2 = pd_rsrc(p.hx2, img_h * U);
-  const __amdgpu_buffer_rsrc_t rq = pd_rsrc(p.qx, img_q * U);
   const __amdgpu_buffer_rsrc_t rc = pd_rsrc(p.ctx, (size_t)U * B * E * sizeof(float));
   const __amdgpu_buffer_rsrc_t re = pd_rsrc(p.emb_in, (size_t)(U + 1) * B * D * sizeof(float));
   const unsigned xoi = (unsigned)((q * PD_BP + nc) * 16);          // lane part of an image read
@@ -367,33 +398,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
     if (!SEN && t > 0) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
     SSASR_DTRACE(t, 1);
 
-    // (B) phi_t: q_t = tanh(W_phi h1_{t-1})          (16 workgroups)
-    if (is_phi && t > 0 && t < U) {
-      float4 bq[4];
-      {
-        const unsigned o1 = (unsigned)((t - 1) * img_h + wave * 4 * PD_BP * 16 + xoi);
-        pd_fetch<SEN, 4>(bq, [=](int j) { return pd_ld_raw(rh1, o1 + (unsigned)(4 * j) * 4 * PD_BP * 16); }, 0, 4,
-                         p.status);
-      }
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-      pd_mma<4>(acc, acc2, wp, bq, 0, 4);
-      red[wave * 64 + lane] = acc + acc2;
-      __syncthreads();
-      if (wave == 0) {
-        f32x4 v = red[lane];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) v += red[w * 64 + lane];
-        // D fragment: rows 4q..4q+3 of this A tile, column = utterance 16*chunk + r
-        const float4 qv = make_float4(fast_tanh(v[0]), fast_tanh(v[1]), fast_tanh(v[2]), fast_tanh(v[3]));
-        pd_st_sc1(rq, (unsigned)(t * img_q + ((atile * PD_BP + 16 * chunk + r) * 16 + 4 * q) * 4), qv);
-        if (!SEN) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_Q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      __syncthreads();
-    }
-
+    // (B) (phi_t = tanh(W_phi h1_{t-1}) is computed by the attention workgroups themselves)
     SSASR_DTRACE(t, 2);
     // (C) cell 2 of step t-1 (overlaps the attention workgroups' step t)
     if (t > 0) {
@@ -506,6 +511,6 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
   }
 }
 
-inline size_t decoder_persistent_lds(int T) { return sizeof(float) * ((size_t)T * 256 + 2176); }
+inline size_t decoder_persistent_lds(int T) { return sizeof(float) * ((size_t)T * 256 + 2176 + 256); }
 
 }  // namespace
