@@ -156,7 +156,12 @@ __device__ __forceinline__ float4 read_frag(const float* lds, int base, int r, i
   }
 }
 
-template <int BM, int BN, bool TA, bool TB>
+// rows of a mapped matrix start on 16-byte boundaries (given a 16-byte aligned base)
+__device__ __forceinline__ bool map_vec_ok_dev(const RowMap& m) {
+  return m.inner ? (m.so % 4 == 0 && m.si % 4 == 0) : (m.ld % 4 == 0);
+}
+
+template <int BM, int BN, bool TA, bool TB, bool TR>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bool vecB) {
   constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
   constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 fragments per wave
@@ -246,7 +251,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
 #define SSASR_GEMM_STEP(KS, C)                                                          \
   _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
   _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[KS][i].C, fb[KS][j].C, acc[i][j], 0, 0, 0)
+    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(fb[KS][j].C, fa[KS][i].C, acc[i][j], 0, 0, 0)      \
+                   : __builtin_amdgcn_mfma_f32_16x16x4f32(fa[KS][i].C, fb[KS][j].C, acc[i][j], 0, 0, 0)
     SSASR_GEMM_STEP(0, x);
     SSASR_GEMM_STEP(0, y);
     SSASR_GEMM_STEP(0, z);
@@ -265,34 +271,95 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
     buf ^= 1;
   }
 
-  // Epilogue.  D fragment: column = lane & 15, row = 4 * (lane >> 4) + reg.
+  if (!TR) {
+    // Epilogue.  D fragment: column = lane & 15, row = 4 * (lane >> 4) + reg.
+    float* C = g.C + (int64_t)bz * g.sc;
+    const float* b1 = g.bias1 ? g.bias1 + (int64_t)bz * g.sbias : nullptr;
+    const float* b2 = g.bias2 ? g.bias2 + (int64_t)bz * g.sbias : nullptr;
+    const bool lead = (kz == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * WM + i * 16 + 4 * q + e;
+        if (m >= g.M) continue;
+        const int64_t rowoff = rm_off(g.mc, m);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * WN + j * 16 + r;
+          if (n >= g.N) continue;
+          float v = g.alpha * acc[i][j][e];
+          if (lead) {
+            if (b1) v += b1[n];
+            if (b2) v += b2[n];
+          }
+          if (g.splitk > 1) {
+            atomicAdd(C + rowoff + n, v);
+          } else {
+            if (g.act == 1) v = tanhf(v);
+            else if (g.act == 2) v = logf(fmaxf(v, 0.f) + 2.220446049250313e-16f);   // np.log(x + eps)
+            if (g.beta != 0.f) v += g.beta * C[rowoff + n];
+            C[rowoff + n] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // Epilogue, TR.  The products were accumulated TRANSPOSED (B fragment as the MFMA's first operand):
+  // D fragment column = lane & 15 is the output ROW m, D rows 4 * (lane >> 4) + reg are four
+  // consecutive output COLUMNS n, so a lane owns 16 contiguous bytes of C and a store instruction
+  // writes 64-byte runs of 16 rows (four times fewer store instructions than one float per lane;
+  // the K = 80 input projection of the first layer is bound by its 0.4 GB of output).
   float* C = g.C + (int64_t)bz * g.sc;
   const float* b1 = g.bias1 ? g.bias1 + (int64_t)bz * g.sbias : nullptr;
   const float* b2 = g.bias2 ? g.bias2 + (int64_t)bz * g.sbias : nullptr;
   const bool lead = (kz == 0);
+  const bool vecC = map_vec_ok_dev(g.mc) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + r;
+    if (m >= g.M) continue;
+    const int64_t rowoff = rm_off(g.mc, m);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int m = m0 + wm * WM + i * 16 + 4 * q + e;
-      if (m >= g.M) continue;
-      const int64_t rowoff = rm_off(g.mc, m);
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + wn * WN + j * 16 + 4 * q;
+      if (nb >= g.N) continue;
+      float v[4];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 16 + r;
-        if (n >= g.N) continue;
-        float v = g.alpha * acc[i][j][e];
-        if (lead) {
-          if (b1) v += b1[n];
-          if (b2) v += b2[n];
+      for (int e = 0; e < 4; ++e) {
+        v[e] = g.alpha * acc[i][j][e];
+        if (lead && nb + e < g.N) {
+          if (b1) v[e] += b1[nb + e];
+          if (b2) v[e] += b2[nb + e];
         }
-        if (g.splitk > 1) {
-          atomicAdd(C + rowoff + n, v);
-        } else {
-          if (g.act == 1) v = tanhf(v);
-          else if (g.act == 2) v = logf(fmaxf(v, 0.f) + 2.220446049250313e-16f);   // np.log(x + eps)
-          if (g.beta != 0.f) v += g.beta * C[rowoff + n];
-          C[rowoff + n] = v;
+      }
+      if (g.splitk > 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (nb + e < g.N) atomicAdd(C + rowoff + nb + e, v[e]);
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (g.act == 1) v[e] = tanhf(v[e]);
+        else if (g.act == 2) v[e] = logf(fmaxf(v[e], 0.f) + 2.220446049250313e-16f);   // np.log(x + eps)
+      }
+      if (vecC && nb + 3 < g.N) {
+        float4* dst = reinterpret_cast<float4*>(C + rowoff + nb);
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.beta != 0.f) {
+          const float4 c0 = *dst;
+          o.x += g.beta * c0.x; o.y += g.beta * c0.y; o.z += g.beta * c0.z; o.w += g.beta * c0.w;
+        }
+        *dst = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (nb + e >= g.N) continue;
+          float o = v[e];
+          if (g.beta != 0.f) o += g.beta * C[rowoff + nb + e];
+          C[rowoff + nb + e] = o;
         }
       }
     }
@@ -308,10 +375,18 @@ template <int BM, int BN>
 int launch_tiles(const GemmDesc& g, bool vecA, bool vecB, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * g.splitk);
   dim3 block(256);
-  if (!g.ta && !g.tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g, vecA, vecB);
-  else if (!g.ta && g.tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g, vecA, vecB);
-  else if (g.ta && !g.tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g, vecA, vecB);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, g, vecA, vecB);
+  // split-K launches add their partial products atomically: one float per lane in rows of 16
+  // consecutive columns (TR = false); everything else stores 16 bytes per lane (TR = true)
+#define SSASR_GEMM_LAUNCH(A_, B_)                                                                           \
+  do {                                                                                                      \
+    if (g.splitk > 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_, B_, false>), grid, block, 0, st, g, vecA, vecB); \
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_, B_, true>), grid, block, 0, st, g, vecA, vecB);    \
+  } while (0)
+  if (!g.ta && !g.tb) SSASR_GEMM_LAUNCH(false, false);
+  else if (!g.ta && g.tb) SSASR_GEMM_LAUNCH(false, true);
+  else if (g.ta && !g.tb) SSASR_GEMM_LAUNCH(true, false);
+  else SSASR_GEMM_LAUNCH(true, true);
+#undef SSASR_GEMM_LAUNCH
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
