@@ -66,26 +66,30 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   const float* bih[2] = {b_ih_f, b_ih_r};
   const float* bhh[2] = {b_hh_f, b_hh_r};
 
-  // (1) input->hidden for every time step: gates[d] = X . W_ih[d]^T + b_ih + b_hh
-  // Both directions as the two batches of ONE launch when their parameters lie at equal
-  // distances (they do in a flat parameter buffer): 2x the tiles per launch halves the share of
-  // the last, partly filled round of workgroups (800 tiles on 256 CUs: 3.1 rounds cost 4).
-  const bool paired = bih[0] && bhh[0] && bih[1] && bhh[1] && (wih[1] - wih[0]) % 4 == 0 &&
-                      (bih[1] - bih[0]) == (bhh[1] - bhh[0]);
-  for (int d = 0; d < (paired ? 1 : 2); ++d) {
-    GemmDesc g{};
-    g.A = x; g.ma = RowMap{0, N, xs_s, xs_n};
-    g.B = wih[d]; g.mb = rm_dense(I);
-    g.C = gates + d * rows * 4 * H; g.mc = rm_dense(4 * H);
-    g.M = (int)rows; g.N = (int)(4 * H); g.K = (int)I;
-    g.ta = 0; g.tb = 0; g.bias1 = bih[d]; g.bias2 = bhh[d];
-    g.alpha = 1.f; g.beta = 0.f; g.splitk = 1; g.batch = 1;
-    if (paired) {
-      g.batch = 2; g.sa = 0; g.sb = wih[1] - wih[0]; g.sc = rows * 4 * H; g.sbias = bih[1] - bih[0];
+  // (1) input->hidden for every time step: gates[d] = X . W_ih[d]^T + b_ih + b_hh -- unless the
+  // persistent recurrence below forms them itself (narrow inputs), see `fuse_in`
+  auto input_projection = [&]() -> int {
+    // Both directions as the two batches of ONE launch when their parameters lie at equal
+    // distances (they do in a flat parameter buffer): 2x the tiles per launch halves the share of
+    // the last, partly filled round of workgroups (800 tiles on 256 CUs: 3.1 rounds cost 4).
+    const bool paired = bih[0] && bhh[0] && bih[1] && bhh[1] && (wih[1] - wih[0]) % 4 == 0 &&
+                        (bih[1] - bih[0]) == (bhh[1] - bhh[0]);
+    for (int d = 0; d < (paired ? 1 : 2); ++d) {
+      GemmDesc g{};
+      g.A = x; g.ma = RowMap{0, N, xs_s, xs_n};
+      g.B = wih[d]; g.mb = rm_dense(I);
+      g.C = gates + d * rows * 4 * H; g.mc = rm_dense(4 * H);
+      g.M = (int)rows; g.N = (int)(4 * H); g.K = (int)I;
+      g.ta = 0; g.tb = 0; g.bias1 = bih[d]; g.bias2 = bhh[d];
+      g.alpha = 1.f; g.beta = 0.f; g.splitk = 1; g.batch = 1;
+      if (paired) {
+        g.batch = 2; g.sa = 0; g.sb = wih[1] - wih[0]; g.sc = rows * 4 * H; g.sbias = bih[1] - bih[0];
+      }
+      int rc = ssasr_launch_gemm(g, st);
+      if (rc) return rc;
     }
-    int rc = ssasr_launch_gemm(g, st);
-    if (rc) return rc;
-  }
+    return SSASR_OK;
+  };
 
   // (2) the recurrence, one launch per step, both directions per launch
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31) || rows * 4 * H >= (1ll << 40)) return SSASR_EARG;
@@ -108,9 +112,21 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     // status words are zero on entry (caller's contract); only the arrival counters of the
     // counter form need clearing per launch
     if (sync_ws && getenv("SSASR_PERSISTENT_COUNTER")) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 4 * sizeof(int32_t), st));
+    // narrow input (the 80 mel bins of the first layer): the persistent kernel's helper wave forms
+    // the pre-activations itself; no input projection GEMM (rnn_kernels.h, KI)
+    const bool sentinel_mode = getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
+    const bool fuse_in = fits && sentinel_mode && kpw == 4 && I == 80 && bih[0] && bhh[0] && bih[1] && bhh[1] &&
+                         aligned16(x) && aligned16(w_ih_f) && aligned16(w_ih_r) && xs_s % 4 == 0 && xs_n % 4 == 0 &&
+                         !getenv("SSASR_NO_FUSED_INPUT");
+    if (!fuse_in) {
+      const int rc = input_projection();
+      if (rc) return rc;
+    }
     if (fits) {
       EncPersist p{};
       p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
+      p.x = x; p.xs_s = xs_s; p.xs_n = xs_n;
+      for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }
       p.gates = gates; p.cs = cs; p.hs = hs; p.hx = hx; p.y = y; p.lens = lens;
       p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
       p.delay = persist_delay("SSASR_PERSIST_DELAY_FWD", 24);
@@ -129,7 +145,9 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
         else if (kpw == 4) SSASR_FWD_LAUNCH(4, SEN, NBT);           \
         else SSASR_FWD_LAUNCH(8, SEN, NBT);                         \
       } while (0)
-      if (sentinel && nb == 1) SSASR_FWD_PICK(true, 1);
+      if (fuse_in && nb == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 1, 5>), pgrid, pblock, 0, st, p);
+      else if (fuse_in) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 2, 5>), pgrid, pblock, 0, st, p);
+      else if (sentinel && nb == 1) SSASR_FWD_PICK(true, 1);
       else if (sentinel) SSASR_FWD_PICK(true, 2);
       else if (nb == 1) SSASR_FWD_PICK(false, 1);
       else SSASR_FWD_PICK(false, 2);

@@ -366,9 +366,18 @@ struct EncPersist {
   int delay;             // initial pacing delay (PersistPacer)
   int ys_s, ys_n;
   int S, N, H;
+  // KI > 0 (template): the helper wave computes the input->hidden pre-activations itself
+  // (small input widths: I = 16 * KI) instead of streaming them from `gates`
+  const float* x;        // logical [S][N][I] through xs_s / xs_n (floats)
+  int64_t xs_s, xs_n;
+  const float* wih[2];   // [4H][I] per direction
+  const float* bih[2];
+  const float* bhh[2];
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 constexpr unsigned PERSIST_MAX_SPINS = 1u << 20;   // ~ a second of polling, then give up for good
 
@@ -408,7 +417,12 @@ struct PersistPacer {
 // step behind it writes the row-major copies of the results (gates, c, h, y),
 // so that no HBM latency, no scattered store and no address arithmetic for
 // them sits in the recurrence waves.
-template <int KPW, bool SENTINEL, int NB>   // k-blocks per wave = H / 64; NB x 16 batch columns per workgroup
+// KI > 0: the layer's input is narrow (I = 16 * KI floats, the 80 mel bins of the first layer) and
+// the helper wave forms the pre-activations W_ih x_s + b itself, one step ahead, with KI * 4 MFMAs
+// per column tile while the recurrence waves wait for their operand loads: the input projection
+// GEMM and its 2 x 0.4 GB of pre-activation traffic disappear.  A fragment: row 4 * unit + gate of
+// this workgroup's 16 gate rows, so that D leaves unit q's four gates in lane (q, column).
+template <int KPW, bool SENTINEL, int NB, int KI = 0>   // k-blocks per wave = H / 64; NB x 16 batch columns per workgroup
 __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * NB * 64];
   // step results staged for the helper wave: [i, f, g, o, c, h][column][4 units]
@@ -437,21 +451,51 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
     // ------------------------------ helper wave ------------------------------
     PersistPacer pacer{e.delay, 0};
     float nadd[NB][4];
+    constexpr int KIN = KI > 0 ? KI : 1;
+    float4 wA[KIN], xb[NB][KIN];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (KI > 0) {
+      const int rowA = (r & 3) * H + 4 * tile + (r >> 2);       // A row r = 4 * unit + gate
+      const float* wp = e.wih[d] + (int64_t)rowA * (16 * KI) + 4 * q;
+#pragma unroll
+      for (int j = 0; j < KIN; ++j) wA[j] = ld4(wp + 16 * j);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bsum[g] = e.bih[d][g * H + u] + e.bhh[d][g * H + u];
+    }
     auto fetch = [&](int i) {
       const int s = d ? S - 1 - i : i;
 #pragma unroll
       for (int bt = 0; bt < NB; ++bt) {
         const int n = n0 + 16 * bt + r;
-        const int64_t g0 = ((int64_t)s * N + (n < N ? n : N - 1)) * 4 * H + u;
+        if (KI > 0) {
+          const float* xp = e.x + (int64_t)s * e.xs_s + (int64_t)(n < N ? n : N - 1) * e.xs_n + 4 * q;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nadd[bt][g] = gbase[g0 + (int64_t)g * H];
+          for (int j = 0; j < KIN; ++j) xb[bt][j] = ld4(xp + 16 * j);
+        } else {
+          const int64_t g0 = ((int64_t)s * N + (n < N ? n : N - 1)) * 4 * H + u;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) nadd[bt][g] = gbase[g0 + (int64_t)g * H];
+        }
       }
     };
     auto publish = [&](int i) {
 #pragma unroll
-      for (int bt = 0; bt < NB; ++bt)
+      for (int bt = 0; bt < NB; ++bt) {
+        if (KI > 0) {
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < KIN; ++j) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[j].x, xb[bt][j].x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[j].y, xb[bt][j].y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[j].z, xb[bt][j].z, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[j].w, xb[bt][j].w, a1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) nadd[bt][g] = a0[g] + a1[g] + bsum[g];
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) addbuf[i & 1][bt][g][lane] = nadd[bt][g];
+      }
     };
     // Row-major copies of a step's results (activated gates, c, h, y) leave
     // through this wave one step later, as 16-byte stores: 7 arrays x 32 columns
@@ -646,7 +690,6 @@ struct CellBwdPair { CellBwd d[2]; };
 constexpr int BWD_NB = 1;    // 16 batch columns per workgroup
 constexpr int BWD_UN = 16;
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // grid (H/16, directions, ceil(N/16)), 256 threads.  All row pointers must be
