@@ -403,9 +403,18 @@ struct PersistPacer {
   __device__ __forceinline__ void sleep() const {
     for (int k = 0; k < delay; ++k) __builtin_amdgcn_s_sleep(1);
   }
+#ifndef SSASR_PACE_UP
+#define SSASR_PACE_UP 2
+#endif
+#ifndef SSASR_PACE_CLEAN
+#define SSASR_PACE_CLEAN 2
+#endif
+#ifndef SSASR_PACE_DOWN
+#define SSASR_PACE_DOWN 1
+#endif
   __device__ __forceinline__ void update(bool missed) {
-    if (missed) { delay = min(delay + 4, 96); clean = 0; }
-    else if (++clean >= 4) { delay = max(delay - 1, 0); clean = 0; }
+    if (missed) { delay = min(delay + SSASR_PACE_UP, 96); clean = 0; }
+    else if (++clean >= SSASR_PACE_CLEAN) { delay = max(delay - SSASR_PACE_DOWN, 0); clean = 0; }
   }
 };
 
