@@ -92,6 +92,18 @@ __global__ void chain_de_fixup_kernel(float* de, const float* att, const float* 
 // stores it waits for, so a wave sleeps `delay` x 64 cycles before its first fetch and
 // adapts the delay to the producer stage: +12 when pieces were missing, -2 after 2 clean steps
 // (a decode loop has only ~50 steps to converge in).
+#ifndef SSASR_WPACE_UP
+#define SSASR_WPACE_UP 12
+#endif
+#ifndef SSASR_WPACE_CLEAN
+#define SSASR_WPACE_CLEAN 2
+#endif
+#ifndef SSASR_WPACE_DOWN
+#define SSASR_WPACE_DOWN 2
+#endif
+#ifndef SSASR_WPACE_INIT
+#define SSASR_WPACE_INIT 100
+#endif
 struct WavePacer {
   int delay, clean;
   __device__ __forceinline__ void sleep() const {
@@ -101,8 +113,8 @@ struct WavePacer {
 #ifdef SSASR_CHAIN_NO_PACE
     delay = 0; return;
 #endif
-    if (missed) { delay = min(delay + 12, 400); clean = 0; }
-    else if (++clean >= 2) { delay = max(delay - 2, 0); clean = 0; }
+    if (missed) { delay = min(delay + SSASR_WPACE_UP, 400); clean = 0; }
+    else if (++clean >= SSASR_WPACE_CLEAN) { delay = max(delay - SSASR_WPACE_DOWN, 0); clean = 0; }
   }
 };
 
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
   const int nb = n < B ? n : B - 1;                  // clamped utterance for the attention results
   const int ablk = q + 4 * wave;                     // this thread's 8 attention columns: 8 * ablk ..
 
-  WavePacer pacer{100, 0};
+  WavePacer pacer{SSASR_WPACE_INIT, 0};
   for (int i = 0; i < U; ++i) {
     const int t = U - 1 - i;
     f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
