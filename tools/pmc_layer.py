@@ -15,6 +15,6 @@ import torch
 import bench
 
 dev = torch.device('cuda', 0)
-bench.recurrence_roofline(dev, reps=1)
+bench.recurrence_roofline(dev, reps=int(os.environ.get('SSASR_ROOFLINE_REPS', '1')))   # 5 = what bench.py times
 bench.attention_roofline(dev, iters=4)
 torch.cuda.synchronize()
