@@ -537,22 +537,20 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
   const float* wih[2] = {w_ih_f, w_ih_r};
   if (!w_hh_f || !w_hh_r) return SSASR_EARG;
+  // Everything of `stream` is enqueued first -- the ranges' launches, an event behind each, the input
+  // gradient -- and only then the second stream's work: a range is ~150 us of GPU time on the short
+  // layers, less than the host needs to enqueue its seven weight-gradient launches, and a recurrence
+  // that waits for the host is time nothing hides (measured: 0.1 ms idle per layer on `stream`).
+  hipEvent_t done[8];
   for (int k = 0; k < nseg; ++k) {
     const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
     // the K-split kernel takes its weight slices straight from W_hh: no transposed copy
     rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
                                       ws_dc, w_hh_f, w_hh_r, armed);
     if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
-    hipEvent_t ev = overlap_event();
-    if (!ev) return (int)hipErrorOutOfMemory;
-    SSASR_HIP(hipEventRecord(ev, st));
-    SSASR_HIP(hipStreamWaitEvent(side, ev, 0));
-    // iterations [i0, i1) cover steps S - i1 .. S - i0 - 1 of the forward direction and i0 .. i1 - 1 of the reverse
-    if ((rc = wgrad_dir_range(0, S - i1, S - i0, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[0], dwhh[0], db[0], db2[0],
-                              side)))
-      return rc;
-    if ((rc = wgrad_dir_range(1, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], side)))
-      return rc;
+    done[k] = overlap_event();
+    if (!done[k]) return (int)hipErrorOutOfMemory;
+    SSASR_HIP(hipEventRecord(done[k], st));
   }
   const int64_t rows = S * N;
   for (int d = 0; d < 2 && dx; ++d) {        // input gradient (critical path: the layer below needs it)
@@ -563,6 +561,16 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     g.M = (int)rows; g.N = (int)I; g.K = (int)(4 * H);
     g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = d ? 1.f : 0.f; g.splitk = 1; g.batch = 1;
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
+  }
+  for (int k = 0; k < nseg; ++k) {
+    const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
+    SSASR_HIP(hipStreamWaitEvent(side, done[k], 0));
+    // iterations [i0, i1) cover steps S - i1 .. S - i0 - 1 of the forward direction and i0 .. i1 - 1 of the reverse
+    if ((rc = wgrad_dir_range(0, S - i1, S - i0, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[0], dwhh[0], db[0], db2[0],
+                              side)))
+      return rc;
+    if ((rc = wgrad_dir_range(1, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], side)))
+      return rc;
   }
   return SSASR_OK;
 }
