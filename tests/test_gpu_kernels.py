@@ -301,3 +301,38 @@ def test_frame_lengths():
     for i, l in enumerate(lens):
         x[i, l:] = 0
     assert ops.frame_lengths(x.to(dev())).cpu().tolist() == lens
+
+
+def test_first_layer_fused_input_projection_equals_gemm(monkeypatch):
+    """I = 80, H = 256: the forward recurrence's helper wave forms W_ih x + b itself
+    (rnn_kernels.h, KI); SSASR_NO_FUSED_INPUT=1 takes the GEMM.  Same MFMA products in a
+    different summation order: outputs and gradients agree to rounding."""
+    from ss_asr_amd import ops
+    torch.manual_seed(5)
+    N, S, I, H = 20, 70, 80, 256
+    x = (torch.randn(N, S + 3, I) * 0.5).to(dev())
+    lens = torch.tensor(sorted(torch.randint(S // 2, S + 1, (N,)).tolist(), reverse=True), dtype=torch.int32)
+    lens[0] = S
+    w = []
+    for _ in range(2):
+        w += [(torch.randn(4 * H, I) * I ** -0.5).to(dev()), (torch.randn(4 * H, H) * H ** -0.5).to(dev()),
+              (torch.randn(4 * H) * 0.1).to(dev()), (torch.randn(4 * H) * 0.1).to(dev())]
+    dy = (torch.randn(N, S, 2 * H) * 0.1).to(dev())
+    out = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv('SSASR_NO_FUSED_INPUT', raising=False)
+        else:
+            monkeypatch.setenv('SSASR_NO_FUSED_INPUT', '1')
+        xs = x.clone().requires_grad_(True)
+        ws = [t.clone().requires_grad_(True) for t in w]
+        y = ops.bilstm(xs, lens.to(dev()), S, True, tuple(ws))
+        y.backward(dy)
+        torch.cuda.synchronize()
+        out.append((y.detach(), xs.grad, [t.grad for t in ws]))
+    ops.check_persistent_status()
+    (ya, dxa, dwa), (yb, dxb, dwb) = out
+    assert float((ya - yb).abs().max()) < 2e-6
+    assert float((dxa - dxb).abs().max()) < 2e-6 * max(1.0, float(dxb.abs().max()))
+    for a, b in zip(dwa, dwb):
+        assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(b.abs().max()))
