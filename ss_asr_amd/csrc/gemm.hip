@@ -16,6 +16,7 @@
 // one 16-deep K step MFMA j (j = 0..3) consumes k = 4 * (lane >> 4) + j from
 // both operands, which lets a K-contiguous operand be fetched with a single
 // ds_read_b128 per 16x16 fragment.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -404,8 +405,23 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   const bool vecB = aligned16(g.B) && map_vec_ok(g.mb) && (g.sb % 4 == 0);
   // 128x128 tiles only when they still give every CU work.
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
-  if (big >= 256) return launch_tiles<128, 128>(g, vecA, vecB, st);
-  return launch_tiles<64, 64>(g, vecA, vecB, st);
+  if (const char* v = getenv("SSASR_GEMM_TILE")) {          // diagnostic: force a tile shape
+    if (atoi(v) == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
+    if (atoi(v) == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
+  }
+  if (big < 256) return launch_tiles<64, 64>(g, vecA, vecB, st);
+  // Both tile shapes run at 85-110 TF once the chip is full; what differs is how the LAST round of
+  // workgroups fills it.  Measured at K = 1024 (tools/gemm_tiles.py), in units of 150 us: 128 x 128
+  // tiles, two per CU -- a CU's pair of tiles costs 1.0, a single one 0.9 (0.63 when every CU has at
+  // most one); 64 x 64 tiles, fine grained -- 0.133 + 0.00052 per tile.  Take the cheaper.
+  if (g.splitk == 1) {
+    const int64_t n = (big + 255) / 256;
+    const double t128 = n == 1 ? 0.63 : 1.0 * (double)(n / 2) + 0.9 * (double)(n % 2);
+    const int64_t small = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch;
+    const double t64 = 0.133 + 0.00052 * (double)small;
+    if (t64 < t128) return launch_tiles<64, 64>(g, vecA, vecB, st);
+  }
+  return launch_tiles<128, 128>(g, vecA, vecB, st);
 }
 
 // C-ABI entry (include/ssasr.h).
