@@ -241,7 +241,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // therefore reserves dynamic LDS it never touches, so that its 30-38 KB + 118 KB leave no room for
     // a GEMM workgroup (36 KB) on the same CU: the GEMMs get the other CUs, the recurrence runs at
     // its standalone speed (+4-5 % on the train step).  SSASR_BPTT_SHARED_CU=1 turns it off.
-    static const int reserve = getenv("SSASR_BPTT_SHARED_CU") ? 0 : 118 * 1024;
+    static const int reserve = getenv("SSASR_BPTT_SHARED_CU") ? 0 : (getenv("SSASR_BPTT_RESERVE_KB") ? atoi(getenv("SSASR_BPTT_RESERVE_KB")) : 118) * 1024;
     static bool reserved = false;
     if (reserve && !reserved) {
       const void* fns[] = {reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<1, 1>),

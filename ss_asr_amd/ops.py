@@ -6,6 +6,8 @@ tensors, or without the shared object, raises.
 """
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -95,7 +97,12 @@ class ExchangeArena:
                 self.offsets.append(self.offsets[-1] + n)
             self.buf = torch.empty(self.offsets[-1], device=self.device, dtype=torch.float32)
             self.buf.view(torch.int32).fill_(_SENTINEL_I32)
-        return self.buf[self.offsets[slot]:self.offsets[slot] + self.sizes[slot]]
+            self.taken = set()
+        view = self.buf[self.offsets[slot]:self.offsets[slot] + self.sizes[slot]]
+        if slot in self.taken:          # a second pass over the same graph (retain_graph): arm it again
+            view.view(torch.int32).fill_(_SENTINEL_I32)
+        self.taken.add(slot)
+        return view
 
 
 def bilstm_exchange_floats(S, N, H):
@@ -682,19 +689,23 @@ class _CELoss(torch.autograd.Function):
         return dlogits, None
 
 
-_i32_cache = (None, None)
+_i32_cache = (None, None, None)      # (weak reference to the source tensor, its version, the int32 copy)
 
 
 def as_i32(t):
-    """int32 copy of an integer device tensor, remembered for the tensor it was made from: the
-    label matrix of a step is needed twice (teacher forcing and the loss)."""
+    """int32 copy of an integer device tensor, remembered for the tensor OBJECT it was made from
+    (weak reference + version counter, never an address: the next batch's labels may well be
+    allocated where the last batch's were): the label matrix of a step is needed twice, for
+    teacher forcing and for the loss."""
     global _i32_cache
     if t.dtype == torch.int32 and t.stride(-1) == 1:
         return t
-    key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
-    if _i32_cache[0] != key:
-        _i32_cache = (key, t.to(torch.int32).contiguous())
-    return _i32_cache[1]
+    ref, version, copy = _i32_cache
+    if ref is not None and ref() is t and version == t._version:
+        return copy
+    copy = t.to(torch.int32).contiguous()
+    _i32_cache = (weakref.ref(t), t._version, copy)
+    return copy
 
 
 def masked_ce_loss(logits, y, ans_len):

@@ -336,3 +336,22 @@ def test_first_layer_fused_input_projection_equals_gemm(monkeypatch):
     assert float((dxa - dxb).abs().max()) < 2e-6 * max(1.0, float(dxb.abs().max()))
     for a, b in zip(dwa, dwb):
         assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_label_copy_cache_follows_the_tensor_not_its_address():
+    """ops.as_i32 remembers the int32 copy of the step's label matrix (teacher forcing and loss
+    share it).  The next batch's labels are usually allocated where the last batch's were: the
+    cache must miss then."""
+    from ss_asr_amd import ops
+    y1 = torch.randint(1, 30, (8, 12), device=dev())
+    c1 = ops.as_i32(y1)
+    assert ops.as_i32(y1) is c1                      # same object, same version: remembered
+    addr = y1.data_ptr()
+    del y1
+    y2 = torch.randint(1, 30, (8, 12), device=dev())  # the caching allocator hands the block out again
+    c2 = ops.as_i32(y2)
+    assert torch.equal(c2.long(), y2)
+    if y2.data_ptr() == addr:
+        assert c2 is not c1
+    y2[0, 0] = 31                                     # in-place edit bumps the version
+    assert int(ops.as_i32(y2)[0, 0]) == 31
