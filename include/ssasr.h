@@ -252,8 +252,8 @@ int ssasr_decoder_wgrad(const ssasr_decoder* d, const ssasr_decoder_grads* g, in
  * logits [B][U][V]; y int32 [B][y_cols] with row stride y_ld (0 = padding):
  * the label of step t is y[b][t + 1] (src/trainer.py:427, the <sos> column is
  * skipped) and a row's denominator is count(y[b][:] != 0) (src/trainer.py:431).
- * loss is one float; lse (B * U + 2 * B floats: log-sum-exp per step, then the
- * per-row terms, then the denominators) is saved for backward. */
+ * loss is one float; lse (B * U + 9 * B floats: log-sum-exp per step, then eight
+ * partial sums per row, then the denominators) is saved for backward. */
 int ssasr_ce_loss_fwd(const float* logits, const int32_t* y, int64_t y_ld, int64_t y_cols, int64_t B,
                       int64_t U, int64_t V, float* lse, float* loss, void* stream);
 int ssasr_ce_loss_bwd(const float* logits, const int32_t* y, int64_t y_ld, const float* lse,

@@ -8,17 +8,19 @@ namespace {
 
 // One workgroup per utterance, one wave per (b, t) row of V logits.
 // lse[b*U+t] = logsumexp(row); tail[b] = sum_t tok(b,t) / denom[b].
-// One block per utterance: log-sum-exp of every step, the row's summed token loss and its
-// denominator count(y != 0).  Labels are read in place: step t's label is y[b][t + 1].
+// CE_G blocks per utterance (steps t = g, g + CE_G, ...): log-sum-exp of every step, the block's
+// share of the row's summed token loss (tail[b][g]) and, from block 0, the row's denominator
+// count(y != 0).  Labels are read in place: step t's label is y[b][t + 1].
+constexpr int CE_G = 8;
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const int32_t* y, int64_t y_ld,
                                                      int y_cols, int U, int V, float* lse, float* tail,
                                                      float* denom) {
   __shared__ float sm[4];
   __shared__ int sn[4];
-  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x, g = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int32_t* yr = y + (int64_t)b * y_ld;
   float tok = 0.f;
-  for (int t = wave; t < U; t += 4) {
+  for (int t = g + CE_G * wave; t < U; t += 4 * CE_G) {
     const float* row = logits + ((int64_t)b * U + t) * V;
     float m = -INFINITY;
     for (int v = lane; v < V; v += 64) m = fmaxf(m, row[v]);
@@ -34,22 +36,27 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const 
     }
   }
   int cnt = 0;
-  for (int j = threadIdx.x; j < y_cols; j += 256) cnt += yr[j] != 0 ? 1 : 0;
+  if (g == 0)
+    for (int j = threadIdx.x; j < y_cols; j += 256) cnt += yr[j] != 0 ? 1 : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
   if (lane == 0) { sm[wave] = tok; sn[wave] = cnt; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float dn = (float)((sn[0] + sn[1]) + (sn[2] + sn[3]));
-    denom[b] = dn;
-    tail[b] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / dn;
+    if (g == 0) denom[b] = (float)((sn[0] + sn[1]) + (sn[2] + sn[3]));
+    tail[b * CE_G + g] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
   }
 }
 
-__global__ void ce_mean_kernel(const float* tail, int B, float* loss) {
+// loss = mean_b( (sum of the row's token losses, in block order) / denom[b] )   -- deterministic
+__global__ void ce_mean_kernel(const float* tail, const float* denom, int B, float* loss) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += tail[b];
+    for (int b = 0; b < B; ++b) {
+      float r = 0.f;
+      for (int g = 0; g < CE_G; ++g) r += tail[b * CE_G + g];
+      s += r / denom[b];
+    }
     *loss = s / (float)B;
   }
 }
@@ -196,9 +203,9 @@ extern "C" int ssasr_ce_loss_fwd(const float* logits, const int32_t* y, int64_t 
   if (!logits || !y || !lse || !loss || B <= 0 || U <= 0 || V <= 0 || y_cols < U + 1 || y_ld < y_cols)
     return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, st, logits, y, y_ld, (int)y_cols, (int)U, (int)V,
-                     lse, lse + B * U, lse + B * U + B);
-  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, st, lse + B * U, (int)B, loss);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)B, CE_G), dim3(256), 0, st, logits, y, y_ld, (int)y_cols, (int)U,
+                     (int)V, lse, lse + B * U, lse + B * U + B * CE_G);
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, st, lse + B * U, lse + B * U + B * CE_G, (int)B, loss);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
@@ -209,7 +216,7 @@ extern "C" int ssasr_ce_loss_bwd(const float* logits, const int32_t* y, int64_t 
   if (!logits || !y || !lse || !dloss || !dlogits || B <= 0 || U <= 0 || V <= 0 || y_ld < U + 1) return SSASR_EARG;
   const int64_t n = B * U * V;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits,
-                     y, y_ld, lse + B * U + B, lse, dloss, (int)B, (int)U, (int)V, dlogits);
+                     y, y_ld, lse + B * U + B * CE_G, lse, dloss, (int)B, (int)U, (int)V, dlogits);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }

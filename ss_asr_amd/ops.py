@@ -670,7 +670,7 @@ class _CELoss(torch.autograd.Function):
         _need_gpu(logits, y32)
         logits = _f32c(logits)
         B, U, V = logits.shape
-        lse = torch.empty(B * U + 2 * B, device=logits.device, dtype=torch.float32)
+        lse = torch.empty(B * U + 9 * B, device=logits.device, dtype=torch.float32)
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
         check(lib.ssasr_ce_loss_fwd(_p(logits), _p(y32), y32.stride(0), y32.shape[1], B, U, V, _p(lse),
                                     _p(loss), _stream()), 'ssasr_ce_loss_fwd')
