@@ -68,8 +68,6 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
  * N <= 128): gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats of exchange
  * workspace (contents irrelevant on entry), sync_ws int32[8] zero on entry; NULL = one
  * launch per step. */
-/* Floats of the forward recurrence's exchange ring `hx` (0: the shape has no persistent form). */
-int64_t ssasr_bilstm_fwd_hx_floats(int64_t S, int64_t N, int64_t H);
 int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);
 /* Floats of the K-split BPTT's exchange ring alone (dirs = 1 or 2 directions), 0 when the
  * shape or the environment does not take that form.  A caller that arms several exchange

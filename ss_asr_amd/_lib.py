@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 9
+ABI_VERSION = 8
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -68,7 +68,6 @@ SIGNATURES = {
     'ssasr_clip_adadelta_ws': (I64, [I64]),
     'ssasr_clip_adadelta': (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, P, P, I32, P]),
     'ssasr_bilstm_bwd_gx_floats': (I64, [I64, I64, I64]),
-    'ssasr_bilstm_fwd_hx_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_bwd_ring_floats': (I64, [I64, I64, I64, I64]),
     'ssasr_exchange_armed': (I32, [I32]),
     'ssasr_decoder_bwd_chain_floats': (I64, [I64] * 6),

@@ -106,7 +106,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     if (const char* v = getenv("SSASR_FWD_NB")) nb = atoi(v) == 1 ? 1 : 2;
     const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
     const bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
-                      (H / 4) * 2 * chunks <= 512 && FWD_RING * Np * H * 4 < (1ll << 31) &&   // <= 2 workgroups per CU
+                      (H / 4) * 2 * chunks <= 512 && S * Np * H * 4 < (1ll << 31) &&   // <= 2 workgroups per CU
                       aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
                       ys_n % 4 == 0 && !getenv("SSASR_NO_PERSISTENT");
     // status words are zero on entry (caller's contract); only the arrival counters of the
@@ -135,7 +135,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       // exchange by sentinel (default) or by arrival counter (SSASR_PERSISTENT_COUNTER=1, for A/B)
       const bool sentinel = getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
       if (sentinel && !armed)
-        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * FWD_RING * Np * H), st));
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * Np * H), st));
 #define SSASR_FWD_LAUNCH(K, SEN, NBT) \
       hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<K, SEN, NBT>), pgrid, pblock, 0, st, p)
 #define SSASR_FWD_PICK(SEN, NBT)                                    \
@@ -173,12 +173,6 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
                                   float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
                                   float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
                                   int accumulate, void* stream);
-
-// Exchange workspace of the persistent forward recurrence (0: no persistent form for the shape)
-extern "C" int64_t ssasr_bilstm_fwd_hx_floats(int64_t S, int64_t N, int64_t H) {
-  if (S <= 0 || N <= 0 || N > 128 || H % 64 != 0) return 0;
-  return 2 * FWD_RING * ((N + 7) & ~(int64_t)7) * H;
-}
 
 // Exchange workspace of the persistent BPTT: the larger of the gather form's
 // per-step image and the K-split form's ring (0: no persistent form for this shape).

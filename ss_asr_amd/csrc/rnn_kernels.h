@@ -358,7 +358,7 @@ struct EncPersist {
   float* gates;          // [2][S*N][4H]
   float* cs;             // [2][S*N][H]
   float* hs;             // [2][S*N][H]   row-major copy (operand of dW_hh)
-  float* hx;             // [2][FWD_RING][H/4][Np][4] exchange ring, Np = N rounded up to 8
+  float* hx;             // [2][S][H/4][Np][4] exchange image, Np = N rounded up to 8
   float* y;
   const int32_t* lens;
   unsigned* cnt;         // [2][chunks] arrival counters, zero at launch
@@ -382,7 +382,6 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 constexpr unsigned PERSIST_MAX_SPINS = 1u << 20;   // ~ a second of polling, then give up for good
 
 constexpr unsigned PERSIST_SENTINEL = 0x7FC0DEADu;   // a NaN: h = o * tanh(c) can never produce it
-constexpr int FWD_RING = 8;                          // steps of the forward recurrence's exchange ring
 
 // SENTINEL = true: no arrival counter.  The host pre-fills the exchange image
 // with PERSIST_SENTINEL; a consumer first polls one 16-byte piece per producer
@@ -452,14 +451,8 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   const int64_t rows = (int64_t)S * N;
   unsigned* cnt = e.cnt + d * gridDim.z + chunk;
   float* gbase = e.gates + (int64_t)d * rows * 4 * H;
-  // The exchange image is a RING of FWD_RING steps (slot = iteration % FWD_RING), not one slot per
-  // step: 2 MB that stay in the caches instead of S x 64 KB of fresh addresses (the step time used
-  // to grow with the layer length: 1.56 / 1.67 / 1.88 us at S = 100 / 400 / 800).  A producer re-arms
-  // its OWN 16-byte pieces of the slot of three steps ago: having verified its loads of step i it
-  // knows that every workgroup published step i - 1, i.e. finished reading the slot of step i - 2;
-  // the same lanes rewrite that address five steps later, in program order.
-  const size_t xbytes = (size_t)FWD_RING * Np * H * sizeof(float);
-  float* xbase = e.hx + (int64_t)d * FWD_RING * Np * H;
+  const size_t xbytes = (size_t)S * Np * H * sizeof(float);
+  float* xbase = e.hx + (int64_t)d * S * Np * H;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)xbytes, 0x00020000);
   const int u = 4 * tile + q;                   // epilogue lanes and helper lanes: unit u, column n0 + 16 * bt + r
 
@@ -595,7 +588,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
     for (int t = 0; t < NB; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     SSASR_PTRACE(i, 0);
     if (i > 0) {
-      const unsigned sbase = (unsigned)(((i - 1) % FWD_RING) * (Np * H * 4));   // slot of the previous step, in bytes
+      const unsigned sbase = (unsigned)((int64_t)sp * Np * H * 4);   // step offset in bytes
       __syncthreads();                                // released by the helper wave
       SSASR_PTRACE(i, 2);
       float4 b[KPW][NB];
@@ -673,12 +666,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
         u32x4 pv = {__builtin_bit_cast(unsigned, hv.x), __builtin_bit_cast(unsigned, hv.y),
                     __builtin_bit_cast(unsigned, hv.z), __builtin_bit_cast(unsigned, hv.w)};
         __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
-                                               (int)((i % FWD_RING) * (Np * H * 4)), 16);
-        if (SENTINEL && i >= 3) {        // re-arm this workgroup's pieces of the slot of step i - 3
-          const u32x4 fill = {PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL};
-          __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)((tile * Np + n0 + lane) * 16),
-                                                 (int)(((i - 3) % FWD_RING) * (Np * H * 4)), 16);
-        }
+                                               (int)((int64_t)s * Np * H * 4), 16);
       }
       SSASR_PTRACE(i, 7);
       if (!SENTINEL) {

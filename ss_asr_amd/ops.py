@@ -109,7 +109,8 @@ def bilstm_exchange_floats(S, N, H):
     """(forward image floats, BPTT ring floats) of a BiLSTM layer; 0 where the layer has no
     persistent form that an ExchangeArena can serve."""
     lib = _lib.load()
-    return int(lib.ssasr_bilstm_fwd_hx_floats(S, N, H)), int(lib.ssasr_bilstm_bwd_ring_floats(S, N, H, 2))
+    hx = 2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4 if N <= 128 and H % 64 == 0 else 0
+    return hx, int(lib.ssasr_bilstm_bwd_ring_floats(S, N, H, 2))
 
 
 def upload_i32(device, *seqs):
@@ -233,7 +234,7 @@ class _BiLSTM(torch.autograd.Function):
         cs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         hs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         # workspaces of the persistent recurrence (exchange image + counters)
-        hx_floats = int(lib.ssasr_bilstm_fwd_hx_floats(S, N, H))
+        hx_floats = 2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4 if N <= 128 and H % 64 == 0 else 0
         if slots is not None and slots[1] is not None and hx_floats:
             hx = slots[0].take(slots[1])              # armed with the arena's one fill
             assert hx.numel() >= hx_floats
