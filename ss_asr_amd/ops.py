@@ -254,6 +254,10 @@ class _BiLSTM(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
+        if getattr(ctx, 'consumed', False):
+            raise RuntimeError('bilstm: the saved gates were overwritten with their derivatives by the first '
+                               'backward pass; a second pass over the same graph (retain_graph) is not supported')
+        ctx.consumed = True
         x, lens, gates, cs, hs, *w = ctx.saved_tensors
         S, N, I, H, xs_s, xs_n, ys_s, ys_n, batch_first = ctx.geom
         dy = _f32c(dy)
@@ -538,6 +542,10 @@ class _DecoderLoop(torch.autograd.Function):
         lib = _lib.load()
         if dlogits is None:
             raise RuntimeError('decoder_loop: no gradient reached the logits')
+        if getattr(ctx, 'consumed', False):
+            raise RuntimeError('decoder_loop: the saved gates were overwritten with their derivatives by the '
+                               'first backward pass; a second pass over the same graph is not supported')
+        ctx.consumed = True
         d = ctx.dec
         feat, comp, enc_len, teacher, modes, uniforms, params, bufs = ctx.keep
         pw = dict(zip(_DEC_PARAMS, params))

@@ -355,3 +355,23 @@ def test_label_copy_cache_follows_the_tensor_not_its_address():
         assert c2 is not c1
     y2[0, 0] = 31                                     # in-place edit bumps the version
     assert int(ops.as_i32(y2)[0, 0]) == 31
+
+
+def test_second_backward_over_the_same_graph_is_refused():
+    """The layers overwrite their saved gates with the gate derivatives (no second copy of the
+    largest activation): a second backward pass must fail loudly, not return garbage."""
+    from ss_asr_amd import ops
+    torch.manual_seed(2)
+    N, S, I, H = 4, 6, 16, 64
+    x = torch.randn(N, S, I, device=dev(), requires_grad=True)
+    w = []
+    for _ in range(2):
+        w += [torch.randn(4 * H, I, device=dev(), requires_grad=True) * 0.1,
+              torch.randn(4 * H, H, device=dev(), requires_grad=True) * 0.1,
+              torch.zeros(4 * H, device=dev(), requires_grad=True), torch.zeros(4 * H, device=dev(), requires_grad=True)]
+    w = [t.detach().requires_grad_(True) for t in w]
+    lens = torch.full((N,), S, dtype=torch.int32, device=dev())
+    y = ops.bilstm(x, lens, S, True, tuple(w)).sum()
+    y.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='second pass'):
+        y.backward()
