@@ -301,3 +301,37 @@ def test_backward_is_reproducible_with_overlapped_streams(golden):
                 worst = (dev, n)
     ops.check_persistent_status()
     assert worst[0] < 5e-5, worst
+
+
+@pytest.mark.parametrize('frames,chars', [([16], [2]),                       # one utterance, two encoder frames
+                                          ([9], [1]),                        # T' = 1: a single attention frame
+                                          (list(range(120, 54, -2)), [3 + k % 9 for k in range(33)]),   # 33 > 32 utterances
+                                          ([200, 8], [12, 1])])              # very ragged pair
+def test_train_step_edge_shapes_match_the_oracle(frames, chars):
+    """Batch sizes and lengths at the edges of the persistent forms (one utterance; an encoder
+    output of one or two frames; more utterances than the 32 the persistent decode loop and the
+    two-chunk recurrences take; a pair whose second utterance ends after one encoder frame): one
+    train step at the full layer sizes against the CPU oracle on the same seeded weights."""
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.engine import ASRTrainStep, label_geometry
+    from ss_asr_amd.synthetic import make_batch
+    from ss_asr_amd import ops
+    dims = (50, 256, 256, 128, 80)
+    x, y, lens = make_batch(np.array(frames), np.array(chars), 80, seed=5)
+    _, ans_len = label_geometry(y)
+    torch.manual_seed(0)
+    ref = lo.OracleASR(*dims, 1.0)
+    lo.seeded_weights(ref, 13)
+    ropt = lo.make_optimizer(ref)
+    ref_loss, ref_norm = lo.train_step(ref, ropt, x, y)
+    model = ASR(*dims, 1.0)
+    lo.seeded_weights(model, 13)
+    model = model.to('cuda:0')
+    step = ASRTrainStep(model)
+    random.seed(0)
+    loss = float(step(x.cuda(), y.cuda(), lens, ans_len))
+    norm, skipped = step.optim.poll(wait=True)
+    ops.check_persistent_status()
+    assert not skipped
+    assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)
+    assert abs(norm - ref_norm) < 2e-3 * max(1.0, ref_norm), (norm, ref_norm)
