@@ -379,6 +379,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), so consecutive unit
+// tiles would sit on 8 different XCDs -- but consecutive tiles share the 128-byte lines of every
+// row-major array they read and write in 16..64-byte pieces (saved gates, c, h, y).  With the tiles
+// of one line on ONE XCD its L2 merges their partial writes and serves their partial reads once.
+// Placement is a speed matter only (MI355X_MICROARCH.md): any mapping is correct.
+__device__ __forceinline__ int xcd_grouped_tile(int bx, int ntile) {
+#ifdef SSASR_NO_TILE_GROUPING
+  return bx;
+#else
+  return (ntile & 7) ? bx : (bx & 7) * (ntile >> 3) + (bx >> 3);
+#endif
+}
+
 constexpr unsigned PERSIST_MAX_SPINS = 1u << 20;   // ~ a second of polling, then give up for good
 
 constexpr unsigned PERSIST_SENTINEL = 0x7FC0DEADu;   // a NaN: h = o * tanh(c) can never produce it
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   if (tid == 0) missed = 0;
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
+  const int tile = xcd_grouped_tile(blockIdx.x, gridDim.x), d = blockIdx.y, chunk = blockIdx.z;
   const int S = e.S, N = e.N, H = e.H;
   const int n0 = chunk * 16 * NB;
   const int Np = (N + 7) & ~7;                 // image columns: 128-byte lines never shared by two tiles
@@ -1181,7 +1194,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   if (tid == 0) missed = 0;
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z / HV, half = blockIdx.z % HV;
+  const int tile = xcd_grouped_tile(blockIdx.x, gridDim.x), d = blockIdx.y, chunk = blockIdx.z / HV, half = blockIdx.z % HV;
   const int nchunk = gridDim.z / HV;
   const int S = e.S, N = e.N, H = e.H;
   const int i0 = e.i0, i1 = e.i1 > 0 ? e.i1 : S;    // this launch's iterations
