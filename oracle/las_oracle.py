@@ -160,7 +160,11 @@ class OracleASR(nn.Module):
             n = cell.bias_ih.numel()
             cell.bias_ih.data[n // 4:n // 2].fill_(1.0)
 
-    def forward(self, audio_feature, decode_step, teacher=None, state_len=None):
+    def forward(self, audio_feature, decode_step, teacher=None, state_len=None, forced_chars=None):
+        """forced_chars ([U+1, B] int64, test hook, not in the reference): the character fed
+        to step t + 1 is forced_chars[t + 1] whatever the step's mode, so that a loop whose
+        sampled characters were drawn elsewhere (the HIP kernel's inverse-CDF draw) can be
+        replayed and each draw checked against this model's logits (inverse_cdf_bounds)."""
         feat, enc_len = self.encoder(audio_feature, state_len)            # asr.py:63
         emb_teacher = self.embed(teacher) if teacher is not None else None
         batch = audio_feature.shape[0]
@@ -172,7 +176,9 @@ class OracleASR(nn.Module):
             alpha, ctx = self.attention(self.decoder.state_list[0], feat, enc_len)
             out = self.decoder(torch.cat([last, ctx], dim=-1))
             cur = self.char_trans(out)
-            if emb_teacher is not None:
+            if forced_chars is not None:
+                last = self.embed(forced_chars[t + 1])
+            elif emb_teacher is not None:
                 if random.random() <= self.tf_rate:                       # asr.py:94
                     last = emb_teacher[:, t + 1, :]
                 else:
@@ -184,6 +190,17 @@ class OracleASR(nn.Module):
             logits.append(cur)
             atts.append(alpha.detach())
         return enc_len, torch.stack(logits, dim=1), torch.stack(atts, dim=1)
+
+
+def inverse_cdf_bounds(logits_row):
+    """Cumulative unnormalised probabilities of softmax(logits_row) in float32, summed in
+    index order: (run [V], total).  A draw with uniform u picks the first v with
+    run[v] > u * total -- the law of Categorical(softmax(logits)).sample() (src/asr.py:96-97)
+    spelled out for a caller-supplied uniform."""
+    l = np.asarray(logits_row, dtype=np.float32)
+    p = np.exp(l - l.max()).astype(np.float32)
+    run = np.cumsum(p, dtype=np.float32)
+    return run, float(run[-1])
 
 
 def masked_ce_loss(logits, y, ans_len):

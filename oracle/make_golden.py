@@ -59,13 +59,19 @@ def ref_loss(logits, y, ans_len):
 
 
 def capture(asr_mod, name, dims, lens, y_lens, tf_rate, seed, weights_seed=None,
-            teacher=True, pad_to=None, keep='all', extra_decode=0):
+            teacher=True, pad_to=None, keep='all', extra_decode=0, xy=None, recipe=None):
+    """xy: (x, y) made by the caller instead of synth_batch; with `recipe` (a dict of
+    integers that lets a test rebuild the same x, y) the fixture carries the recipe and
+    not the 8 MB input."""
     seed_all(seed)
     model = asr_mod.ASR(*dims, tf_rate)
     if weights_seed is not None:
         seeded_weights(model, weights_seed)
     rng = np.random.default_rng(seed + 1000)
-    x, y = synth_batch(rng, lens, dims[4], y_lens, dims[0])
+    if xy is not None:
+        x, y = xy
+    else:
+        x, y = synth_batch(rng, lens, dims[4], y_lens, dims[0])
     if pad_to is not None:       # dataset-wide zero padding beyond the batch max
         x = torch.cat([x, x.new_zeros(x.shape[0], pad_to - x.shape[1], x.shape[2])], 1)
     ans_len = int(max((y != 0).sum(-1) + 1)) - 1
@@ -96,11 +102,21 @@ def capture(asr_mod, name, dims, lens, y_lens, tf_rate, seed, weights_seed=None,
     out = dict(dims=np.array(dims), tf_rate=np.float64(tf_rate), seed=np.int64(seed),
                weights_seed=np.int64(-1 if weights_seed is None else weights_seed),
                teacher=np.int64(teacher), rng_seed=np.int64(seed + 7),
-               x=x.numpy(), y=y.numpy(), lens=np.array(lens), ans_len=np.int64(ans_len),
+               y=y.numpy(), lens=np.array(lens), ans_len=np.int64(ans_len),
                decode_steps=np.int64(steps),
                enc_len=np.array(enc_len), logits=logits.detach().numpy(),
-               att=att.numpy(), loss=np.float64(loss.item()),
+               loss=np.float64(loss.item()),
                grad_norm=np.float64(float(grad_norm)))
+    if recipe is None:
+        out['x'] = x.numpy()
+        out['att'] = att.numpy()
+    else:
+        for k, v in recipe.items():
+            out['recipe_' + k] = np.int64(v)
+        # input: a checksum instead of the tensor; attention map: every fourth utterance
+        out['x_abs_sum'] = np.float64(x.double().abs().sum().item())
+        out['att_rows'] = np.arange(0, att.shape[0], 4)
+        out['att'] = att[::4].numpy()
     names = list(grads.keys())
     out['param_names'] = np.array(names)
     out['grad_norms'] = np.array([grads[k].double().norm().item() for k in names])
@@ -129,9 +145,12 @@ def capture(asr_mod, name, dims, lens, y_lens, tf_rate, seed, weights_seed=None,
         name, loss.item(), float(grad_norm), enc_len[:6], os.path.getsize(path) / 1024))
 
 
-def main():
+def main(only=None):
     os.makedirs(OUT, exist_ok=True)
     asr_mod = import_reference()
+    if only:
+        real = capture
+        globals()['capture'] = lambda mod, name, *a, **k: real(mod, name, *a, **k) if name in only else None
     small = (50, 32, 32, 16, 12)         # output, enc H, dec H, mlp, feat
     full = (50, 256, 256, 128, 80)       # conf/default.yaml:6-9 with feature_dim 80
     capture(asr_mod, 'small_tf1', small, [64, 56, 48, 40], [10, 7, 5, 3], 1.0, 1)
@@ -151,7 +170,17 @@ def main():
     ylens16 = np.random.default_rng(10).integers(10, 41, size=16).tolist()
     capture(asr_mod, 'full_b16_t400', full, lens16, ylens16, 1.0, 7,
             weights_seed=12, keep='compact')
+    # BASELINE.json configs[1] at its own size: the batches bench.py times (its longest bucket,
+    # 32 utterances x 800 frames, and its median bucket), teacher forced so that the decode loop is
+    # deterministic.  The fixture carries the recipe of the batch, not its 8 MB of frames.
+    sys.path.insert(0, os.path.dirname(HERE))
+    from ss_asr_amd.synthetic import config2_batches
+    for name, pick, seed, wseed in (('bench_b32_t800', 0, 8, 14), ('bench_b32_median', 4, 9, 15)):
+        x, y, lens = config2_batches(8, batch_size=32, feat_dim=80, seed=1)[pick]
+        ylens = [int(v) - 1 for v in (y != 0).sum(-1)]
+        capture(asr_mod, name, full, lens, ylens, 1.0, seed, weights_seed=wseed, keep='compact',
+                xy=(x, y), recipe=dict(n_batches=8, pick=pick, batch_size=32, corpus_seed=1))
 
 
 if __name__ == '__main__':
-    main()
+    main(set(sys.argv[1:]))         # optional: names of the fixtures to (re)generate

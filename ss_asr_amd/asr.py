@@ -245,7 +245,7 @@ class ASR(nn.Module):
         # False: the attention map stays on the device (ASRTrainStep sets this around a train step)
         self.att_on_host = True
         self.att_event = None
-        self.last_chars = None
+        self.last_chars = self.last_modes = self.last_uniforms = None
         self.init_parameters()
 
     def init_parameters(self):
@@ -304,7 +304,9 @@ class ASR(nn.Module):
                                               modes_dev=modes_dev if decode_step else None,
                                               psi=(self.attention.psi.weight, self.attention.psi.bias),
                                               slots=dec_slots)
-        self.last_chars = chars
+        # what the loop was driven by: characters fed to each step [U+1, B], the per-step modes
+        # (0 teacher, 1 sample, 2 argmax) and the uniforms of the sampled steps [U, B] or None
+        self.last_chars, self.last_modes, self.last_uniforms = chars, modes, uniforms
         if not self.att_on_host:
             host = att.detach()         # left on the device (train steps never look at it)
         elif self.training and self.async_att:

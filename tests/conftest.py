@@ -33,3 +33,25 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     return load
+
+
+def fixture_xy(fx):
+    """(x, y) float32 / int64 CPU tensors of a golden fixture: stored in it, or rebuilt from
+    the recipe it carries (the bench-shape fixtures hold the recipe of their synthetic batch
+    instead of 8 MB of frames; `x_abs_sum` guards the rebuild)."""
+    import numpy as np
+    import torch
+    if 'x' in fx.files:
+        return torch.from_numpy(fx['x']), torch.from_numpy(fx['y'])
+    from ss_asr_amd.synthetic import config2_batches
+    x, y, lens = config2_batches(int(fx['recipe_n_batches']), batch_size=int(fx['recipe_batch_size']),
+                                 feat_dim=int(fx['dims'][4]), seed=int(fx['recipe_corpus_seed']))[int(fx['recipe_pick'])]
+    assert lens == [int(v) for v in fx['lens']]
+    assert np.array_equal(y.numpy(), fx['y'])
+    assert abs(float(x.double().abs().sum()) - float(fx['x_abs_sum'])) < 1e-6 * float(fx['x_abs_sum'])
+    return x, y
+
+
+def fixture_att(fx, att):
+    """The rows of an attention map [B, U, T'] that the fixture holds (all, or `att_rows`)."""
+    return att[fx['att_rows']] if 'att_rows' in fx.files else att

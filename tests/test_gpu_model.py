@@ -10,8 +10,13 @@ import pytest
 import torch
 
 import las_oracle as lo
+from conftest import fixture_att, fixture_xy
 
 pytestmark = pytest.mark.gpu
+
+# BASELINE.json configs[1] at its own size: bench.py's longest (32 x 800 frames, 81 label steps:
+# four BPTT segments, two-chunk recurrences, the 32-utterance persistent decode loop) and median bucket
+BENCH_SHAPES = ['bench_b32_t800', 'bench_b32_median']
 
 
 def build(fx):
@@ -30,8 +35,7 @@ def build(fx):
 
 def forward(fx, model):
     from ss_asr_amd import ops
-    x = torch.from_numpy(fx['x']).cuda()
-    y = torch.from_numpy(fx['y']).cuda()
+    x, y = (t.cuda() for t in fixture_xy(fx))
     lens = [int(v) for v in fx['lens']]
     assert ops.frame_lengths(x).cpu().tolist() == lens
     ans_len = int(fx['ans_len'])
@@ -44,7 +48,7 @@ def forward(fx, model):
 
 
 @pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'small_greedy',
-                                  'full_b4', 'full_b16_t400'])
+                                  'full_b4', 'full_b16_t400'] + BENCH_SHAPES)
 def test_forward_matches_reference(golden, name):
     fx = golden(name)
     model = build(fx)
@@ -60,13 +64,19 @@ def test_forward_matches_reference(golden, name):
         if 'act_' + n in fx.files:
             np.testing.assert_allclose(v.cpu().numpy(), fx['act_' + n], atol=2e-5, rtol=0,
                                        err_msg=n)
-    np.testing.assert_allclose(att.numpy(), fx['att'], atol=2e-6, rtol=0)
+        elif 'act_' + n + '_sample' in fx.files:      # compact fixtures: a strided sample and a checksum
+            flat = v.reshape(-1)
+            got = flat[::max(1, flat.numel() // 512)][:512].cpu().numpy()
+            np.testing.assert_allclose(got, fx['act_' + n + '_sample'], atol=2e-5, rtol=0, err_msg=n)
+            ref_sum = float(fx['act_' + n + '_abs_sum'])
+            assert abs(float(flat.double().abs().sum()) - ref_sum) < 2e-5 * ref_sum, n
+    np.testing.assert_allclose(fixture_att(fx, att.numpy()), fx['att'], atol=2e-6, rtol=0)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), fx['logits'], atol=5e-5, rtol=0)
     assert abs(float(loss) - float(fx['loss'])) < 1e-4
 
 
 @pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'full_b4',
-                                  'full_b16_t400'])
+                                  'full_b16_t400'] + BENCH_SHAPES)
 def test_backward_and_solver_step_match_reference(golden, name):
     from ss_asr_amd.optim import FlatParameters, FusedAdadelta
     fx = golden(name)
@@ -150,6 +160,72 @@ def test_sampled_steps_follow_the_categorical_law():
     top = int(torch.argmax(probs))
     rate = counts[top].item() / counts.sum().item()
     assert abs(rate - probs[top].item()) < 0.25
+
+
+@pytest.mark.parametrize('dims,frames,chars', [
+    ((50, 256, 256, 128, 80), [168, 160, 152, 120, 96, 90, 64, 40], [14, 12, 12, 9, 8, 7, 5, 3]),   # persistent loop
+    ((50, 32, 32, 16, 12), [64, 56, 48, 40], [10, 7, 5, 3])])                                     # per-step kernels
+def test_sampled_steps_match_the_oracle_draw(dims, frames, chars):
+    """The sampled branch of the decode loop (src/asr.py:94-98) against the oracle.  The kernel
+    draws by inverse CDF from caller-visible uniforms, so every draw can be checked exactly: the
+    oracle replays the loop on the characters the kernel fed (forced_chars), and for every
+    sampled (step, utterance) the kernel's character c must satisfy run[c-1] <= u * total <
+    run[c] on the ORACLE's logits, up to a CDF-boundary tolerance of 1e-5 * total (fp32 rounding
+    of the cumulative sums); teacher-forced steps must feed the label.  Logits, loss and the
+    gradient norm of that tf_rate 0.5 pass then have to match the oracle's."""
+    from ss_asr_amd import ops
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.optim import FlatParameters
+    from ss_asr_amd.synthetic import make_batch
+    x, y, lens = make_batch(np.array(frames), np.array(chars), dims[4], seed=17)
+    ans_len = max(lo.label_lengths(y)) - 1
+    torch.manual_seed(0)
+    ref = lo.OracleASR(*dims, 0.5)
+    lo.seeded_weights(ref, 31)
+    model = ASR(*dims, 0.5)
+    lo.seeded_weights(model, 31)
+    model = model.to('cuda:0')
+    flat = FlatParameters(model)
+    flat.zero_grad()
+    random.seed(123)
+    torch.manual_seed(123)
+    _, logits, _ = model(x.cuda(), ans_len, teacher=y.cuda(), state_len=lens)
+    loss = ops.masked_ce_loss(logits, y.cuda(), ans_len)
+    loss.backward()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    ops.check_persistent_status()
+    modes = list(model.last_modes)
+    random.seed(123)
+    assert modes == [0 if random.random() <= 0.5 else 1 for _ in range(ans_len)]   # the reference's coin flips
+    assert 1 in modes and 0 in modes
+    fed = model.last_chars.cpu().long()                     # [U + 1, B]
+    uni = model.last_uniforms.cpu().numpy()                 # [U, B]
+
+    _, ref_logits, _ = ref(x, ans_len, teacher=y, state_len=lens, forced_chars=fed)
+    ref_loss = lo.masked_ce_loss(ref_logits, y, ans_len)
+    ref_loss.backward()
+    rl = ref_logits.detach().numpy()
+    assert (fed[0] == 0).all()
+    exact = total = 0
+    for t, mode in enumerate(modes):
+        for b in range(len(frames)):
+            c = int(fed[t + 1, b])
+            if mode == 0:
+                assert c == int(y[b, t + 1]), (t, b)
+                continue
+            run, tot = lo.inverse_cdf_bounds(rl[b, t])
+            target = float(uni[t, b]) * tot
+            lo_edge = float(run[c - 1]) if c > 0 else 0.0
+            assert lo_edge - 1e-5 * tot <= target < float(run[c]) + 1e-5 * tot, (t, b, c, target, lo_edge, float(run[c]))
+            total += 1
+            exact += int(np.argmax(run > np.float32(target))) == c
+    assert total > 0 and exact >= total - 1, (exact, total)        # at most one draw on a CDF boundary
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), rl, atol=5e-5, rtol=0)
+    assert abs(float(loss) - float(ref_loss)) < 1e-4
+    got = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())).item()
+    want = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ref.parameters())).item()
+    assert abs(got - want) < 1e-3 * max(1.0, want), (got, want)
 
 
 def test_persistent_decode_loop_equals_multi_launch_loop():
@@ -266,7 +342,8 @@ def test_four_train_steps_follow_the_oracle_trajectory():
     assert worst < 5e-4, worst
 
 
-def test_backward_is_reproducible_with_overlapped_streams(golden):
+@pytest.mark.parametrize('name', ['full_b16_t400', 'bench_b32_t800'])
+def test_backward_is_reproducible_with_overlapped_streams(golden, name):
     """The recurrences have no atomics, so repeated backward passes over the same batch may
     differ only by the summation order of the weight-gradient accumulations (~1e-6).  Larger
     run-to-run differences mean a race between the persistent kernels and the work that
@@ -275,7 +352,7 @@ def test_backward_is_reproducible_with_overlapped_streams(golden):
     other still had to read)."""
     from ss_asr_amd import ops
     from ss_asr_amd.optim import FlatParameters
-    fx = golden('full_b16_t400')
+    fx = golden(name)
     model = build(fx)
     flat = FlatParameters(model)
     names = [n for n, _ in model.named_parameters()]

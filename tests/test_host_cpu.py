@@ -68,6 +68,23 @@ def test_product_package_never_imports_the_oracle():
                 assert 'las_oracle' not in text and 'oracle/' not in text, f
 
 
+def test_seeded_init_equals_the_reference_initialisation(golden):
+    """ASR(...) built after seeding the RNGs as src/train.py:58-61 does holds, bit for bit, the
+    parameters the reference's own ASR.__init__ + init_parameters (src/asr.py:16-50, :175-212)
+    produced under the same seed (captured as w0/* of the small_tf1 fixture)."""
+    import random
+    from ss_asr_amd.asr import ASR
+    fx = golden('small_tf1')
+    seed = int(fx['seed'])
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    model = ASR(*[int(v) for v in fx['dims']], float(fx['tf_rate']))
+    sd = model.state_dict()
+    keys = [k[3:] for k in fx.files if k.startswith('w0/')]
+    assert sorted(keys) == sorted(sd.keys())
+    for k in keys:
+        assert np.array_equal(sd[k].numpy(), fx['w0/' + k]), k
+
+
 def test_state_dict_and_seeded_init_match_the_oracle_model():
     """Same constructor-time RNG consumption and key set as the reference layout."""
     import las_oracle as lo

@@ -7,9 +7,10 @@ import pytest
 import torch
 
 import las_oracle as lo
+from conftest import fixture_att, fixture_xy
 
 CASES = ['small_tf1', 'small_odd', 'small_padded', 'small_greedy', 'small_sampled',
-         'full_b4']
+         'full_b4', 'bench_b32_t800', 'bench_b32_median']
 
 
 def build(fx):
@@ -26,8 +27,7 @@ def build(fx):
 
 
 def run(fx, model):
-    x = torch.from_numpy(fx['x'])
-    y = torch.from_numpy(fx['y'])
+    x, y = fixture_xy(fx)
     lens = [int(v) for v in fx['lens']]
     ans_len = int(fx['ans_len'])
     s = int(fx['rng_seed'])
@@ -46,7 +46,7 @@ def test_forward_matches_reference(golden, name):
     enc_len, logits, att, loss = run(fx, model)
     assert enc_len == [int(v) for v in fx['enc_len']]
     np.testing.assert_allclose(logits.detach().numpy(), fx['logits'], atol=1e-5, rtol=0)
-    np.testing.assert_allclose(att.numpy(), fx['att'], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(fixture_att(fx, att.numpy()), fx['att'], atol=1e-6, rtol=0)
     assert abs(float(loss) - float(fx['loss'])) < 1e-5
 
 
