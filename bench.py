@@ -4,17 +4,27 @@ utterances/sec on 80-dim mel).
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = forward (Listener -> Attention -> Speller) + masked CE + backward +
-gradient all-reduce (N > 1) + clip + Adadelta on one synthetic batch that is
-already resident in HBM.  Workload: BASELINE.json configs[1], the ~10 h
-Malromur-shaped corpus (8,000 utterances, <= 800 frames of 80-dim fbank,
+One step = what one iteration of ASRTrainer.exec runs (ss_asr_amd/trainer.py,
+mirroring src/trainer.py:411-438): batch assembly from the device-resident
+corpus (ssasr_gather_batch: the zero-padded [32, T, 80] batch is built inside the
+timed region; the corpus' frames are resident in HBM when it starts), forward
+(Listener -> Attention -> Speller) + masked CE + backward + gradient all-reduce
+(N > 1) + clip + Adadelta: engine.ASRTrainStep fed by gpu_loader.GpuResidentLoader,
+the same two objects the trainer uses.  Workload: BASELINE.json configs[1], the
+~10 h Malromur-shaped corpus (8,000 utterances, <= 800 frames of 80-dim fbank,
 batch 32 per GPU, bucketed by length), fp32 arithmetic, tf_rate 0.9 as in
 conf/default.yaml.  Prints ONE JSON line on rank 0.
+
+`--gpus N` with N > 1 and no torchrun environment starts the N ranks itself
+(python -m torch.distributed.run, one process per GPU, before this process
+touches a GPU) and exits with their status.
 """
 import argparse
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -201,27 +211,47 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
     return out
 
 
-def cpu_baseline(batch):
+def cpu_baseline(batches):
     """The oracle (a CPU restatement of the reference, pinned to its golden
-    vectors) timed on the host cores for ONE train step on one bench batch."""
+    vectors) timed on the host cores for one train step on each of `batches`
+    (bench batches: x, y, lens), optimizer state carried from step to step."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import las_oracle as lo
     cores = host_cores()
     torch.set_num_threads(cores)
-    note('cpu baseline: 1 oracle train step on %d cores ...' % cores)
+    note('cpu baseline: %d oracle train steps on %d cores ...' % (len(batches), cores))
     torch.manual_seed(1)
+    random.seed(1)
     model = lo.OracleASR(**DIMS)
     optim = lo.make_optimizer(model)
-    x, y, _ = batch
-    x, y = x.cpu(), y.cpu()
-    lo.train_step(model, optim, x[:2, :32].contiguous(), y[:2])          # thread-pool warm-up
-    t0 = time.perf_counter()
-    loss, _ = lo.train_step(model, optim, x, y)
-    dt = time.perf_counter() - t0
-    return dict(value=round(x.shape[0] / dt, 4), unit='utterances/sec', cores=cores, kind='port',
-                sample='1 train step on one bench batch: %d utterances, %d frames max, fp32, torch %s'
-                       % (x.shape[0], x.shape[1], torch.__version__),
-                seconds=round(dt, 2), loss=round(loss, 5))
+    x0, y0, _ = batches[0]
+    lo.train_step(model, optim, x0[:2, :32].contiguous(), y0[:2])          # thread-pool warm-up
+    utts, secs, losses = 0, [], []
+    for x, y, _ in batches:
+        t0 = time.perf_counter()
+        loss, _ = lo.train_step(model, optim, x.cpu(), y.cpu())
+        secs.append(time.perf_counter() - t0)
+        losses.append(loss)
+        utts += x.shape[0]
+        note('cpu baseline: %d x %d frames in %.1f s' % (x.shape[0], x.shape[1], secs[-1]))
+    frames = [int(b[0].shape[1]) for b in batches]
+    return dict(value=round(utts / sum(secs), 4), unit='utterances/sec', cores=cores, kind='port',
+                sample='%d train steps (optimizer state carried over) on %d of the bench batches: %d utterances each, '
+                       '%s frames max, fp32, torch %s' % (len(batches), len(batches), batches[0][0].shape[0],
+                                                         '/'.join(str(f) for f in frames), torch.__version__),
+                seconds=[round(v, 2) for v in secs], loss=round(losses[-1], 5))
+
+
+def self_launch(args):
+    """--gpus N without a torchrun environment: start the N ranks as children of this process
+    (which has not touched a GPU), pass their output through, return their exit status."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note('starting %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+    return subprocess.call(cmd)
 
 
 def main():
@@ -235,6 +265,8 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))            # no GPU call has been made in this process
     from ss_asr_amd import dist as sdist
     rank, world, local = sdist.init_from_env()
     if world != args.gpus:
@@ -248,7 +280,8 @@ def main():
     device = torch.device('cuda', local)
 
     from ss_asr_amd.asr import ASR
-    from ss_asr_amd.engine import ASRTrainStep, label_geometry
+    from ss_asr_amd.engine import ASRTrainStep
+    from ss_asr_amd.gpu_loader import GpuResidentLoader
     from ss_asr_amd.synthetic import config2_batches
 
     random.seed(1); np.random.seed(1); torch.manual_seed(1)
@@ -256,17 +289,23 @@ def main():
     model.train()
     stepper = ASRTrainStep(model, lr=1.0, eps=1e-8, grad_clip=5.0)
 
+    # the rank's corpus: 8 batches spread over the length range, unpadded frames resident in HBM
     nb = 8
     host_batches = config2_batches(nb, batch_size=args.batch, feat_dim=DIMS['feature_dim'], seed=1, rank=rank,
                                    hi=args.max_frames)
-    batches = []
+    corpus, labels = [], []
     for x, y, lens in host_batches:
-        _, ans_len = label_geometry(y)
-        batches.append((x.to(device), y.to(device), lens, ans_len))
+        for b, n in enumerate(lens):
+            corpus.append(x[b, :n].numpy())
+            labels.append(y[b, :int((y[b] != 0).sum()) + 1].tolist())       # '<' chars '>'
+    loader = GpuResidentLoader.from_arrays(corpus, labels, args.batch, device)
+    assert len(loader) == nb
+    batch_frames = [loader.x_lens[s:s + args.batch] for s in loader.starts]
 
     def run(i):
-        x, y, lens, ans_len = batches[i % nb]
-        return stepper(x, y, lens, ans_len)
+        # one iteration of ASRTrainer.exec: assemble the batch on the GPU, then the fused step
+        x, x_lens, y, y_lens = loader.batch(i % nb)
+        return stepper(x, y, x_lens, max(y_lens) - 1)
 
     for i in range(args.warmup):
         run(i)
@@ -288,21 +327,22 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     last_loss = float(loss.detach()) if loss is not None else float('nan')
-    from ss_asr_amd import ops
-    ops.check_persistent_status()             # a timed-out persistent recurrence voids the run
+    stepper.finish()                          # a timed-out persistent recurrence voids the run (raises)
     if rank == 0:
         note('gpu: %d steps in %.3f s -> %.1f utt/s (loss %.4f)' % (args.steps, dt, world * args.batch * args.steps / dt, last_loss))
 
     if rank != 0:
+        sdist.shutdown()
         return
     utts = world * args.batch * args.steps
-    frames = sum(sum(batches[(args.warmup + i) % nb][2]) for i in range(args.steps))
+    frames = sum(sum(batch_frames[(args.warmup + i) % nb]) for i in range(args.steps))
     out = {
         'metric': 'train-step utterances/sec on 80-dim mel', 'value': round(utts / dt, 2),
         'unit': 'utterances/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE.json configs[1]: ASRTrainer step, ~10h synthetic Malromur-shape '
+        'config': {'workload': 'BASELINE.json configs[1]: one ASRTrainer.exec iteration (GPU batch assembly from the '
+                               'HBM-resident corpus + engine.ASRTrainStep), ~10h synthetic Malromur-shape '
                                'fbanks (8000 utts, <=%d frames, 80-dim), batch %d per GPU, bucketed by length, '
                                'LAS 256/256/128, tf_rate 0.9, Adadelta' % (args.max_frames, args.batch),
                    'global_batch': world * args.batch, 'max_frames': args.max_frames,
@@ -326,8 +366,9 @@ def main():
         out['roofline_forward_recurrence'] = fwd_rec
         out['roofline_attention'] = att
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(host_batches[nb // 2])
+        out['cpu_baseline'] = cpu_baseline([host_batches[k] for k in (2, 4, 6)])
     print(json.dumps(out), flush=True)
+    sdist.shutdown()
 
 
 if __name__ == '__main__':

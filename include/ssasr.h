@@ -11,11 +11,26 @@
  *   - plain C symbols; every pointer is a DEVICE pointer unless it says host;
  *   - fp32 data, int32 lengths / character ids, int64_t sizes and strides
  *     (strides in ELEMENTS);
- *   - the caller owns every buffer, including workspaces; nothing is
- *     allocated, no global state is kept, nothing synchronises;
+ *   - the caller owns every buffer, including workspaces and the events of
+ *     ssasr_events_create; nothing is allocated, nothing synchronises, and no
+ *     call leaves state behind for the next one: entry points are reentrant
+ *     and may be called from several threads on different streams;
+ *   - the only process-wide state is the table of diagnostic switches below
+ *     (ssasr_set_option), read from the environment once and constant
+ *     afterwards unless a tool changes it, plus a cache of occupancy-query
+ *     results (a pure function of kernel and device);
  *   - work is enqueued on `stream` (a hipStream_t) by the calling thread;
  *   - return 0 on success, a negative value for an argument error, a positive
  *     hipError_t for a HIP failure.
+ *
+ * Persistent launches.  Several entry points run a whole layer / decode loop as
+ * ONE launch whose workgroups hand data to each other.  Such a grid is only
+ * launched when an occupancy query says every workgroup of it can be resident
+ * on the current device at once; otherwise the entry point takes its
+ * one-launch-per-step form.  Hand-offs are bounded spins: a workgroup that
+ * gives up sets the caller's status word (sync_ws[4] / ws_sync[5]) and the
+ * launch drains (later waits of that launch return at once), so a caller must
+ * check the status words before it trusts the results of that step.
  */
 #ifndef SSASR_H
 #define SSASR_H
@@ -25,6 +40,21 @@ extern "C" {
 #endif
 
 int ssasr_abi_version(void);
+
+/* Diagnostic switches (A/B measurements; every setting computes the same results).  Each is
+ * initialised ONCE from the environment variable of the same name when the library is first
+ * used -- entry points never read the environment -- and may be changed by tools between
+ * calls.  Names: SSASR_NO_PERSISTENT, SSASR_PERSISTENT_COUNTER, SSASR_NO_FUSED_INPUT,
+ * SSASR_FWD_NB, SSASR_BPTT_GATHER, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
+ * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
+ * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_NO_RESIDENCY_CHECK.  Unknown name: -1. */
+int ssasr_set_option(const char* name, int value);
+int ssasr_get_option(const char* name, int* value);
+
+/* A caller-owned set of events with which ssasr_bilstm_bwd_overlapped orders its second stream
+ * behind the first.  One set serves all calls of its owner (one thread at a time). */
+int ssasr_events_create(void** handle);
+int ssasr_events_destroy(void* handle);
 
 /* C[b] = act(alpha * op(A[b]) . op(B[b]) + bias) + beta * C[b], fp32 MFMA.
  * ta = 0: A is [M][K] (ld = lda); ta = 1: A is [K][M].
@@ -52,13 +82,16 @@ int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
  * (taken when H % 64 == 0 and N <= 128): hx [2][S][H/4][roundup(N,8)][4] floats
  * and sync_ws int32[8], ZERO ON ENTRY (sync_ws[4] != 0 afterwards reports an exchange
  * timeout); pass NULL for one launch per step.
+ * armed != 0: hx already holds the fill pattern 0x7FC0DEAD in every word, written on the same
+ * stream (a caller that arms the exchange workspaces of a whole pass with ONE fill: a dependent
+ * launch costs ~6 us however small); 0: the call fills it itself.
  * Replaces: pBLSTM.forward / nn.LSTM, src/asr.py:406-427, :262. */
 int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
                      int64_t H, const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
                      const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,
                      const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* y,
                      int64_t ys_s, int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
-                     int32_t* sync_ws, void* stream);
+                     int32_t* sync_ws, int armed, void* stream);
 
 /* Backward of ssasr_bilstm_fwd.  `gates` is consumed (overwritten with the
  * gate pre-activation derivatives).  dx may be NULL.  db_* is the derivative
@@ -70,32 +103,26 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
  * launch per step. */
 int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);
 /* Floats of the K-split BPTT's exchange ring alone (dirs = 1 or 2 directions), 0 when the
- * shape or the environment does not take that form.  A caller that arms several exchange
- * workspaces with one fill (ssasr_exchange_armed) reserves this instead of gx_floats. */
+ * shape, the options or the device do not take that form.  A caller that arms several exchange
+ * workspaces with one fill (`armed` below) reserves this instead of gx_floats.
+ * armed != 0 (ssasr_bilstm_bwd, _overlapped): the first ssasr_bilstm_bwd_ring_floats(S, N, H, 2)
+ * floats of gx already hold the fill pattern 0x7FC0DEAD, written on the same stream; only
+ * meaningful when that query is non-zero. */
 int64_t ssasr_bilstm_bwd_ring_floats(int64_t S, int64_t N, int64_t H, int64_t dirs);
-
-/* One-shot declaration about the NEXT call made on this thread: armed != 0 says that the
- * exchange workspaces that call receives (hx of ssasr_bilstm_fwd; the ring in gx of
- * ssasr_bilstm_bwd[_overlapped]; ws_hx1.. and ctx of ssasr_decoder_fwd; the ring in ws_gx and
- * all of ws_chain of ssasr_decoder_bwd) already hold the fill pattern 0x7FC0DEAD, written on
- * the same stream, so the call skips its own fill.  Lets a caller arm the workspaces of a
- * whole pass with one fill (a dependent launch costs ~6 us however small).  The call
- * consumes the declaration.  Only valid for the sentinel exchange (the default). */
-int ssasr_exchange_armed(int armed);
 int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
                      int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H, const int32_t* lens,
                      const float* w_ih_f, const float* w_hh_f, const float* w_ih_r,
                      const float* w_hh_r, float* gates, const float* cs, const float* hs, float* dx,
                      int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f, float* db_f,
                      float* dw_ih_r, float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc,
-                     float* gx, int32_t* sync_ws, void* stream);
+                     float* gx, int32_t* sync_ws, int armed, void* stream);
 
 /* ssasr_bilstm_bwd with the weight gradients accumulated (+=) into dw_* / db* (db2_*: optional
  * second copy, b_ih and b_hh share theirs) on `side_stream`, overlapped with the recurrence:
  * for layers that take the persistent K-split BPTT, the recurrence runs as `segments` (1..8)
  * launches over consecutive step ranges and each range's weight-gradient products start on
  * side_stream as soon as that launch has been enqueued.  The caller joins side_stream before
- * it reads the gradients. */
+ * it reads the gradients.  events: from ssasr_events_create. */
 int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
                                 int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H,
                                 const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
@@ -103,7 +130,8 @@ int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_t ys_n, con
                                 const float* hs, float* dx, int64_t dxs_s, int64_t dxs_n, float* dw_ih_f,
                                 float* dw_hh_f, float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
                                 float* db_r, float* db2_r, float* ws_whhT, float* ws_dc, float* gx,
-                                int32_t* sync_ws, int segments, void* stream, void* side_stream);
+                                int32_t* sync_ws, int armed, int segments, void* events, void* stream,
+                                void* side_stream);
 
 /* Weight gradients of a layer from the gate derivatives ssasr_bilstm_bwd left
  * in `gates`: dW_ih = dG^T X, dW_hh = sum_s dG[s]^T h[s_prev], db = column sums.
@@ -199,6 +227,8 @@ typedef struct ssasr_decoder {
   int32_t* ws_sync;                      /* int32[8]; [5] != 0 reports a timeout */
   int32_t modes_ready;                   /* != 0: ws_modes already holds step_mode (the caller
                                           * uploaded it with its other per-step integers)   */
+  int32_t ws_armed;                      /* != 0: ws_hx1, ws_hx2, ws_qx and ctx already hold the fill
+                                          * pattern 0x7FC0DEAD (written on the same stream)  */
 } ssasr_decoder;
 
 int ssasr_decoder_fwd(const ssasr_decoder* d, void* stream);
@@ -235,6 +265,9 @@ typedef struct ssasr_decoder_grads {
   /* != 0: ssasr_decoder_bwd leaves every parameter gradient (dw_*, db*, dembed) to
    * ssasr_decoder_wgrad, which may run later and on another stream                  */
   int32_t defer_wgrad;
+  /* != 0: the ring at the head of ws_gx (ssasr_bilstm_bwd_ring_floats(U, B, D, 1) floats) and the
+   * exchange part of ws_chain already hold the fill pattern 0x7FC0DEAD                       */
+  int32_t ws_armed;
 } ssasr_decoder_grads;
 
 /* Workspace of the persistent decoder backward chain (0: shape has none). */

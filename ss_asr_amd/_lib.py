@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -30,7 +30,7 @@ class Decoder(C.Structure):
          ('w_phi_t', P), ('q', P), ('ctx', P), ('emb_in', P), ('chars', P),
          ('gates1', P), ('c1', P), ('h1', P), ('gates2', P), ('c2', P), ('h2', P),
          ('ws_hx1', P), ('ws_hx2', P), ('ws_qx', P), ('ws_modes', P), ('ws_sync', P),
-         ('modes_ready', C.c_int32)])
+         ('modes_ready', C.c_int32), ('ws_armed', C.c_int32)])
 
 
 class DecoderGrads(C.Structure):
@@ -39,20 +39,24 @@ class DecoderGrads(C.Structure):
         'dlogits', 'dfeat', 'dcomp', 'dw_phi', 'dw_ih1', 'dw_hh1', 'db1', 'dw_ih2', 'dw_hh2',
         'db2', 'dembed', 'dw_ct', 'db_ct', 'ws_t_ih1', 'ws_t_hh1', 'ws_t_ih2', 'ws_t_hh2',
         'ws_dh2', 'ws_dctx', 'ws_de', 'ws_dqpre', 'ws_dc', 'ws_demb', 'ws_gx', 'ws_sync', 'ws_chain',
-        'db1_2', 'db2_2')] + [('defer_wgrad', C.c_int32)]
+        'db1_2', 'db2_2')] + [('defer_wgrad', C.c_int32), ('ws_armed', C.c_int32)]
 
 
 SIGNATURES = {
     'ssasr_abi_version': (I32, []),
+    'ssasr_set_option': (I32, [C.c_char_p, I32]),
+    'ssasr_get_option': (I32, [C.c_char_p, C.POINTER(C.c_int)]),
+    'ssasr_events_create': (I32, [C.POINTER(P)]),
+    'ssasr_events_destroy': (I32, [P]),
     'ssasr_gemm_f32': (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32,
                              I64, I64, I64, I64, I32, P]),
     'ssasr_bilstm_fwd': (I32, [P, I64, I64, I64, I64, I64, I64, P] + [P] * 8 +
-                         [P, I64, I64, P, P, P, P, P, P]),
+                         [P, I64, I64, P, P, P, P, P, I32, P]),
     'ssasr_bilstm_bwd': (I32, [P, I64, I64, P, I64, I64, I64, I64, I64, I64, P] + [P] * 4 +
-                         [P, P, P, P, I64, I64] + [P] * 6 + [P, P, P, P, P]),
+                         [P, P, P, P, I64, I64] + [P] * 6 + [P, P, P, P, I32, P]),
     'ssasr_bilstm_wgrad': (I32, [P, P, I64, I64, P, I64, I64, I64, I64] + [P] * 8 + [I32, P]),
     'ssasr_bilstm_bwd_overlapped': (I32, [P, I64, I64, P, I64, I64, I64, I64, I64, I64, P] + [P] * 4 +
-                                    [P, P, P, P, I64, I64] + [P] * 8 + [P, P, P, P, I32, P, P]),
+                                    [P, P, P, P, I64, I64] + [P] * 8 + [P, P, P, P, I32, I32, P, P, P]),
     'ssasr_lstm_cell_fwd': (I32, [P, I64, I64, P, I64, I64, P, P, P, P, P, P, I64, I64, P, P, P, P]),
     'ssasr_lstm_cell_bwd': (I32, [P, P, P, P, P, I64, I64, P, P, P]),
     'ssasr_attn_precompute_fwd': (I32, [P, P, P, I64, I64, I64, P, P]),
@@ -69,7 +73,6 @@ SIGNATURES = {
     'ssasr_clip_adadelta': (I32, [P, P, P, P, I64, F32, F32, F32, F32, F32, P, P, I32, P]),
     'ssasr_bilstm_bwd_gx_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_bwd_ring_floats': (I64, [I64, I64, I64, I64]),
-    'ssasr_exchange_armed': (I32, [I32]),
     'ssasr_decoder_bwd_chain_floats': (I64, [I64] * 6),
     'ssasr_frame_lengths': (I32, [P, I64, I64, I64, P, P]),
     'ssasr_gather_batch': (I32, [P, P, P, I64, I64, I64, P, P]),
@@ -102,6 +105,16 @@ def load():
         raise ImportError('ss_asr_amd: ABI version mismatch, rebuild libssasr_hip.so')
     _lib = lib
     return lib
+
+
+def set_option(name, value):
+    """Diagnostic switch of the library (include/ssasr.h, ssasr_set_option); returns the old value."""
+    lib = load()
+    old = C.c_int(0)
+    if lib.ssasr_get_option(name.encode(), C.byref(old)) != 0:
+        raise KeyError(name)
+    lib.ssasr_set_option(name.encode(), int(value))
+    return old.value
 
 
 def check(rc, what):

@@ -96,9 +96,28 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0 = 0, int64_t i1 = 0,
                                  float* dc_state = nullptr, const float* whh_f = nullptr, const float* whh_r = nullptr,
                                  bool armed = false);
-// ssasr_exchange_armed (include/ssasr.h): reads and clears the caller's declaration that the exchange
-// workspaces of the call in progress already hold the fill pattern.
-bool ssasr_take_armed();
+// Process-wide diagnostic switches (include/ssasr.h, ssasr_set_option): read from the environment
+// ONCE, when the first entry point runs, never per call; A/B tools change them through
+// ssasr_set_option.  Everything here selects between kernels that compute the same result.
+struct SsasrOptions {
+  int no_persistent;              // SSASR_NO_PERSISTENT: one launch per step everywhere
+  int persistent_counter;         // SSASR_PERSISTENT_COUNTER: arrival-counter exchange instead of the sentinel form
+  int no_fused_input;             // SSASR_NO_FUSED_INPUT: first layer's input projection as a GEMM
+  int fwd_nb;                     // SSASR_FWD_NB: 0 auto, 1 | 2 column tiles per forward workgroup
+  int bptt_gather;                // SSASR_BPTT_GATHER: gather form of the persistent BPTT
+  int bptt_halves_off;            // SSASR_BPTT_HALVES_OFF
+  int bptt_reserve_kb;            // SSASR_BPTT_RESERVE_KB (118); SSASR_BPTT_SHARED_CU=1 makes it 0
+  int no_persistent_decoder;      // SSASR_NO_PERSISTENT_DECODER
+  int no_persistent_decoder_bwd;  // SSASR_NO_PERSISTENT_DECODER_BWD
+  int delay_fwd, delay_bwd, delay_bwd_ksplit;   // SSASR_PERSIST_DELAY_FWD / _BWD (initial pacing, x 64 cycles; -1 = default)
+  int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
+  int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches
+};
+const SsasrOptions& ssasr_options();
+// Upper bound of co-resident workgroups of `kernel` (block threads, dynamic LDS bytes) on the current
+// device: occupancy per CU x CU count, cached per (kernel, LDS).  A persistent grid larger than this
+// could spin on a workgroup that is not resident; the launchers fall back to one launch per step.
+int64_t ssasr_resident_capacity(const void* kernel, int threads, size_t dyn_lds);
 // true when the shape takes the K-split persistent form (which supports iteration ranges)
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs);
 extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);

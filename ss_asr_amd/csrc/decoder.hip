@@ -15,7 +15,7 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 8; }
+extern "C" int ssasr_abi_version(void) { return 9; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
@@ -162,9 +162,17 @@ extern "C" int ssasr_attn_step_bwd(const float* dctx, const float* datt, const f
 }
 
 // ------------------------------ decode loop --------------------------------
+// every workgroup of a persistent grid must be resident at once (see rnn.hip, grid_fits)
+static bool dec_grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t workgroups) {
+  if (ssasr_options().no_residency_check) return true;
+  const int64_t cap = ssasr_resident_capacity(kernel, threads, dyn_lds);
+  return cap <= 0 || workgroups <= cap;
+}
+
 extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
-  const bool armed = ssasr_take_armed();
   if (!dp) return SSASR_EARG;
+  const bool armed = dp->ws_armed != 0;
+  const SsasrOptions& opt = ssasr_options();
   const ssasr_decoder& d = *dp;
   const int64_t B = d.B, T = d.T, E = d.E, A = d.A, D = d.D, V = d.V, U = d.U;
   if (!attn_dims_ok(B, T, A, E, D) || D % 16 != 0 || V <= 0 || U <= 0) return SSASR_EARG;
@@ -188,10 +196,17 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   // Embeddings of every known input character in one gather; rows of sampled
   // steps are overwritten inside the loop.
   // Single persistent launch for the production sizes (decoder_persistent.h).
-  const bool persistent = d.ws_hx1 && d.ws_hx2 && d.ws_qx && d.ws_modes && d.ws_sync && A == PD_A &&
-                          E == PD_E && D == PD_D && B <= 32 && T <= 128 && V <= 64 &&
-                          !getenv("SSASR_NO_PERSISTENT") && !getenv("SSASR_NO_PERSISTENT_DECODER");
-  const bool sentinel = persistent && getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
+  bool persistent = d.ws_hx1 && d.ws_hx2 && d.ws_qx && d.ws_modes && d.ws_sync && A == PD_A &&
+                    E == PD_E && D == PD_D && B <= 32 && T <= 128 && V <= 64 &&
+                    !opt.no_persistent && !opt.no_persistent_decoder;
+  if (persistent) {
+    const size_t lds = decoder_persistent_lds((int)T);
+    const void* fn = opt.persistent_counter ? reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<false>)
+                                            : reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<true>);
+    SSASR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    persistent = dec_grid_fits(fn, 256, lds, PD_NATTWG + 128);
+  }
+  const bool sentinel = persistent && !opt.persistent_counter;
   if (persistent && !d.modes_ready)
     SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
   // (self-verifying loop: rows the loop itself produces start as the fill pattern)
@@ -200,7 +215,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
                      (int)U);
   SSASR_LAUNCH_CHECK();
 
-  if (d.ws_sync && getenv("SSASR_PERSISTENT_COUNTER")) SSASR_HIP(hipMemsetAsync(d.ws_sync, 0, 5 * sizeof(int32_t), st));
+  if (d.ws_sync && opt.persistent_counter) SSASR_HIP(hipMemsetAsync(d.ws_sync, 0, 5 * sizeof(int32_t), st));
   if (persistent) {
     DecPersist p{};
     p.feat = d.feat; p.comp = d.comp; p.enc_len = d.enc_len; p.w_phi = d.w_phi;
@@ -231,12 +246,8 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_qx, (int)PERSIST_SENTINEL, img_q * U, st));
       }
       if (!ctx_filled) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ctx, (int)PERSIST_SENTINEL, n_ctx, st));
-      SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(decoder_fwd_persistent_kernel<true>, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
     } else {
-      SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(decoder_fwd_persistent_kernel<false>, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
     }
     SSASR_LAUNCH_CHECK();
@@ -330,8 +341,9 @@ int gemm_tn_acc(const float* A, RowMap ma, const float* B, RowMap mb, float* C, 
 }  // namespace
 
 extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_grads* gp, void* stream) {
-  const bool armed = ssasr_take_armed();
   if (!dp || !gp) return SSASR_EARG;
+  const bool armed = gp->ws_armed != 0;
+  const SsasrOptions& opt = ssasr_options();
   const ssasr_decoder& d = *dp;
   const ssasr_decoder_grads& g = *gp;
   const int64_t B = d.B, T = d.T, E = d.E, A = d.A, D = d.D, V = d.V, U = d.U;
@@ -360,10 +372,16 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   // K-contiguous copies of the recurrent weights for the per-step products.
   // (only for the per-step kernels: the persistent forms read the weights as they are)
   const bool cell2_first = g.ws_gx && g.ws_sync && ssasr_bilstm_bwd_gx_floats(U, B, D) > 0 &&
-                           !getenv("SSASR_NO_PERSISTENT") && !getenv("SSASR_NO_PERSISTENT_DECODER");
+                           !opt.no_persistent && !opt.no_persistent_decoder;
   const bool cell2_direct = cell2_first && ssasr_bptt_ksplit_ok(U, B, D, 1);
-  const bool chain = cell2_first && g.ws_chain && ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D) > 0 &&
-                     !getenv("SSASR_NO_PERSISTENT_DECODER_BWD");
+  bool chain = cell2_first && g.ws_chain && ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D) > 0 &&
+               !opt.no_persistent_decoder_bwd;
+  if (chain) {
+    const size_t lds = chain_lds_bytes((int)T);
+    SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_chain_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    chain = dec_grid_fits(reinterpret_cast<const void*>(decoder_bwd_chain_kernel), 320, lds, CB_NATTWG + 64);
+  }
   if (!chain) {
     if ((rc = ssasr_launch_transpose(d.w_phi, d.w_phi_t, (int)A, (int)D, st))) return rc;
     if ((rc = ssasr_launch_transpose(d.w_ih1, g.ws_t_ih1, (int)(4 * D), (int)(D + E), st))) return rc;
@@ -425,8 +443,6 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     c.xa = xa; c.xc = xc; c.xu = xu; c.status = g.ws_sync + 5;
     c.B = (int)B; c.T = (int)T; c.U = (int)U;
     const size_t lds = chain_lds_bytes((int)T);
-    SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_chain_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(decoder_bwd_chain_kernel, dim3(CB_NATTWG + 64), dim3(320), lds, st, c);
     hipLaunchKernelGGL(chain_de_fixup_kernel, dim3(256), dim3(256), 0, st, g.ws_de, d.att, wsS, (int)B, (int)U, (int)T,
                        reinterpret_cast<float4*>(d.gates1), reinterpret_cast<const float4*>(dg1), U * B * D,

@@ -405,9 +405,9 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   const bool vecB = aligned16(g.B) && map_vec_ok(g.mb) && (g.sb % 4 == 0);
   // 128x128 tiles only when they still give every CU work.
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
-  if (const char* v = getenv("SSASR_GEMM_TILE")) {          // diagnostic: force a tile shape
-    if (atoi(v) == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
-    if (atoi(v) == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
+  if (const int forced = ssasr_options().gemm_tile) {       // diagnostic: force a tile shape
+    if (forced == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
+    if (forced == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
   }
   if (big < 256) return launch_tiles<64, 64>(g, vecA, vecB, st);
   // Both tile shapes run at 85-110 TF once the chip is full; what differs is how the LAST round of

@@ -1,0 +1,98 @@
+// Process-wide diagnostic switches and device queries shared by the entry points.
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include "common.h"
+
+namespace {
+
+SsasrOptions g_opt;
+std::once_flag g_opt_once;
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+int env_flag(const char* name) { return getenv(name) != nullptr; }
+
+void init_options() {
+  g_opt.no_persistent = env_flag("SSASR_NO_PERSISTENT");
+  g_opt.persistent_counter = env_flag("SSASR_PERSISTENT_COUNTER");
+  g_opt.no_fused_input = env_flag("SSASR_NO_FUSED_INPUT");
+  g_opt.fwd_nb = env_int("SSASR_FWD_NB", 0);
+  g_opt.bptt_gather = env_flag("SSASR_BPTT_GATHER");
+  g_opt.bptt_halves_off = env_flag("SSASR_BPTT_HALVES_OFF");
+  g_opt.bptt_reserve_kb = env_flag("SSASR_BPTT_SHARED_CU") ? 0 : env_int("SSASR_BPTT_RESERVE_KB", 118);
+  g_opt.no_persistent_decoder = env_flag("SSASR_NO_PERSISTENT_DECODER");
+  g_opt.no_persistent_decoder_bwd = env_flag("SSASR_NO_PERSISTENT_DECODER_BWD");
+  g_opt.delay_fwd = env_int("SSASR_PERSIST_DELAY_FWD", -1);
+  g_opt.delay_bwd = env_int("SSASR_PERSIST_DELAY_BWD", -1);
+  g_opt.delay_bwd_ksplit = g_opt.delay_bwd;
+  g_opt.gemm_tile = env_int("SSASR_GEMM_TILE", 0);
+  g_opt.no_residency_check = env_flag("SSASR_NO_RESIDENCY_CHECK");
+}
+
+struct Named { const char* name; int SsasrOptions::*field; };
+const Named kNames[] = {
+    {"SSASR_NO_PERSISTENT", &SsasrOptions::no_persistent},
+    {"SSASR_PERSISTENT_COUNTER", &SsasrOptions::persistent_counter},
+    {"SSASR_NO_FUSED_INPUT", &SsasrOptions::no_fused_input},
+    {"SSASR_FWD_NB", &SsasrOptions::fwd_nb},
+    {"SSASR_BPTT_GATHER", &SsasrOptions::bptt_gather},
+    {"SSASR_BPTT_HALVES_OFF", &SsasrOptions::bptt_halves_off},
+    {"SSASR_BPTT_RESERVE_KB", &SsasrOptions::bptt_reserve_kb},
+    {"SSASR_NO_PERSISTENT_DECODER", &SsasrOptions::no_persistent_decoder},
+    {"SSASR_NO_PERSISTENT_DECODER_BWD", &SsasrOptions::no_persistent_decoder_bwd},
+    {"SSASR_PERSIST_DELAY_FWD", &SsasrOptions::delay_fwd},
+    {"SSASR_PERSIST_DELAY_BWD", &SsasrOptions::delay_bwd},
+    {"SSASR_GEMM_TILE", &SsasrOptions::gemm_tile},
+    {"SSASR_NO_RESIDENCY_CHECK", &SsasrOptions::no_residency_check},
+};
+
+}  // namespace
+
+const SsasrOptions& ssasr_options() {
+  std::call_once(g_opt_once, init_options);
+  return g_opt;
+}
+
+extern "C" int ssasr_set_option(const char* name, int value) {
+  if (!name) return SSASR_EARG;
+  std::call_once(g_opt_once, init_options);
+  for (const Named& n : kNames)
+    if (strcmp(n.name, name) == 0) {
+      g_opt.*(n.field) = value;
+      if (n.field == &SsasrOptions::delay_bwd) g_opt.delay_bwd_ksplit = value;
+      return SSASR_OK;
+    }
+  return SSASR_EARG;
+}
+
+extern "C" int ssasr_get_option(const char* name, int* value) {
+  if (!name || !value) return SSASR_EARG;
+  std::call_once(g_opt_once, init_options);
+  for (const Named& n : kNames)
+    if (strcmp(n.name, name) == 0) { *value = g_opt.*(n.field); return SSASR_OK; }
+  return SSASR_EARG;
+}
+
+int64_t ssasr_resident_capacity(const void* kernel, int threads, size_t dyn_lds) {
+  static std::mutex mu;
+  static std::map<std::tuple<const void*, int, size_t, int>, int64_t> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_tuple(kernel, threads, dyn_lds, dev);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dyn_lds) != hipSuccess) per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  // MI355X_MICROARCH.md: the API answer can be one block per CU high near SGPR edges; the persistent
+  // kernels here are 320- or 256-thread, register-heavy workgroups (1-2 per CU), where it is exact.
+  const int64_t cap = (int64_t)per_cu * cus;
+  cache[key] = cap;
+  return cap;
+}

@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include "rnn_kernels.h"
 
+constexpr int SSASR_MAX_SEGMENTS = 8;
+
 int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st) {
   dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(32, 8);
   hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, src, dst, rows, cols);
@@ -25,25 +27,20 @@ int ssasr_launch_colsum(const float* m, int64_t rows, int cols, int64_t ld, floa
   return SSASR_OK;
 }
 
-// ssasr_exchange_armed (include/ssasr.h): a one-shot declaration about the next call
-static thread_local int g_exchange_armed = 0;
-extern "C" int ssasr_exchange_armed(int armed) {
-  g_exchange_armed = armed;
-  return SSASR_OK;
-}
-bool ssasr_take_armed() {
-  const bool a = g_exchange_armed != 0;
-  g_exchange_armed = 0;
-  return a;
+// Initial pacing delay of a persistent recurrence (PersistPacer, rnn_kernels.h),
+// in units of 64 cycles; the kernel adapts it from there.  opt < 0: the default.
+static int persist_delay(int opt, int dflt) {
+  if (opt < 0) return dflt;
+  return opt > 96 ? 96 : opt;
 }
 
-// Initial pacing delay of a persistent recurrence (PersistPacer, rnn_kernels.h),
-// in units of 64 cycles; the kernel adapts it from there.
-static int persist_delay(const char* env, int dflt) {
-  const char* v = getenv(env);
-  if (!v) return dflt;
-  const int d = atoi(v);
-  return d < 0 ? 0 : (d > 96 ? 96 : d);
+// A persistent grid is only launched when every workgroup of it can be resident at once on this
+// device (occupancy query x CU count, ssasr_resident_capacity): its workgroups wait for each other,
+// and one that is queued behind the others would never start.  capacity 0 = no device / unknown.
+static bool grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t workgroups) {
+  if (ssasr_options().no_residency_check) return true;
+  const int64_t cap = ssasr_resident_capacity(kernel, threads, dyn_lds);
+  return cap <= 0 || workgroups <= cap;
 }
 
 // ---------------------------------------------------------------------------
@@ -55,8 +52,8 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
                                 const float* b_hh_f, const float* w_ih_r, const float* w_hh_r,
                                 const float* b_ih_r, const float* b_hh_r, float* y, int64_t ys_s,
                                 int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
-                                int32_t* sync_ws, void* stream) {
-  const bool armed = ssasr_take_armed();
+                                int32_t* sync_ws, int armed, void* stream) {
+  const SsasrOptions& opt = ssasr_options();
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
   if (!x || !y || !gates || !cs || !hs) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
@@ -103,21 +100,35 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     const int kpw = (int)(H / 64);
     const int64_t Np = (N + 7) & ~(int64_t)7;
     int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
-    if (const char* v = getenv("SSASR_FWD_NB")) nb = atoi(v) == 1 ? 1 : 2;
+    if (opt.fwd_nb) nb = opt.fwd_nb == 1 ? 1 : 2;
     const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
-    const bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
-                      (H / 4) * 2 * chunks <= 512 && S * Np * H * 4 < (1ll << 31) &&   // <= 2 workgroups per CU
-                      aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
-                      ys_n % 4 == 0 && !getenv("SSASR_NO_PERSISTENT");
+    bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
+                (H / 4) * 2 * chunks <= 512 && S * Np * H * 4 < (1ll << 31) &&   // <= 2 workgroups per CU
+                aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
+                ys_n % 4 == 0 && !opt.no_persistent;
     // status words are zero on entry (caller's contract); only the arrival counters of the
     // counter form need clearing per launch
-    if (sync_ws && getenv("SSASR_PERSISTENT_COUNTER")) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 4 * sizeof(int32_t), st));
+    if (sync_ws && opt.persistent_counter) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 4 * sizeof(int32_t), st));
     // narrow input (the 80 mel bins of the first layer): the persistent kernel's helper wave forms
     // the pre-activations itself; no input projection GEMM (rnn_kernels.h, KI)
-    const bool sentinel_mode = getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
-    const bool fuse_in = fits && sentinel_mode && kpw == 4 && I == 80 && bih[0] && bhh[0] && bih[1] && bhh[1] &&
-                         aligned16(x) && aligned16(w_ih_f) && aligned16(w_ih_r) && xs_s % 4 == 0 && xs_n % 4 == 0 &&
-                         !getenv("SSASR_NO_FUSED_INPUT");
+    const bool sentinel_mode = !opt.persistent_counter;
+    bool fuse_in = fits && sentinel_mode && kpw == 4 && I == 80 && bih[0] && bhh[0] && bih[1] && bhh[1] &&
+                   aligned16(x) && aligned16(w_ih_f) && aligned16(w_ih_r) && xs_s % 4 == 0 && xs_n % 4 == 0 &&
+                   !opt.no_fused_input;
+    // the kernel instance that would run, for the residency check
+    const void* kfn = nullptr;
+#define SSASR_FWD_FN(K, SEN, NBT) reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, SEN, NBT>)
+#define SSASR_FWD_FN_PICK(SEN, NBT) \
+    (kpw == 1 ? SSASR_FWD_FN(1, SEN, NBT) : kpw == 2 ? SSASR_FWD_FN(2, SEN, NBT) : kpw == 4 ? SSASR_FWD_FN(4, SEN, NBT) : SSASR_FWD_FN(8, SEN, NBT))
+    if (fits) {
+      if (fuse_in) kfn = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 1, 5>)
+                                 : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 2, 5>);
+      else if (sentinel_mode) kfn = nb == 1 ? SSASR_FWD_FN_PICK(true, 1) : SSASR_FWD_FN_PICK(true, 2);
+      else kfn = nb == 1 ? SSASR_FWD_FN_PICK(false, 1) : SSASR_FWD_FN_PICK(false, 2);
+      if (!grid_fits(kfn, 320, 0, (H / 4) * 2 * chunks)) { fits = false; fuse_in = false; }
+    }
+#undef SSASR_FWD_FN_PICK
+#undef SSASR_FWD_FN
     if (!fuse_in) {
       const int rc = input_projection();
       if (rc) return rc;
@@ -129,11 +140,11 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }
       p.gates = gates; p.cs = cs; p.hs = hs; p.hx = hx; p.y = y; p.lens = lens;
       p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
-      p.delay = persist_delay("SSASR_PERSIST_DELAY_FWD", 24);
+      p.delay = persist_delay(opt.delay_fwd, 24);
       p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
       dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
       // exchange by sentinel (default) or by arrival counter (SSASR_PERSISTENT_COUNTER=1, for A/B)
-      const bool sentinel = getenv("SSASR_PERSISTENT_COUNTER") == nullptr;
+      const bool sentinel = sentinel_mode;
       if (sentinel && !armed)
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * Np * H), st));
 #define SSASR_FWD_LAUNCH(K, SEN, NBT) \
@@ -191,11 +202,23 @@ extern "C" int64_t ssasr_bilstm_bwd_ring_floats(int64_t S, int64_t N, int64_t H,
   return dirs * ((N + 15) / 16) * BWD_RS_RING * (H / 16) * (H / 16) * 256;
 }
 
+// the K-split kernel instance for H (and halves), for the residency check and the launch
+static const void* bptt_rs_fn(int kpw, bool halves) {
+  if (kpw == 4) return reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<1, 1>);
+  if (kpw == 8) return halves ? reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 2>)
+                              : reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 1>);
+  return halves ? reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 2>)
+                : reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 1>);
+}
+
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
+  const SsasrOptions& opt = ssasr_options();
   const int64_t chunks = (N + 15) / 16;
-  return S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 &&
-         getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr &&
-         getenv("SSASR_NO_PERSISTENT") == nullptr;
+  if (!(S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 &&
+        !opt.persistent_counter && !opt.bptt_gather && !opt.no_persistent))
+    return false;
+  // every workgroup of the one-per-(tile, chunk) grid must be resident (the two-halves grid is checked at launch)
+  return grid_fits(bptt_rs_fn((int)(H / 16), false), 320, (size_t)opt.bptt_reserve_kb * 1024, (H / 16) * dirs * chunks);
 }
 
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
@@ -204,7 +227,8 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
                                  float* dc_state, const float* whh_f, const float* whh_r, bool armed) {
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int kpw = (int)(H / 16);
-  const bool ksplit = getenv("SSASR_PERSISTENT_COUNTER") == nullptr && getenv("SSASR_BPTT_GATHER") == nullptr;
+  const SsasrOptions& opt = ssasr_options();
+  const bool ksplit = !opt.persistent_counter && !opt.bptt_gather;
   if (i1 <= 0) i1 = S;
   const bool ranged = i0 != 0 || i1 != S;
   if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && (!ksplit || !dc_state))) return SSASR_EARG;
@@ -220,18 +244,20 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
   if (ksplit && whh_f && (dirs == 1 || whh_r)) { p.whh[0] = whh_f; p.whh[1] = whh_r; }
   p.whhT = whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens;
   p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
-  p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 16);
+  p.delay = persist_delay(opt.delay_bwd, 16);
   p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
   dim3 pgrid((unsigned)(H / 16), (unsigned)dirs, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
   if (ksplit) {
     // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
     const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
-    p.delay = persist_delay("SSASR_PERSIST_DELAY_BWD", 40);
-    if (i0 == 0 && !armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
+    p.delay = persist_delay(opt.delay_bwd_ksplit, 40);
+    const int reserve = opt.bptt_reserve_kb * 1024;
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
     // (not for launches of fewer than three steps: see the note on in-place rows in rnn_kernels.h)
-    const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && i1 - i0 >= 3 &&
-                        getenv("SSASR_BPTT_HALVES_OFF") == nullptr;
+    const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && i1 - i0 >= 3 && !opt.bptt_halves_off &&
+                        grid_fits(bptt_rs_fn(kpw, true), 320, (size_t)reserve, (H / 16) * dirs * chunks * 2);
+    if (!halves && !grid_fits(bptt_rs_fn(kpw, false), 320, (size_t)reserve, (H / 16) * dirs * chunks)) return SSASR_EARG;
+    if (i0 == 0 && !armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
     if (halves) pgrid.z *= 2;
     // (a range shorter than the hand-off distance between the two halves could rewrite dc_state early)
     if (halves && ranged && i1 < S && i1 - i0 < 4) return SSASR_EARG;
@@ -241,23 +267,15 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // therefore reserves dynamic LDS it never touches, so that its 30-38 KB + 118 KB leave no room for
     // a GEMM workgroup (36 KB) on the same CU: the GEMMs get the other CUs, the recurrence runs at
     // its standalone speed (+4-5 % on the train step).  SSASR_BPTT_SHARED_CU=1 turns it off.
-    static const int reserve = getenv("SSASR_BPTT_SHARED_CU") ? 0 : (getenv("SSASR_BPTT_RESERVE_KB") ? atoi(getenv("SSASR_BPTT_RESERVE_KB")) : 118) * 1024;
-    static bool reserved = false;
-    if (reserve && !reserved) {
-      const void* fns[] = {reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<1, 1>),
-                           reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 2>),
-                           reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 1>),
-                           reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 2>),
-                           reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 1>)};
-      for (const void* f : fns) SSASR_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
-      reserved = true;
-    }
+    // (the attribute is a property of the loaded code object: setting it again is idempotent and costs
+    // no device work)
+    if (reserve) SSASR_HIP(hipFuncSetAttribute(bptt_rs_fn(kpw, halves), hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, reserve, st, p);
     else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, reserve, st, p);
     else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, reserve, st, p);
     else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, reserve, st, p);
     else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, reserve, st, p);
-  } else if (getenv("SSASR_PERSISTENT_COUNTER") == nullptr) {
+  } else if (!opt.persistent_counter) {
     SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(dirs * S * 4 * H * Np), st));
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
     else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, true>), pgrid, pblock, 0, st, p);
@@ -313,7 +331,7 @@ static int bilstm_bwd_impl(bool armed, const float* dy, int64_t ys_s, int64_t ys
   // (rnn_kernels.h, "persistent backward recurrence"), else one launch per step.
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31)) return SSASR_EARG;
   bool persistent = false;
-  if (gx && sync_ws && !getenv("SSASR_NO_PERSISTENT")) {
+  if (gx && sync_ws && !ssasr_options().no_persistent) {
     rc = ssasr_launch_bptt_persistent(direct ? nullptr : ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H,
                                       2, st, 0, 0, nullptr, direct ? w_hh_f : nullptr, direct ? w_hh_r : nullptr,
                                       armed && direct);
@@ -352,8 +370,8 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
                                 float* gates, const float* cs, const float* hs, float* dx, int64_t dxs_s,
                                 int64_t dxs_n, float* dw_ih_f, float* dw_hh_f, float* db_f, float* dw_ih_r,
                                 float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc, float* gx,
-                                int32_t* sync_ws, void* stream) {
-  return bilstm_bwd_impl(ssasr_take_armed(), dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r,
+                                int32_t* sync_ws, int armed, void* stream) {
+  return bilstm_bwd_impl(armed != 0, dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r,
                          w_hh_r, gates, cs, hs, dx, dxs_s, dxs_n, dw_ih_f, dw_hh_f, db_f, dw_ih_r, dw_hh_r, db_r,
                          ws_whhT, ws_dc, gx, sync_ws, stream);
 }
@@ -365,17 +383,32 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
 // second copy of the bias gradient (b_ih and b_hh have the same derivative).
 // Off the critical path of the backward pass: callers may enqueue it on a
 // second stream.
-static hipEvent_t overlap_event() {       // small ring of events that order the second stream after the first
-  static hipEvent_t pool[16];
-  static int next = -1;
-  if (next < 0) {
-    for (auto& e : pool)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    next = 0;
+// Caller-owned events that order the second stream after the first (ssasr_events_create): one set
+// serves every call of its owner in turn -- a stream's wait refers to the record that preceded it,
+// so an event may be recorded again as soon as the wait on it has been enqueued.
+struct SsasrEvents { hipEvent_t ev[SSASR_MAX_SEGMENTS]; };
+
+extern "C" int ssasr_events_create(void** handle) {
+  if (!handle) return SSASR_EARG;
+  SsasrEvents* h = new SsasrEvents();
+  for (int i = 0; i < SSASR_MAX_SEGMENTS; ++i) {
+    const hipError_t e = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(h->ev[j]);
+      delete h;
+      return (int)e;
+    }
   }
-  hipEvent_t e = pool[next];
-  next = (next + 1) % 16;
-  return e;
+  *handle = h;
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_events_destroy(void* handle) {
+  if (!handle) return SSASR_OK;
+  SsasrEvents* h = static_cast<SsasrEvents*>(handle);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  delete h;
+  return SSASR_OK;
 }
 
 // Weight / bias gradients of direction d from the time steps [s_lo, s_hi) only, added to the
@@ -509,16 +542,18 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
                                            int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f,
                                            float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
                                            float* db_r, float* db2_r, float* ws_whhT, float* ws_dc, float* gx,
-                                           int32_t* sync_ws, int segments, void* stream, void* side_stream) {
-  const bool armed = ssasr_take_armed();
-  if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r || !side_stream) return SSASR_EARG;
+                                           int32_t* sync_ws, int armed_in, int segments, void* events,
+                                           void* stream, void* side_stream) {
+  const bool armed = armed_in != 0;
+  if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r || !side_stream || !events) return SSASR_EARG;
+  SsasrEvents* evs = static_cast<SsasrEvents*>(events);
   hipStream_t st = (hipStream_t)stream, side = (hipStream_t)side_stream;
   float* dwih[2] = {dw_ih_f, dw_ih_r};
   float* dwhh[2] = {dw_hh_f, dw_hh_r};
   float* db[2] = {db_f, db_r};
   float* db2[2] = {db2_f, db2_r};
   int nseg = segments;
-  if (nseg > 8) nseg = 8;
+  if (nseg > SSASR_MAX_SEGMENTS) nseg = SSASR_MAX_SEGMENTS;
   if (nseg < 1 || !gx || !sync_ws || !ssasr_bptt_ksplit_ok(S, N, H, 2) || S < 32 * nseg) nseg = 1;
   int rc;
   if (nseg == 1) {
@@ -527,8 +562,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
                          cs, hs, dx, dxs_s, dxs_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws_whhT, ws_dc,
                          gx, sync_ws, stream);
     if (rc) return rc;
-    hipEvent_t ev = overlap_event();
-    if (!ev) return (int)hipErrorOutOfMemory;
+    hipEvent_t ev = evs->ev[0];
     SSASR_HIP(hipEventRecord(ev, st));
     SSASR_HIP(hipStreamWaitEvent(side, ev, 0));
     return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, db2_f, dw_ih_r, dw_hh_r,
@@ -541,15 +575,14 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
   // gradient -- and only then the second stream's work: a range is ~150 us of GPU time on the short
   // layers, less than the host needs to enqueue its seven weight-gradient launches, and a recurrence
   // that waits for the host is time nothing hides (measured: 0.1 ms idle per layer on `stream`).
-  hipEvent_t done[8];
+  hipEvent_t done[SSASR_MAX_SEGMENTS];
   for (int k = 0; k < nseg; ++k) {
     const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
     // the K-split kernel takes its weight slices straight from W_hh: no transposed copy
     rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
                                       ws_dc, w_hh_f, w_hh_r, armed);
     if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
-    done[k] = overlap_event();
-    if (!done[k]) return (int)hipErrorOutOfMemory;
+    done[k] = evs->ev[k];
     SSASR_HIP(hipEventRecord(done[k], st));
   }
   const int64_t rows = S * N;

@@ -586,11 +586,18 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   const bool epi = bt < NB && n < N;
   float cstate = 0.f;
   const int len = (epi && e.lens) ? e.lens[n] : 0x7fffffff;
-  unsigned xo[NB];                           // lane part of the h_{s-1} operand address
+  // lane part of the h_{s-1} operand address.  Columns past N read this chunk's OWN first column
+  // (their products are never stored).  They used to read column 0, which belongs to chunk 0: a
+  // different, independently paced group of workgroups.  With one fresh image per step that is only
+  // a needless dependency, but it is what made an exchange RING time out at N = 48 (commit 2c688db,
+  // gpurun_out/rs.log): chunk 0 may run ahead by any number of steps or finish, and the ring slots
+  // its re-arm stores left holding the fill pattern are never rewritten, so a lagging chunk 1
+  // re-fetched column 0 of them for ever.  A ring is valid only among workgroups that wait for each other.
+  unsigned xo[NB];
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
     const int nn = n0 + 16 * t + r;
-    xo[t] = (unsigned)((q * Np + (nn < N ? nn : 0)) * 16);
+    xo[t] = (unsigned)((q * Np + (nn < N ? nn : n0)) * 16);
   }
 
   for (int i = 0; i < S; ++i) {

@@ -24,12 +24,24 @@ import torch
 import torch.distributed as dist
 
 
+_single = False      # a one-rank process group drives the collective path (SSASR_DIST_SINGLE=1)
+
+
 def init_from_env(backend=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when
-    they are set (torchrun); returns (rank, world_size, local_rank)."""
+    they are set (torchrun); returns (rank, world_size, local_rank).
+    SSASR_DIST_SINGLE=1 with a world of one still creates the process group and keeps the
+    collective path on (broadcast, both all-reduces of GradReducer): a hardware rehearsal of
+    the RCCL calls where only one GPU is at hand."""
+    global _single
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and not os.environ.get('SSASR_DIST_SINGLE'):
         return 0, 1, 0
+    _single = world <= 1
+    world = max(world, 1)
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    os.environ.setdefault('MASTER_PORT', '29511')
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
     if backend is None:
@@ -46,11 +58,16 @@ def init_from_env(backend=None):
 
 
 def is_active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single)
 
 
 def world_size():
     return dist.get_world_size() if is_active() else 1
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def broadcast_flat(flat_data):

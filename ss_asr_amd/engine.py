@@ -1,7 +1,7 @@
 """One ASR train step (the body of ASRTrainer.exec, src/trainer.py:415-438) as a
 reusable object: forward, masked CE, backward, gradient all-reduce across
-ranks, clip + NaN guard + Adadelta.  Used by trainer.py, bench.py and the
-tests so that all of them time and check the same code."""
+ranks, clip + NaN guard + Adadelta.  ASRTrainer.exec, bench.py, smoke() and the
+tests all run THIS object, so that what is timed and checked is what trains."""
 import torch
 
 from . import dist as sdist
@@ -23,6 +23,8 @@ class ASRTrainStep:
         ops.set_wgrad_listener(self.reducer.wgrad_enqueued)
         self._one = torch.ones((), device=self.flat.data.device)
         self._grads_clean = False      # True right after a step that zeroed them in its update kernel
+        self.last_logits = None        # [B, U, V] of the most recent step (for the trainer's logging)
+        self.last_done = None          # (grad_norm, skipped) of the last step whose words have arrived
 
     def forward_loss(self, x, y, x_lens, ans_len):
         _, logits, att = self.model(x, ans_len, teacher=y, state_len=x_lens)
@@ -31,7 +33,14 @@ class ASRTrainStep:
     def __call__(self, x, y, x_lens, ans_len):
         """x [B,T,F] float32, y [B,L] int64 (both on the GPU), x_lens host list
         (descending), ans_len = max label length - 1.  Returns the loss tensor
-        (on the device; reading it synchronises)."""
+        (on the device; reading it synchronises).
+
+        The verdict of the PREVIOUS step (gradient norm, NaN skip, and whether one of its
+        persistent launches timed out) is picked up here when its words have reached the host
+        -- no synchronisation; a timeout raises."""
+        done = self.optim.poll()
+        if done is not None:
+            self.last_done = done
         if not self._grads_clean:
             self.optim.zero_grad()
         self._grads_clean = False
@@ -39,14 +48,23 @@ class ASRTrainStep:
         # the attention map is only looked at by valid(): no device-to-host copy per train step
         keep, self.model.att_on_host = getattr(self.model, 'att_on_host', True), False
         try:
-            loss, _, _ = self.forward_loss(x, y, x_lens, ans_len)
+            # every persistent launch of the step reports into the optimizer's status row
+            with ops.shared_status_row(self.optim.status_row):
+                loss, self.last_logits, _ = self.forward_loss(x, y, x_lens, ans_len)
+                loss.backward(self._one)
         finally:
             self.model.att_on_host = keep
-        loss.backward(self._one)
         scale = self.reducer.finish()
         self.optim.clip_and_step(self.grad_clip, grad_scale=scale, zero_grad=True)
         self._grads_clean = True
         return loss
+
+    def finish(self):
+        """Waits for the last step's words: returns its (grad_norm, skipped); raises on a timeout."""
+        done = self.optim.poll(wait=True)
+        if done is not None:
+            self.last_done = done
+        return self.last_done
 
 
 def label_geometry(y_cpu):

@@ -30,28 +30,53 @@ def plan_batches(n_rows, batch_size):
     return list(range(0, n_rows - batch_size + 1, batch_size))
 
 
+def rank_batches(n_batches, rank, world):
+    """Batch indices rank `rank` of `world` runs in one epoch: r, r + world, ... over the full
+    rounds of `world` batches.  The tail that does not fill a round is dropped, so every rank runs
+    n_batches // world steps: a rank alone in the gradient all-reduce would wait for ever, and
+    unequal step counts would let validation / checkpoints fire at different steps per rank."""
+    return [k * world + rank for k in range(n_batches // world)]
+
+
 class GpuResidentLoader:
     def __init__(self, tsv_file, batch_size, device, chars=TOKENS + ALL_CHARS, rank=0, world=1,
                  bucket=False, time_multiple=8):
-        self.device = torch.device(device)
-        if self.device.type != 'cuda':
-            raise RuntimeError('GpuResidentLoader keeps the corpus on the GPU (no CPU path)')
         rows = load_index(tsv_file)
         if bucket:
             rows.sort(key=lambda r: r['unpadded_num_frames'], reverse=True)
         self.rows = rows
-        self.batch_size = batch_size
-        self.rank, self.world = rank, world
-        self.time_multiple = time_multiple
-        self.char2idx = {c: i for i, c in enumerate(chars)}
-        self.starts = plan_batches(len(rows), batch_size)
-
-        kept, lens = [], []
-        for r in rows[:self.starts[-1] + batch_size if self.starts else 0]:
+        char2idx = {c: i for i, c in enumerate(chars)}
+        starts = plan_batches(len(rows), batch_size)
+        used = rows[:starts[-1] + batch_size if starts else 0]
+        kept = []
+        for r in used:
             a = np.load(r['path_to_fbank']).astype(np.float32, copy=False)
             n = int((a.sum(-1) != 0).sum())              # prepare_x's definition of a frame
             kept.append(a[:n])
-            lens.append(n)
+        labels = [[char2idx[c] for c in r['normalized_text']] for r in used]
+        self._setup(kept, labels, batch_size, device, rank, world, time_multiple, char2idx[SOS_TKN])
+
+    @classmethod
+    def from_arrays(cls, utterances, labels, batch_size, device, rank=0, world=1, time_multiple=8, pad=0):
+        """The same loader over in-memory data: `utterances` = unpadded float32 [n_i, F] arrays in
+        index order, `labels` = their character-id rows ('<' ... '>').  Used by bench.py, whose
+        corpus is synthetic: the timed step then assembles its batch exactly as ASRTrainer's does."""
+        self = cls.__new__(cls)
+        self.rows = None
+        n = len(plan_batches(len(utterances), batch_size)) * batch_size
+        self._setup([np.asarray(u, dtype=np.float32) for u in utterances[:n]], [list(l) for l in labels[:n]],
+                    batch_size, device, rank, world, time_multiple, pad)
+        return self
+
+    def _setup(self, kept, labels, batch_size, device, rank, world, time_multiple, pad):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('GpuResidentLoader keeps the corpus on the GPU (no CPU path)')
+        self.batch_size = batch_size
+        self.rank, self.world = rank, world
+        self.time_multiple = time_multiple
+        self.starts = plan_batches(len(kept), batch_size)
+        lens = [int(a.shape[0]) for a in kept]
         self.feature_dim = kept[0].shape[1] if kept else 0
         self.x_lens = lens
         offs = np.zeros(len(lens) + 1, dtype=np.int64)
@@ -62,9 +87,8 @@ class GpuResidentLoader:
         self.lens_dev = torch.tensor(lens, dtype=torch.int32, device=self.device)
         # labels: padded with <sos> like ASRDataset.get_batched_texts
         self.y, self.y_lens = [], []
-        pad = self.char2idx[SOS_TKN]
         for s in self.starts:
-            enc = [[self.char2idx[c] for c in r['normalized_text']] for r in rows[s:s + batch_size]]
+            enc = labels[s:s + batch_size]
             L = max(len(e) for e in enc)
             y = np.full((batch_size, L), pad, dtype=np.int64)
             for i, e in enumerate(enc):
@@ -89,6 +113,5 @@ class GpuResidentLoader:
         return x, list(lens), self.y[b], list(self.y_lens[b])
 
     def __iter__(self):
-        for b in range(len(self.starts)):
-            if b % self.world == self.rank:
-                yield (b,) + self.batch(b)
+        for b in rank_batches(len(self.starts), self.rank, self.world):
+            yield (b,) + self.batch(b)

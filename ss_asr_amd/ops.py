@@ -5,7 +5,7 @@ libssasr_hip.so.  There is no CPU implementation: calling these with CPU
 tensors, or without the shared object, raises.
 """
 import ctypes as C
-
+import os
 import weakref
 
 import torch
@@ -15,19 +15,47 @@ from ._lib import check
 
 
 _persist_status = []     # int32[8] workspaces of persistent launches not yet checked
+TIMEOUT_MESSAGE = 'ss_asr_amd: a persistent recurrence / decode loop timed out'
 
 
 def check_persistent_status():
     """Raises if any persistent kernel launched since the last call timed out
-    waiting for its peers (synchronises the device).  Call it where the host
-    synchronises anyway (ASRTrainer does at its logging steps)."""
+    waiting for its peers (synchronises the device).  For callers that drive the ops
+    themselves; a train step (engine.ASRTrainStep) gets the same verdict without a
+    synchronisation from the status row that travels with its optimizer statistics."""
     global _persist_status
     pending, _persist_status = _persist_status, []
     if pending and any(int(v) for v in torch.stack([t[i] for t, i in pending]).cpu()):
-        raise RuntimeError('ss_asr_amd: a persistent recurrence / decode loop timed out')
+        raise RuntimeError(TIMEOUT_MESSAGE)
 
 
 _status_pools = {}
+_shared_status = None    # one int32[8] row for every persistent launch of the step in progress
+
+
+class shared_status_row:
+    """Context manager: every persistent launch inside it reports into `row` (int32[8] on the
+    device, zero on entry) instead of a row of its own.  The sentinel exchange only ever writes
+    1 into words 4 / 5, so the launches of a whole train step can share one row, which the
+    caller then reads back with its other per-step statistics (no extra copy, no
+    synchronisation).  Not taken when the arrival-counter form is selected: its counters
+    (words 0..3) are per launch."""
+
+    def __init__(self, row):
+        self.row = row
+
+    def __enter__(self):
+        global _shared_status
+        self.prev = _shared_status
+        counter_form = C.c_int(0)
+        _lib.load().ssasr_get_option(b'SSASR_PERSISTENT_COUNTER', C.byref(counter_form))
+        _shared_status = None if counter_form.value else self.row
+        return self
+
+    def __exit__(self, *exc):
+        global _shared_status
+        _shared_status = self.prev
+        return False
 
 
 def _status_words(device):
@@ -35,6 +63,8 @@ def _status_words(device):
     asks.  Rows of one zero-initialised pool are handed out in turn, so that no fill kernel
     runs per launch; a row is reused after 4096 launches and still holds zeros unless a
     launch timed out (check_persistent_status() reports that, and it is fatal anyway)."""
+    if _shared_status is not None:
+        return _shared_status
     key = str(device)
     pool = _status_pools.get(key)
     if pool is None:
@@ -47,9 +77,27 @@ def _status_words(device):
 def _track_status(sync, index):
     """Remembers a status word for check_persistent_status(); checks by itself
     before the list grows without bound (a caller that never checks)."""
+    if sync is _shared_status:
+        return                      # its owner reads it back
     _persist_status.append((sync, index))
     if len(_persist_status) > 4096:
         check_persistent_status()
+
+
+_events = None
+# step ranges per BiLSTM layer whose weight gradients overlap the recurrence (1..8)
+bptt_segments = int(os.environ.get('SSASR_BPTT_SEGMENTS', '4'))
+
+
+def _overlap_events():
+    """The caller-owned event set of ssasr_bilstm_bwd_overlapped (one per process: autograd's
+    backward runs the layers one after another on one thread)."""
+    global _events
+    if _events is None:
+        h = C.c_void_p()
+        check(_lib.load().ssasr_events_create(C.byref(h)), 'ssasr_events_create')
+        _events = h
+    return _events
 
 
 # ---- weight-gradient overlap ------------------------------------------------
@@ -80,7 +128,7 @@ _SENTINEL_I32 = 0x7FC0DEAD        # PERSIST_SENTINEL (csrc/rnn_kernels.h): the e
 class ExchangeArena:
     """Exchange workspaces of one pass over the model (all forward images, or all BPTT rings),
     laid out back to back and armed with ONE fill: every slot is reserved before the first one
-    is taken; the calls that receive a slot are told so with ssasr_exchange_armed."""
+    is taken; the calls that receive a slot are told so with their `armed` argument."""
 
     def __init__(self, device):
         self.device, self.sizes, self.offsets, self.buf = device, [], None, None
@@ -235,16 +283,17 @@ class _BiLSTM(torch.autograd.Function):
         hs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         # workspaces of the persistent recurrence (exchange image + counters)
         hx_floats = 2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4 if N <= 128 and H % 64 == 0 else 0
+        armed = 0
         if slots is not None and slots[1] is not None and hx_floats:
             hx = slots[0].take(slots[1])              # armed with the arena's one fill
             assert hx.numel() >= hx_floats
-            lib.ssasr_exchange_armed(1)
+            armed = 1
         else:
             hx = torch.empty(hx_floats, device=x.device, dtype=torch.float32) if hx_floats else None
         sync = _status_words(x.device) if hx is not None else None
         check(lib.ssasr_bilstm_fwd(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
                                    _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
-                                   _stream()), 'ssasr_bilstm_fwd')
+                                   armed, _stream()), 'ssasr_bilstm_fwd')
         if sync is not None:
             _track_status(sync, 4)
         ctx.save_for_backward(x, lens, gates, cs, hs, *w)
@@ -287,22 +336,19 @@ class _BiLSTM(torch.autograd.Function):
         sync = _status_words(dev) if gx is not None else None
         if sync is not None:
             _track_status(sync, 4)
-        if armed:
-            lib.ssasr_exchange_armed(1)               # consumed by the backward call below
         if sinks is not None:
             # Weight gradients go to the side stream, accumulated into the flat gradient
             # buffer.  The BPTT is cut into 4 segments whose weight-gradient GEMMs start
             # while the next segment recurs: the first layer is the last of the backward
             # pass and nothing else would run beside its GEMMs (measured +2 % with 4
             # segments on every layer, against +0.7 % on the first only).
-            import os
-            segments = int(os.environ.get('SSASR_BPTT_SEGMENTS', '4'))
+            segments = bptt_segments
             side = side_stream()
             check(lib.ssasr_bilstm_bwd_overlapped(
                 _p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens), _p(w[0]), _p(w[1]), _p(w[4]),
                 _p(w[5]), _p(gates), _p(cs), _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in sinks], _p(ws_t),
-                _p(ws_dc), _p(gx), _p(sync), segments, _stream(), C.c_void_p(side.cuda_stream)),
-                'ssasr_bilstm_bwd_overlapped')
+                _p(ws_dc), _p(gx), _p(sync), int(armed), segments, _overlap_events(), _stream(),
+                C.c_void_p(side.cuda_stream)), 'ssasr_bilstm_bwd_overlapped')
             for t in (gates, x, hs):
                 t.record_stream(side)
             _notify_wgrad(sinks)
@@ -310,7 +356,7 @@ class _BiLSTM(torch.autograd.Function):
         check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
                                    _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
-                                   _p(ws_dc), _p(gx), _p(sync), _stream()), 'ssasr_bilstm_bwd')
+                                   _p(ws_dc), _p(gx), _p(sync), int(armed), _stream()), 'ssasr_bilstm_bwd')
         # inputs: x, lens, steps, batch_first, sinks, then w_ih,w_hh,b_ih,b_hh per direction
         return (dx, None, None, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
                 dw[3], dw[4], dw[5], dw[5].clone())
@@ -528,8 +574,7 @@ class _DecoderLoop(torch.autograd.Function):
             setattr(d, k, t.data_ptr())
         for k, t in bufs.items():
             setattr(d, k, t.data_ptr())
-        if 'ws_hx1' in bufs and ctx_armed:
-            lib.ssasr_exchange_armed(1)
+        d.ws_armed = 1 if ('ws_hx1' in bufs and ctx_armed) else 0
         check(lib.ssasr_decoder_fwd(C.byref(d), _stream()), 'ssasr_decoder_fwd')
         ctx.dec = d
         ctx.slots = slots
@@ -593,8 +638,7 @@ class _DecoderLoop(torch.autograd.Function):
         if sinks is not None:
             g.db1_2, g.db2_2 = sk['b_hh1'].data_ptr(), sk['b_hh2'].data_ptr()
             g.defer_wgrad = 1
-        if armed:
-            lib.ssasr_exchange_armed(1)
+        g.ws_armed = 1 if armed else 0
         check(lib.ssasr_decoder_bwd(C.byref(d), C.byref(g), _stream()), 'ssasr_decoder_bwd')
         dpsi = ()
         if ctx.psi:

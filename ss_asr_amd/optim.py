@@ -60,8 +60,13 @@ class FusedAdadelta(torch.optim.Optimizer):
         self.square_avg = torch.zeros_like(flat.data)
         self.acc_delta = torch.zeros_like(flat.data)
         self._ws = ops.clip_adadelta_ws(flat.numel, dev)
-        self.stats = torch.zeros(2, device=dev)          # [grad_norm, skipped]
-        self._host_stats = torch.zeros(2, pin_memory=True)
+        # per-step words that reach the host in ONE asynchronous copy: [grad_norm, skipped] written
+        # by the update kernel, then the int32[8] status row of the step's persistent launches
+        # (ops.shared_status_row; words 4 / 5 turn non-zero when a launch timed out)
+        self._words = torch.zeros(2 + 8, device=dev)
+        self.stats = self._words[:2]
+        self.status_row = self._words[2:].view(torch.int32)
+        self._host_words = torch.zeros(2 + 8, pin_memory=dev.type == 'cuda')
         self._pending = None
 
     def zero_grad(self, set_to_none=False):
@@ -75,8 +80,8 @@ class FusedAdadelta(torch.optim.Optimizer):
         ops.clip_adadelta_(self.flat.data, self.flat.grad, self.square_avg, self.acc_delta,
                            self._ws, self.stats, grad_scale=grad_scale, max_norm=max_norm,
                            lr=g['lr'], rho=g['rho'], eps=g['eps'], zero_grad=zero_grad)
-        # the norm / NaN flag reach the host asynchronously; see poll()
-        self._host_stats.copy_(self.stats, non_blocking=True)
+        # the norm / NaN flag / status row reach the host asynchronously; see poll()
+        self._host_words.copy_(self._words, non_blocking=True)
         self._pending = torch.cuda.Event()
         self._pending.record()
 
@@ -85,7 +90,10 @@ class FusedAdadelta(torch.optim.Optimizer):
         self.clip_and_step(max_norm=float('inf'))
 
     def poll(self, wait=False):
-        """Returns (grad_norm, skipped) of the most recent finished step, or None."""
+        """Returns (grad_norm, skipped) of the most recent finished step, or None when there is
+        none (or, without `wait`, when its words have not arrived yet).  Raises if a persistent
+        launch of that step reported a timeout in the shared status row: its results, and the
+        update computed from them, are not to be trusted."""
         if self._pending is None:
             return None
         if wait:
@@ -93,4 +101,6 @@ class FusedAdadelta(torch.optim.Optimizer):
         elif not self._pending.query():
             return None
         self._pending = None
-        return float(self._host_stats[0]), bool(self._host_stats[1] != 0)
+        if self._host_words[2:].view(torch.int32).any():
+            raise RuntimeError(ops.TIMEOUT_MESSAGE)
+        return float(self._host_words[0]), bool(self._host_words[1] != 0)

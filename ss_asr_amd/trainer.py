@@ -5,12 +5,17 @@ unchanged: ``getattr(trainer, 'ASRTrainer')(config, paras)`` then
 
 Differences, all inside the same call surface:
   * the model computes through libssasr_hip.so (MI355X only);
-  * parameters and gradients live in flat buffers and Solver.step runs the
-    fused clip + NaN-guard + Adadelta kernel (optim.py) for Adadelta, the
-    reference's clip_grad_norm_ + optim.step() for any other optimizer type;
-  * launched under torchrun (WORLD_SIZE > 1) every rank takes the batches
-    ``index % world == rank`` and gradients are averaged with one RCCL
-    all-reduce per step (dist.py); rank 0 alone logs and checkpoints;
+  * with Adadelta (conf/default.yaml) one iteration of exec() is ONE call of
+    engine.ASRTrainStep -- the object bench.py times: zero_grad folded into the
+    update kernel, forward, masked CE, backward with the weight gradients on a
+    second stream, two-bucket gradient all-reduce, fused clip + NaN guard +
+    Adadelta (optim.py), no device-to-host copy -- fed by the device-resident
+    loader (gpu_loader.py).  Any other optimizer type takes the reference's
+    sequence (zero_grad, forward, backward, Solver.step with clip_grad_norm_);
+  * launched under torchrun (WORLD_SIZE > 1) rank r takes batches r, r + world,
+    ... of every full round of `world` batches (a tail that does not fill a round
+    is dropped, so every rank runs the same number of steps) and gradients are
+    averaged over RCCL (dist.py); rank 0 alone logs and checkpoints;
   * valid() no longer dies on the undefined names of src/trainer.py:531.
 """
 import math
@@ -26,7 +31,7 @@ from .ASRDataset import load_asr_dataset, prepare_x, prepare_y
 from .LogHandler import LogHandler
 from .TrackerHandler import TrackerHandler
 from .asr import ASR
-from .optim import FlatParameters, FusedAdadelta
+from .optim import FusedAdadelta
 from .postprocess import calc_acc, calc_err, draw_att
 
 
@@ -167,12 +172,16 @@ class ASRTrainer(Solver):
                     self.gpu_loader.bytes_resident() / 1e6))
 
     def _train_batches(self):
-        """(batch index, x, x_lens, y, y_lens) for this rank's batches of one epoch."""
+        """(batch index, x, x_lens, y, y_lens) for this rank's batches of one epoch.  Every rank
+        yields the same number of batches: a tail that does not fill a round of `world` batches
+        is dropped (a rank alone in an all-reduce would wait for ever)."""
         if self.gpu_loader is not None:
             yield from self.gpu_loader
             return
+        from .gpu_loader import rank_batches
+        mine = set(rank_batches(len(self.train_set), self.rank, self.world))
         for b_ind, (x, y) in enumerate(self.train_set):
-            if b_ind % self.world != self.rank:
+            if b_ind not in mine:
                 continue
             (x, x_lens) = prepare_x(x, device=self.device)
             (y, y_lens) = prepare_y(y, device=self.device)
@@ -182,10 +191,12 @@ class ASRTrainer(Solver):
         self.asr_model = self.setup_module(ASR, self.ckppath, self.mapper.get_dim(),
                                            **self.config['asr']['mdl'])
         opt = self.config['asr']['opt']
+        self.train_step = None
         if opt['type'] == 'Adadelta' and self.device.type == 'cuda':
-            self.flat = FlatParameters(self.asr_model)
-            sdist.broadcast_flat(self.flat.data)
-            self.optim = FusedAdadelta(self.flat, lr=opt['learning_rate'], eps=1e-8)
+            # the fused step (engine.ASRTrainStep): what bench.py times is what trains
+            from .engine import ASRTrainStep
+            self.train_step = ASRTrainStep(self.asr_model, lr=opt['learning_rate'], eps=1e-8, grad_clip=5.0)
+            self.flat, self.optim = self.train_step.flat, self.train_step.optim
         else:
             self.optim = getattr(torch.optim, opt['type'])(
                 self.asr_model.parameters(), lr=opt['learning_rate'], eps=1e-8)
@@ -207,15 +218,24 @@ class ASRTrainer(Solver):
                 state_len = x_lens
                 ans_len = max(y_lens) - 1
 
-                self.optim.zero_grad()
-                _, prediction, _ = self.asr_model(x, ans_len, teacher=y, state_len=state_len)
-                label = y[:, 1:ans_len + 1].contiguous()
-                loss = self._loss(prediction, y, ans_len)
-                loss.backward()
-                self.step(self.asr_model.parameters(), self.optim)
-
-                if self.tr.step % self.logging_step == 0:
-                    ops.check_persistent_status()      # the host synchronises here anyway
+                if self.train_step is not None:
+                    # src/trainer.py:419-438 as one fused step; a persistent launch that timed out
+                    # in the previous step raises here (its status words arrive with the optimizer's)
+                    before = self.train_step.last_done
+                    loss = self.train_step(x, y, state_len, ans_len)
+                    prediction = self.train_step.last_logits
+                    done = self.train_step.last_done
+                    if done is not before and done is not None and done[1]:
+                        self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+                else:
+                    self.optim.zero_grad()
+                    _, prediction, _ = self.asr_model(x, ans_len, teacher=y, state_len=state_len)
+                    loss = self._loss(prediction, y, ans_len)
+                    loss.backward()
+                    self.step(self.asr_model.parameters(), self.optim)
+                    if self.tr.step % self.logging_step == 0:
+                        ops.check_persistent_status()      # the host synchronises here anyway
+                label = y[:, 1:ans_len + 1]
                 if self.rank == 0:
                     if self.tr.step % self.logging_step == 0:
                         self.lg.scalar('train_loss', loss.item(), self.tr.step)
@@ -228,10 +248,11 @@ class ASRTrainer(Solver):
                         self.verbose("Model saved at step {}".format(self.tr.step))
                         torch.save(self.asr_model.state_dict(), self.ckppath)
                 if self.tr.step % self.valid_step == 0:
-                    self.optim.zero_grad()
                     self.valid()
                 self.tr.do_step()
             epoch += 1
+        if self.train_step is not None:
+            self.train_step.finish()           # the last step's verdict (raises on a timeout)
 
     def valid(self):
         """Greedy decoding for ans_len + 30 steps without a teacher, loss on the

@@ -78,6 +78,39 @@ def _worker(rank, world, port, out):
         gathered = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
         assert torch.allclose(flat.grad, sum(gathered), atol=1e-5), step
+    # An odd number of batches: both ranks run the same number of steps (the tail batch is
+    # dropped), so every all-reduce has its peer and the shared step counter stays aligned.
+    from ss_asr_amd.gpu_loader import rank_batches
+    mine = rank_batches(5, rank, world)
+    assert mine == [rank, 2 + rank]
+    for _ in mine:
+        t = torch.ones(4)
+        dist.all_reduce(t)
+        assert float(t[0]) == world
+
+    # SURVEY.md 8(e) parity statement on stand-in steps: a rank's loss on its local batch equals
+    # the single-process loss on that batch, and the averaged gradient equals the mean of the
+    # per-rank single-process gradients (a linear model stands in for the HIP step, which has no
+    # CPU path; the collective contract under test is dist.py's).
+    torch.manual_seed(5)
+    w0 = torch.randn(6, 3)
+    data = [(torch.randn(4, 6, generator=torch.Generator().manual_seed(50 + r)),
+             torch.randn(4, 3, generator=torch.Generator().manual_seed(60 + r))) for r in range(world)]
+
+    def local_step(r):
+        w = w0.clone().requires_grad_(True)
+        xb, yb = data[r]
+        loss = ((xb @ w - yb) ** 2).mean()
+        loss.backward()
+        return float(loss), w.grad.reshape(-1).clone()
+    singles = [local_step(r) for r in range(world)]          # what one process would compute per batch
+    my_loss, my_grad = local_step(rank)
+    assert my_loss == singles[rank][0]
+    buf = my_grad.clone()
+    sc = sdist.allreduce_grad(buf)
+    want = sum(g for _, g in singles) / world
+    assert torch.allclose(buf * sc, want, atol=1e-6)
+
     if rank == 0:
         with open(out, 'w') as f:
             f.write('ok')

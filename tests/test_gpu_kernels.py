@@ -119,7 +119,7 @@ def test_bilstm_segmented_bptt_with_overlapped_weight_gradients(N, S, I, H, segm
     gradients are accumulated from a second stream, range by range."""
     from ss_asr_amd import ops
     from ss_asr_amd.optim import FlatParameters
-    monkeypatch.setenv('SSASR_BPTT_SEGMENTS', str(segments))
+    monkeypatch.setattr(ops, 'bptt_segments', segments)
     lens = sorted(np.random.default_rng(3).integers(S // 3, S + 1, size=N).tolist(), reverse=True)
     lens[0] = S
     x = rnd(N, S, I, seed=51)
@@ -307,7 +307,7 @@ def test_first_layer_fused_input_projection_equals_gemm(monkeypatch):
     """I = 80, H = 256: the forward recurrence's helper wave forms W_ih x + b itself
     (rnn_kernels.h, KI); SSASR_NO_FUSED_INPUT=1 takes the GEMM.  Same MFMA products in a
     different summation order: outputs and gradients agree to rounding."""
-    from ss_asr_amd import ops
+    from ss_asr_amd import _lib, ops
     torch.manual_seed(5)
     N, S, I, H = 20, 70, 80, 256
     x = (torch.randn(N, S + 3, I) * 0.5).to(dev())
@@ -320,15 +320,15 @@ def test_first_layer_fused_input_projection_equals_gemm(monkeypatch):
     dy = (torch.randn(N, S, 2 * H) * 0.1).to(dev())
     out = []
     for fused in (True, False):
-        if fused:
-            monkeypatch.delenv('SSASR_NO_FUSED_INPUT', raising=False)
-        else:
-            monkeypatch.setenv('SSASR_NO_FUSED_INPUT', '1')
-        xs = x.clone().requires_grad_(True)
-        ws = [t.clone().requires_grad_(True) for t in w]
-        y = ops.bilstm(xs, lens.to(dev()), S, True, tuple(ws))
-        y.backward(dy)
-        torch.cuda.synchronize()
+        old = _lib.set_option('SSASR_NO_FUSED_INPUT', 0 if fused else 1)     # switches are read once: set, not setenv
+        try:
+            xs = x.clone().requires_grad_(True)
+            ws = [t.clone().requires_grad_(True) for t in w]
+            y = ops.bilstm(xs, lens.to(dev()), S, True, tuple(ws))
+            y.backward(dy)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option('SSASR_NO_FUSED_INPUT', old)
         out.append((y.detach(), xs.grad, [t.grad for t in ws]))
     ops.check_persistent_status()
     (ya, dxa, dwa), (yb, dxb, dwb) = out

@@ -245,10 +245,8 @@ def test_persistent_decode_loop_equals_multi_launch_loop():
     modes = [0, 1, 0, 0, 2, 1, 1, 0, 0, 0, 1, 0, 2, 0]
     uniforms = torch.rand(U, B, device='cuda')
     results = []
-    for env in (None, '1'):
-        if env:
-            import os
-            os.environ['SSASR_NO_PERSISTENT_DECODER'] = env
+    for per_step in (0, 1):
+        _lib.set_option('SSASR_NO_PERSISTENT_DECODER', per_step)
         f = feat.clone().requires_grad_(True)
         comp = ops.attn_precompute(f, model.attention.psi.weight, model.attention.psi.bias)
         logits, att, chars = ops.decoder_loop(f, comp, enc_len, teacher, modes, uniforms,
@@ -260,8 +258,7 @@ def test_persistent_decode_loop_equals_multi_launch_loop():
         results.append((logits.detach().cpu(), att.cpu(), chars.cpu(), f.grad.cpu(),
                         model.decoder.layer_1.weight_ih.grad.cpu().clone(),
                         model.attention.phi.weight.grad.cpu().clone()))
-    import os
-    os.environ.pop('SSASR_NO_PERSISTENT_DECODER', None)
+    _lib.set_option('SSASR_NO_PERSISTENT_DECODER', 0)
     a, b = results
     assert torch.equal(a[2], b[2])                                  # same characters fed
     np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), atol=2e-5, rtol=0)

@@ -100,3 +100,52 @@ def test_gpu_resident_loader_yields_what_prepare_x_and_prepare_y_yield(tmp_path)
         assert torch.equal(y, yr)
     # sharding: rank r of 2 sees batches r, r + 2, ...
     assert [t[0] for t in GpuResidentLoader(index, 8, dev, rank=1, world=2)] == [1]
+
+
+def test_asr_trainer_steps_follow_the_oracle_trajectory(tmp_path):
+    """ASRTrainer.exec runs engine.ASRTrainStep fed by the device-resident loader -- the objects
+    bench.py times.  Four iterations (two epochs over two batches of 16, Adadelta state carried
+    over) against the CPU oracle's trajectory from the same checkpoint: every logged train loss,
+    and the weights at the end."""
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_x, prepare_y
+    from ss_asr_amd.engine import ASRTrainStep
+    from ss_asr_amd.trainer import ASRTrainer
+    root = str(tmp_path)
+    index, lens = make_corpus(root, n=32, t_max=120, feat=80, seed=9)
+    cfg = config_for(index)
+    cfg['asr'].update(valid_step=10 ** 9, save_step=10 ** 9, wer_step=10 ** 9, n_epochs=2)
+    cfg['asr']['mdl'].update(encoder_state_size=64, decoder_state_size=64, mlp_out_size=32)
+    paras = types.SimpleNamespace(name='traj', logdir=os.path.join(root, 'runs'),
+                                  ckpdir=os.path.join(root, 'result'), verbose=False, seed=1)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = ASRTrainer(cfg, paras)
+    tr.load_data()
+    tr.set_model()
+    assert isinstance(tr.train_step, ASRTrainStep) and tr.gpu_loader is not None
+    start = {k: v.detach().cpu().clone() for k, v in tr.asr_model.state_dict().items()}
+    # step 0 of exec() also validates (0 % valid_step == 0), as in the reference
+    tr.exec()
+    tr.close()
+    torch.cuda.synchronize()
+    events = [json.loads(l) for l in open(os.path.join(root, 'runs', 'traj', 'asr', 'events.jsonl'))]
+    losses = [e['value'] for e in events if e['key'] == 'asr_train_loss']
+    assert len(losses) == 4
+
+    ref = lo.OracleASR(50, 64, 64, 32, 80, 1.0)
+    ref.load_state_dict(start)
+    ropt = lo.make_optimizer(ref)
+    _, _, loader = load_asr_dataset(index, batch_size=16, n_jobs=0)
+    batches = []
+    for x, y in loader:
+        x, x_lens = prepare_x(x)
+        y, _ = prepare_y(y)
+        batches.append((x[:, :max(x_lens)].contiguous(), y))
+    assert len(batches) == 2
+    want = []
+    for k in range(4):
+        x, y = batches[k % 2]
+        want.append(lo.train_step(ref, ropt, x, y)[0])
+    np.testing.assert_allclose(losses, want, atol=2e-4, rtol=0)
+    got = tr.asr_model.state_dict()
+    worst = max(float((got[k].cpu() - v).abs().max()) for k, v in ref.state_dict().items())
+    assert worst < 5e-4, worst

@@ -43,9 +43,12 @@ def test_argument_errors_are_negative_and_need_no_gpu():
     from ss_asr_amd import _lib
     lib = _lib.load()
     assert lib.ssasr_bilstm_fwd(None, 0, 0, 0, 0, 0, 0, None, *([None] * 8), None, 0, 0, None,
-                                None, None, None, None, None) < 0
+                                None, None, None, None, 0, None) < 0
     assert lib.ssasr_decoder_fwd(None, None) < 0
     assert lib.ssasr_clip_adadelta_ws(10269874) == 1 + (10269874 + 4095) // 4096
+    # diagnostic switches: known names round-trip, unknown names are refused
+    assert _lib.set_option('SSASR_GEMM_TILE', 64) == 0 and _lib.set_option('SSASR_GEMM_TILE', 0) == 64
+    assert lib.ssasr_set_option(b'SSASR_NO_SUCH_SWITCH', 1) < 0
 
 
 def test_ops_refuse_cpu_tensors():
@@ -226,3 +229,57 @@ def test_gpu_loader_plans_the_reference_batches_and_refuses_the_cpu(tmp_path):
     index, _ = make_corpus(str(tmp_path), n=9)
     with pytest.raises(RuntimeError, match='no CPU path'):
         GpuResidentLoader(index, 4, 'cpu')
+
+
+# ------------------------------------------------------- drop-in boundary ----
+REFERENCE_TRAIN = '/root/reference/src/train.py'
+
+
+@pytest.mark.skipif(not os.path.isfile(REFERENCE_TRAIN),
+                    reason='build-container only: the reference tree does not travel to the GPU box')
+def test_reference_train_script_runs_unchanged_against_the_shims(tmp_path):
+    """`python -m ss_asr_amd.run_reference <reference>/src/train.py ...`
+    executes the reference's unmodified entry point with its bare imports (`import trainer`,
+    src/train.py:9) bound to ss_asr_amd.  Without a GPU the run must get all the way through
+    argument parsing, yaml, seeding, ASRTrainer construction, load_data and set_model, and stop at
+    the first arithmetic with the product's "no CPU path" error -- never with an ImportError from
+    the reference's own modules (librosa, editdistance, tensorboardX are absent here)."""
+    import subprocess
+    import yaml
+    root = str(tmp_path)
+    index, _ = make_corpus(root, n=16, t_max=24, feat=80, seed=2)
+    conf = {'asr': {'opt': {'type': 'Adadelta', 'learning_rate': 1.0},
+                    'mdl': {'encoder_state_size': 32, 'mlp_out_size': 16, 'decoder_state_size': 32,
+                            'tf_rate': 0.9, 'feature_dim': 80},
+                    'train_index': index, 'valid_index': index, 'wer_step': 1, 'train_batch_size': 16,
+                    'valid_batch_size': 16, 'n_epochs': 1, 'loader_jobs': 0}}
+    conf_path = os.path.join(root, 'conf.yaml')
+    with open(conf_path, 'w') as f:
+        yaml.safe_dump(conf, f)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    env.pop('PYTHONPATH', None)
+    res = subprocess.run([sys.executable, '-m', 'ss_asr_amd.run_reference', REFERENCE_TRAIN, 'ASRTrainer', 'dropin',
+                          conf_path, os.path.join(root, 'runs'), os.path.join(root, 'result')],
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    out = res.stdout
+    assert 'ModuleNotFoundError' not in out and 'ImportError' not in out, out[-2000:]
+    if torch.cuda.is_available():
+        assert res.returncode == 0, out[-2000:]
+    else:
+        assert res.returncode != 0 and 'no CPU path' in out, out[-2000:]
+    # the trainer that ran was ours: it wrote its tracker where the reference's Solver would
+    assert os.path.isdir(os.path.join(root, 'result', 'dropin'))
+
+
+def test_flat_shims_bind_the_product_modules():
+    """Importing `trainer` / `asr` / `ASRDataset` the way the reference's scripts do, with
+    ss_asr_amd/flat first on sys.path, yields the product's classes."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import trainer, asr, ASRDataset; "
+            "import ss_asr_amd.trainer as t, ss_asr_amd.asr as a; "
+            "assert trainer.ASRTrainer is t.ASRTrainer and asr.ASR is a.ASR and asr.Listener is a.Listener; "
+            "assert hasattr(ASRDataset, 'load_asr_dataset') and hasattr(trainer, 'Solver'); print('bound')"
+            % os.path.join(ROOT, 'ss_asr_amd', 'flat'))
+    res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=120)
+    assert res.returncode == 0 and 'bound' in res.stdout, res.stdout[-2000:]

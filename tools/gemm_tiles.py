@@ -2,7 +2,7 @@
 time with 128 x 128 and with 64 x 64 tiles (SSASR_GEMM_TILE), NN (input projection) and NT (input gradient)."""
 import os, sys; sys.path.insert(0, '.')
 import torch
-from ss_asr_amd import ops
+from ss_asr_amd import _lib, ops
 dev = 'cuda'
 def t(fn, n=10):
     fn(); torch.cuda.synchronize()
@@ -19,9 +19,9 @@ for tb, name in ((0, 'NN'), (1, 'NT')):
         out = torch.zeros(M, N, device=dev)
         r = []
         for tile in ('128', '64'):
-            os.environ['SSASR_GEMM_TILE'] = tile
+            _lib.set_option('SSASR_GEMM_TILE', int(tile))
             r.append(t(lambda: ops.gemm(a, b, ta=False, tb=bool(tb), out=out)))
-        del os.environ['SSASR_GEMM_TILE']
+        _lib.set_option('SSASR_GEMM_TILE', 0)
         auto = t(lambda: ops.gemm(a, b, ta=False, tb=bool(tb), out=out))
         print('%s M=%6d  128: %7.1f us %6.1f TF | 64: %7.1f us %6.1f TF | auto %7.1f' % (
             name, M, r[0], 2.0 * M * N * K / r[0] / 1e6, r[1], 2.0 * M * N * K / r[1] / 1e6, auto), flush=True)

@@ -37,13 +37,12 @@ def run_once():
     return [p.grad.detach().clone() for p in model.parameters()], float(loss)
 
 
-# reference gradients: per-step kernels, no segments (environment toggles are read per launch)
-saved = {k: os.environ.get(k) for k in ('SSASR_NO_PERSISTENT', 'SSASR_BPTT_SEGMENTS')}
-os.environ['SSASR_NO_PERSISTENT'] = '1'; os.environ['SSASR_BPTT_SEGMENTS'] = '1'
+# reference gradients: per-step kernels, no segments
+from ss_asr_amd import _lib
+old_np, old_seg = _lib.set_option('SSASR_NO_PERSISTENT', 1), ops.bptt_segments
+ops.bptt_segments = 1
 ref, ref_loss = run_once()
-for k, v in saved.items():
-    if v is None: os.environ.pop(k, None)
-    else: os.environ[k] = v
+_lib.set_option('SSASR_NO_PERSISTENT', old_np); ops.bptt_segments = old_seg
 scale = [float(r.abs().max()) + 1e-30 for r in ref]
 dev = np.zeros((N, len(ref)))
 for it in range(N):
