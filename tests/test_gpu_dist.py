@@ -2,7 +2,8 @@
 the driver's): process-group init on the nccl (= RCCL) backend, parameter broadcast, and both
 all-reduces of dist.GradReducer -- the early tail bucket on the second stream, the head after the
 backward pass -- inside engine.ASRTrainStep.  With one rank every collective is the identity, so
-losses and weights must equal the run without a process group bit for bit; what the test proves
+losses and weights must equal the run without a process group (to the rounding of the atomically
+accumulated weight gradients); what the test proves
 is that the library loads, the collectives are issued on the right streams and nothing deadlocks.
 Multi-rank arithmetic is covered by tests/test_ddp_cpu.py (gloo, world size 2)."""
 import json
@@ -82,5 +83,7 @@ def test_rccl_single_rank_train_steps_equal_the_plain_run():
     # step 1: one collective over the whole flat gradient (which gradients arrive by the second
     # stream is learned from it); steps 2, 3: the tail bucket early, the head after backward
     assert rccl['calls'] == [n, n - split, split, n - split, split], rccl['calls']
-    assert rccl['losses'] == plain['losses']
-    assert rccl['norm'] == plain['norm'] and rccl['wsum'] == plain['wsum']
+    # identity collectives: equal up to the run-to-run rounding of the split-K weight-gradient atomics
+    assert max(abs(a - b) for a, b in zip(rccl['losses'], plain['losses'])) < 1e-5
+    assert abs(rccl['norm'] - plain['norm']) < 1e-5 * max(1.0, plain['norm'])
+    assert abs(rccl['wsum'] - plain['wsum']) < 1e-6 * plain['wsum']

@@ -86,6 +86,11 @@ def lstm_weights(I, H, seed):
     (5, 9, 20, 16, [7, 6, 3, 2, 1]),          # input longer than max(lens)
     (33, 6, 8, 16, [6] * 20 + [3] * 13),      # more than one 32-column chunk
     (3, 10, 80, 256, [10, 8, 5]),             # production widths (vector path)
+    # 48 / 64 columns at H = 256: the forward takes two 32-column chunks of 256 workgroups in all,
+    # the second chunk of N = 48 half empty (its padded lanes once aliased chunk 0's column, which is
+    # what timed out under an exchange ring: DESIGN.md 4.2); the BPTT runs 3 / 4 chunks without halves
+    (48, 40, 64, 256, [40] * 10 + [33] * 20 + [9] * 18),
+    (64, 24, 64, 256, [24] * 30 + [11] * 34),
 ])
 def test_bilstm_packed_forward_backward(N, T, I, H, lens):
     from ss_asr_amd import ops
