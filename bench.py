@@ -160,13 +160,13 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
 
     def fwd():
         ops.check(lib.ssasr_bilstm_fwd(p(x), N * I, I, S, N, I, H, None, *[p(t) for t in w], p(y), N * 2 * H, 2 * H,
-                                       p(gates), p(cs), p(hs), p(hx), p(sync), st), 'ssasr_bilstm_fwd')
+                                       p(gates), p(cs), p(hs), p(hx), p(sync), 0, st), 'ssasr_bilstm_fwd')
 
     def bwd():
         ops.check(lib.ssasr_bilstm_bwd(p(dy), N * 2 * H, 2 * H, p(x), N * I, I, S, N, I, H, None,
                                        p(w[0]), p(w[1]), p(w[4]), p(w[5]), p(gates), p(cs), p(hs),
                                        None, N * I, I, None, None, None, None, None, None,
-                                       p(ws_t), p(ws_dc), p(gx), p(sync), st), 'ssasr_bilstm_bwd')
+                                       p(ws_t), p(ws_dc), p(gx), p(sync), 0, st), 'ssasr_bilstm_bwd')
 
     def i2h():
         # the input projection exactly as ssasr_bilstm_fwd launches it: both directions as the two

@@ -192,6 +192,60 @@ class OracleASR(nn.Module):
         return enc_len, torch.stack(logits, dim=1), torch.stack(atts, dim=1)
 
 
+class OracleTextEncoder(nn.Module):
+    """TextEncoder, src/text_autoencoder.py:96-107: embedding + 2-layer BiLSTM over the padded
+    character rows (no packing: padded positions are encoded too)."""
+
+    def __init__(self, char_dim, emb_dim, state_size, num_layers):
+        super().__init__()
+        self.emb = nn.Embedding(char_dim, emb_dim)
+        self.blstm = nn.LSTM(input_size=emb_dim, hidden_size=state_size, num_layers=num_layers,
+                             bidirectional=True, batch_first=True)
+
+    def forward(self, y):
+        out, _ = self.blstm(self.emb(y))
+        return out
+
+
+class OracleTextAutoEncoder(nn.Module):
+    """TextAutoEncoder, src/text_autoencoder.py:8-94: a text encoder in place of the Listener,
+    then the ASR model's own attention / speller / embed / char_trans (shared parameters)."""
+
+    def __init__(self, char_dim, emb_dim=128, state_size=256, num_layers=2):
+        super().__init__()
+        self.encoder = OracleTextEncoder(char_dim, emb_dim, state_size, num_layers)
+
+    def forward(self, asr, y, y_noised, decode_step, noise_lens=None):
+        feat = self.encoder(y_noised)                                     # text_autoencoder.py:52
+        batch = y_noised.shape[0]
+        asr.decoder.init_rnn(batch)                                       # :55-56
+        asr.attention.reset_enc_mem()
+        emb = asr.embed(y)                                                # :59
+        last = asr.embed(torch.zeros(batch, dtype=torch.long))            # :62-63
+        outs = []
+        for t in range(decode_step):                                      # :69
+            _, ctx = asr.attention(asr.decoder.state_list[0], feat, noise_lens)
+            cur = asr.char_trans(asr.decoder(torch.cat([last, ctx], dim=-1)))
+            if t < decode_step - 1:                                       # :81
+                if random.random() <= asr.tf_rate:
+                    last = emb[:, t + 1, :]
+                else:
+                    pick = torch.distributions.Categorical(F.softmax(cur, dim=-1)).sample()
+                    last = asr.embed(pick)
+            else:
+                last = asr.embed(torch.argmax(cur, dim=-1))               # :88
+            outs.append(cur)
+        return noise_lens, torch.stack(outs, dim=1)
+
+
+def tae_loss(logits, y):
+    """TAETrainer's loss, src/trainer.py:662-669: the label of output t is y[:, t]."""
+    b, t, c = logits.shape
+    per_tok = F.cross_entropy(logits.reshape(b * t, c), y.reshape(-1), ignore_index=0, reduction='none')
+    per_utt = per_tok.view(b, t).sum(-1) / (y != 0).sum(-1).to(torch.float32)
+    return per_utt.mean()
+
+
 def inverse_cdf_bounds(logits_row):
     """Cumulative unnormalised probabilities of softmax(logits_row) in float32, summed in
     index order: (run [V], total).  A draw with uniform u picks the first v with
@@ -366,3 +420,15 @@ def seeded_weights(model, seed):
             n = cell.bias_ih.numel()
             cell.bias_ih[n // 4:n // 2] = 1.0
     return model
+
+
+def seeded_tae_weights(tae, seed):
+    """numpy-PCG64 parameters for a TextAutoEncoder (reference or oracle: same parameter names and
+    order): matrices N(0, 1/sqrt(fan_in)), the embedding N(0, 1), biases N(0, 0.1) -- non-zero on
+    purpose, the ASR fixtures only ever see zero encoder biases."""
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for name, p in tae.named_parameters():
+            std = 1.0 if name == 'encoder.emb.weight' else (1.0 / math.sqrt(p.shape[-1]) if p.dim() > 1 else 0.1)
+            p.copy_(torch.from_numpy((rng.standard_normal(tuple(p.shape)) * std).astype(np.float32)))
+    return tae

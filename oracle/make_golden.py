@@ -22,7 +22,7 @@ import torch.nn as nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from ref_harness import import_reference  # noqa: E402
-from las_oracle import seeded_weights  # noqa: E402
+from las_oracle import seeded_tae_weights, seeded_weights  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 
@@ -145,6 +145,65 @@ def capture(asr_mod, name, dims, lens, y_lens, tf_rate, seed, weights_seed=None,
         name, loss.item(), float(grad_norm), enc_len[:6], os.path.getsize(path) / 1024))
 
 
+def noisy_text_batch(rng, y_lens, drop_rate, vocab=50):
+    """Label rows '<' chars '>' padded with 0 and their noised copies (characters dropped with
+    probability drop_rate, never the tokens: src/ASRDataset.py:111-127), as TAETrainer gets them."""
+    rows, noisy = [], []
+    for l in y_lens:
+        chars = rng.integers(3, vocab, size=l).tolist()
+        rows.append([0] + chars + [1])
+        noisy.append([0] + [c for c in chars if rng.random() > drop_rate] + [1])
+    def pad(rs):
+        w = max(len(r) for r in rs)
+        out = np.zeros((len(rs), w), dtype=np.int64)
+        for i, r in enumerate(rs):
+            out[i, :len(r)] = r
+        return torch.from_numpy(out)
+    return pad(rows), pad(noisy)
+
+
+def capture_tae(asr_mod, tae_mod, name, dims, tae_dims, y_lens, tf_rate, seed, drop_rate=0.2):
+    """TextAutoEncoder.forward (src/text_autoencoder.py:31-94) + TAETrainer's loss
+    (src/trainer.py:662-672) + backward on the real reference, both models with seeded weights."""
+    seed_all(seed)
+    asr = asr_mod.ASR(*dims, tf_rate)
+    seeded_weights(asr, seed + 100)
+    tae = tae_mod.TextAutoEncoder(dims[0], *tae_dims)
+    seeded_tae_weights(tae, seed + 200)
+    rng = np.random.default_rng(seed + 1000)
+    y, y_noise = noisy_text_batch(rng, y_lens, drop_rate, dims[0])
+    y_l = [int(v) + 1 for v in (y != 0).sum(-1)]                 # prepare_y
+    noise_l = [int(v) + 1 for v in (y_noise != 0).sum(-1)]
+    decode_step = max(y_l)
+    assert decode_step == y.shape[1]
+    seed_all(seed + 7)
+    _, logits = tae(asr, y, y_noise, decode_step, noise_lens=noise_l)
+    metric = nn.CrossEntropyLoss(ignore_index=0, reduction='none')          # trainer.py:637-638
+    b, t, c = logits.shape
+    loss = metric(logits.view(b * t, c), y.view(-1))
+    loss = torch.mean(torch.sum(loss.view(b, t), dim=-1) / torch.sum(y != 0, dim=-1).to(torch.float32))
+    loss.backward()
+    out = dict(dims=np.array(dims), tae_dims=np.array(tae_dims), tf_rate=np.float64(tf_rate),
+               seed=np.int64(seed), rng_seed=np.int64(seed + 7), y=y.numpy(), y_noise=y_noise.numpy(),
+               noise_lens=np.array(noise_l), decode_step=np.int64(decode_step),
+               logits=logits.detach().numpy(), loss=np.float64(loss.item()))
+    out['asr_weights_seed'] = np.int64(seed + 100)
+    out['tae_weights_seed'] = np.int64(seed + 200)
+    grads = {('tae.' + k): p.grad for k, p in tae.named_parameters()}
+    grads.update({('asr.' + k): p.grad for k, p in asr.named_parameters() if p.grad is not None})
+    names = sorted(grads)
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array([grads[k].double().norm().item() for k in names])
+    for k in ('tae.encoder.emb.weight', 'tae.encoder.blstm.weight_hh_l0', 'tae.encoder.blstm.weight_ih_l1_reverse',
+              'asr.decoder.layer_1.weight_ih', 'asr.attention.phi.weight', 'asr.attention.psi.weight',
+              'asr.embed.weight', 'asr.char_trans.bias'):
+        out['g_head/' + k] = grads[k].reshape(-1)[:256].numpy()
+    out['asr_no_grad'] = np.array(sorted(k for k, p in asr.named_parameters() if p.grad is None))
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-18s loss %.6f  decode_step %d  %.1f KB' % (name, loss.item(), decode_step, os.path.getsize(path) / 1024))
+
+
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)
     asr_mod = import_reference()
@@ -175,6 +234,18 @@ def main(only=None):
     # deterministic.  The fixture carries the recipe of the batch, not its 8 MB of frames.
     sys.path.insert(0, os.path.dirname(HERE))
     from ss_asr_amd.synthetic import config2_batches
+    # config 5's shared decoder: the reference's TextAutoEncoder drives asr.attention / decoder /
+    # embed / char_trans (src/text_autoencoder.py:55-94).  Full layer sizes: 12 rows (the persistent
+    # decode loop's shape) and 40 rows (more than its 32: the per-step kernels); a small model too.
+    import text_autoencoder as tae_mod                          # reference module (path set by import_reference)
+    real_tae = capture_tae
+
+    def cap_tae(name, *a, **k):
+        if not only or name in only:
+            real_tae(asr_mod, tae_mod, name, *a, **k)
+    cap_tae('tae_full_b12', full, (128, 256, 2), [14, 12, 12, 11, 9, 9, 8, 6, 5, 5, 3, 2], 1.0, 31)
+    cap_tae('tae_full_b40', full, (128, 256, 2), [3 + (7 * k) % 13 for k in range(40)], 1.0, 32)
+    cap_tae('tae_small_tf05', small, (8, 32, 2), [10, 7, 5, 3, 3], 0.5, 33)
     for name, pick, seed, wseed in (('bench_b32_t800', 0, 8, 14), ('bench_b32_median', 4, 9, 15)):
         x, y, lens = config2_batches(8, batch_size=32, feat_dim=80, seed=1)[pick]
         ylens = [int(v) - 1 for v in (y != 0).sum(-1)]

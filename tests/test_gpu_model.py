@@ -409,3 +409,46 @@ def test_train_step_edge_shapes_match_the_oracle(frames, chars):
     assert not skipped
     assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)
     assert abs(norm - ref_norm) < 2e-3 * max(1.0, ref_norm), (norm, ref_norm)
+
+
+@pytest.mark.parametrize('name', ['tae_full_b12', 'tae_full_b40'])
+def test_text_autoencoder_on_the_kernels_matches_reference(golden, name):
+    """SURVEY.md 8 f4 (config 5's shared decoder): ss_asr_amd.text_autoencoder.TextAutoEncoder runs
+    the reference's attend-and-spell loop (src/text_autoencoder.py:55-94) through ssasr_decoder_fwd /
+    _bwd with the text encoder's output as the listener features.  Logits, TAETrainer's loss and the
+    gradients (of the text encoder and of the shared asr.attention / decoder / embed / char_trans)
+    against the fixture captured from the reference; 12 rows take the persistent decode loop, 40 rows
+    (more than its 32) the per-step kernels."""
+    from ss_asr_amd import ops
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.text_autoencoder import TextAutoEncoder, tae_loss
+    fx = golden(name)
+    dims = [int(v) for v in fx['dims']]
+    torch.manual_seed(0)
+    asr = ASR(*dims, float(fx['tf_rate']))
+    lo.seeded_weights(asr, int(fx['asr_weights_seed']))
+    tae = TextAutoEncoder(dims[0], *[int(v) for v in fx['tae_dims']])
+    lo.seeded_tae_weights(tae, int(fx['tae_weights_seed']))
+    ref_keys = lo.OracleTextAutoEncoder(dims[0], *[int(v) for v in fx['tae_dims']]).state_dict().keys()
+    assert list(tae.state_dict().keys()) == list(ref_keys)          # checkpoint compatibility
+    asr, tae = asr.to('cuda:0'), tae.to('cuda:0')
+    y, y_noise = torch.from_numpy(fx['y']).cuda(), torch.from_numpy(fx['y_noise']).cuda()
+    random.seed(int(fx['rng_seed']))
+    lens, logits = tae(asr, y, y_noise, int(fx['decode_step']), noise_lens=[int(v) for v in fx['noise_lens']])
+    assert lens == [int(v) for v in fx['noise_lens']]
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), fx['logits'], atol=5e-5, rtol=0)
+    loss = tae_loss(logits, y)
+    assert abs(float(loss) - float(fx['loss'])) < 1e-4
+    loss.backward()
+    torch.cuda.synchronize()
+    ops.check_persistent_status()
+    grads = {('tae.' + k): p.grad for k, p in tae.named_parameters()}
+    grads.update({('asr.' + k): p.grad for k, p in asr.named_parameters() if p.grad is not None})
+    names = [str(n) for n in fx['grad_names']]
+    assert sorted(grads) == names                                    # the Listener gets no gradient
+    got = np.array([grads[k].double().norm().item() for k in names])
+    np.testing.assert_allclose(got, fx['grad_norms'], rtol=1e-3, atol=1e-6)
+    for k in fx.files:
+        if k.startswith('g_head/'):
+            np.testing.assert_allclose(grads[k[7:]].reshape(-1)[:256].cpu().numpy(), fx[k], atol=2e-5, rtol=0,
+                                       err_msg=k)

@@ -121,3 +121,31 @@ def test_config1_shape_b16_t400(golden):
     enc_len, logits, att, loss = run(fx, model)
     assert enc_len == [int(v) for v in fx['enc_len']]
     assert abs(float(loss) - float(fx['loss'])) < 1e-4
+
+
+@pytest.mark.parametrize('name', ['tae_full_b12', 'tae_full_b40', 'tae_small_tf05'])
+def test_text_autoencoder_oracle_matches_reference(golden, name):
+    """the oracle's TextAutoEncoder + TAETrainer loss against the fixture captured
+    from the reference's (src/text_autoencoder.py:31-94, src/trainer.py:662-672), including the
+    sampled steps of the tf_rate 0.5 case (same RNG consumption) and every gradient norm."""
+    fx = golden(name)
+    dims = [int(v) for v in fx['dims']]
+    torch.manual_seed(0)
+    asr = lo.OracleASR(*dims, float(fx['tf_rate']))
+    lo.seeded_weights(asr, int(fx['asr_weights_seed']))
+    tae = lo.OracleTextAutoEncoder(dims[0], *[int(v) for v in fx['tae_dims']])
+    lo.seeded_tae_weights(tae, int(fx['tae_weights_seed']))
+    y, y_noise = torch.from_numpy(fx['y']), torch.from_numpy(fx['y_noise'])
+    s = int(fx['rng_seed'])
+    random.seed(s); np.random.seed(s); torch.manual_seed(s)
+    _, logits = tae(asr, y, y_noise, int(fx['decode_step']), noise_lens=[int(v) for v in fx['noise_lens']])
+    np.testing.assert_allclose(logits.detach().numpy(), fx['logits'], atol=1e-5, rtol=0)
+    loss = lo.tae_loss(logits, y)
+    assert abs(float(loss) - float(fx['loss'])) < 1e-5
+    loss.backward()
+    grads = {('tae.' + k): p.grad for k, p in tae.named_parameters()}
+    grads.update({('asr.' + k): p.grad for k, p in asr.named_parameters() if p.grad is not None})
+    names = [str(n) for n in fx['grad_names']]
+    assert sorted(grads) == names
+    got = np.array([grads[k].double().norm().item() for k in names])
+    np.testing.assert_allclose(got, fx['grad_norms'], rtol=2e-4, atol=1e-7)
