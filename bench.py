@@ -101,8 +101,12 @@ def attention_roofline(device, B=32, T=100, A=128, E=512, D=256, iters=400):
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
             cst = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for _ in range(iters):
-                lib.ssasr_attn_step_fwd(*args, B, T, A, E, D, *outs, cst)
+            # split-T form (T > 128): the workspace's two exchange buffers alternate call by call
+            ws, phase = ops.attn_workspace(B, T, A, E, device, calls=iters)
+            wsp = C.c_void_p(ws.data_ptr()) if ws is not None else None
+            assert iters % 2 == 0         # every replay then starts on the same, re-armed buffer
+            for i in range(iters):
+                lib.ssasr_attn_step_fwd(*args, B, T, A, E, D, *outs, wsp, (phase + i) & 1, cst)
     torch.cuda.current_stream().wait_stream(side)
     graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -115,10 +119,62 @@ def attention_roofline(device, B=32, T=100, A=128, E=512, D=256, iters=400):
     s = 4
     nbytes = B * T * (A + E) * s + B * T * (s + 1) + B * (D + E) * s + D * A * s
     achieved = nbytes / (us * 1e-6) / 1e9
-    return dict(kernel=('attn_step_fwd_fast_kernel<%d>' % ((T + 127) // 128)) if T <= 256 else 'attn_step_fwd_long_kernel', bound='hbm', achieved=round(achieved, 1),
+    return dict(kernel='attn_step_fwd_split_kernel' if T > 128 else 'attn_step_fwd_fast_kernel<1>', bound='hbm', achieved=round(achieved, 1),
                 peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
                 traffic=None, bytes_per_launch=nbytes, us_per_launch=round(us, 3),
                 shape=dict(B=B, T=T, A=A, E=E), timing='HIP-graph replay of %d launches, HIP events' % iters)
+
+
+def decode_loop_attention(device, B=32, T=100, U=52, A=128, E=512, D=256):
+    """The attention of the TRAIN STEP runs inside decoder_fwd_persistent_kernel (one launch for
+    all U decode steps; 64 attention workgroups keep their slices of feat in LDS and re-read comp
+    from L2).  Live: HIP events around ssasr_decoder_fwd -> us per decode step.  From the in-kernel
+    stamps of the diagnostic build (tools/dectrace.py, committed as profiles/r02_dectrace.txt): the
+    attention stage of a step (its h1 seen -> its context published).  `achieved_equivalent` prices
+    the step's ALGORITHMIC bytes (comp + feat + ...) against that stage time; the bytes
+    that actually leave L2 / HBM per step are comp, h1 and the context only."""
+    from ss_asr_amd import ops
+    from ss_asr_amd.asr import ASR
+    torch.manual_seed(5)
+    model = ASR(**DIMS).to(device)
+    feat = torch.randn(B, T, E, device=device)
+    enc_len = torch.full((B,), T, dtype=torch.int32, device=device)
+    teacher = torch.randint(3, 50, (B, U + 2), device=device).to(torch.int32)
+    modes = [0] * U
+    with torch.no_grad():
+        comp = ops.attn_precompute(feat, model.attention.psi.weight, model.attention.psi.bias)
+        run = lambda: ops.decoder_loop(feat, comp, enc_len, teacher, modes, None, model._decoder_params())
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+    ops.check_persistent_status()
+    us_step = e0.elapsed_time(e1) * 1e3 / 5 / U
+    s = 4
+    nbytes = B * T * (A + E) * s + B * T * (s + 1) + B * (D + E) * s + D * A * s
+    moved = B * T * A * s + 2 * B * T * s + B * (D + E) * s          # comp from L2, alpha out, h1 in, context out
+    stage_us, src = None, os.path.join(ROOT, 'profiles', 'r02_dectrace.txt')
+    try:
+        with open(src) as f:
+            for line in f:
+                if line.startswith('attention (64 wg)'):
+                    vals = dict(tok.split('=') for tok in line.split() if '=' in tok)
+                    stage_us = float(vals['s4']) - float(vals['s1'])
+    except (OSError, KeyError, ValueError):
+        pass
+    out = dict(kernel='decoder_fwd_persistent_kernel<true> (attention workgroups)', us_per_decode_step=round(us_step, 2),
+               note='whole ssasr_decoder_fwd call / U: includes the embedding gather, the workspace fill and the logits GEMM',
+               algorithmic_bytes_per_step=nbytes, bytes_moved_per_step=moved, shape=dict(B=B, T=T, U=U))
+    if stage_us:
+        out.update(attention_stage_us=round(stage_us, 2), stage_source='profiles/r02_dectrace.txt (trace build, s1 -> s4)',
+                   achieved_equivalent=round(nbytes / (stage_us * 1e-6) / 1e9, 1),
+                   frac_equivalent=round(nbytes / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
+    return out
 
 
 def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
@@ -350,8 +406,18 @@ def main():
         'final_loss': round(last_loss, 5),
     }
     if not args.no_roofline:
-        att = attention_roofline(device)
-        note('attention kernel: %s' % att)
+        # The attention-softmax kernel, standalone, where its HBM roofline is reachable: BASELINE.json
+        # configs[3]'s longest encoder output (3000 frames -> T' = 375, 31 MB per launch; split-T form),
+        # with the training shape (T' = 100, 8.4 MB: the launch floor alone is most of it) beside it and,
+        # for the train step itself, the attention stage INSIDE the persistent decode loop, where feat
+        # stays in LDS for the whole loop (stage time from the in-kernel stamps of profiles/r02_dectrace.txt).
+        att = attention_roofline(device, T=375)
+        note('attention kernel, T\' = 375: %s' % att)
+        att100 = attention_roofline(device, T=100)
+        note('attention kernel, T\' = 100: %s' % att100)
+        att['at_training_shape'] = {k: att100[k] for k in ('kernel', 'achieved', 'frac', 'bytes_per_launch', 'us_per_launch', 'shape')}
+        att['in_decode_loop'] = decode_loop_attention(device)
+        note('attention stage of the persistent decode loop: %s' % att['in_decode_loop'])
         bptt, fwd_rec = recurrence_roofline(device)
         note('BPTT recurrence: %s' % bptt)
         note('forward recurrence: %s' % fwd_rec)
@@ -361,7 +427,7 @@ def main():
                 t = json.load(f)
             bptt['traffic'] = t.get('bptt_bytes_per_launch')
             fwd_rec['traffic'] = t.get('fwd_bytes_per_launch')
-            att['traffic'] = t.get('attention_bytes_per_launch')
+            att['at_training_shape']['traffic'] = t.get('attention_bytes_per_launch')
         out['roofline'] = bptt                       # dominant kernel of the step (profiles/)
         out['roofline_forward_recurrence'] = fwd_rec
         out['roofline_attention'] = att

@@ -176,10 +176,19 @@ int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat, int64_t r
  * state [B][D], w_phi [A][D] (phi.weight), comp [B][T][A], feat [B][T][E],
  * enc_len int32[B].  Two launches: q [B][A] = tanh(phi(state)) (small MFMA
  * kernel), then energies + masked softmax + context: att [B][T], ctx [B][E].
- * state == NULL skips the first launch and takes q as an input. */
+ * state == NULL skips the first launch and takes q as an input.
+ * ws: optional workspace of ssasr_attn_step_ws_floats(B, T, A, E) floats (0: the shape has no
+ * use for one) that enables the split-T form for long encoder outputs (T > 128 at A = 128,
+ * E = 512): frames of an utterance spread over several workgroups (comp and feat are streamed
+ * exactly once, by >= 256 workgroups), partial softmaxes exchanged through the workspace inside
+ * the launch.  ws is two exchange buffers: a call uses buffer ws_phase & 1 and re-arms the other.
+ * EVERY word of ws must hold the fill pattern 0x7FC0DEAD before the first call, and consecutive
+ * calls on one workspace must alternate ws_phase (0, 1, 0, ...) and be ordered on one stream. */
+int64_t ssasr_attn_step_ws_floats(int64_t B, int64_t T, int64_t A, int64_t E);
 int ssasr_attn_step_fwd(const float* state, const float* w_phi, const float* comp,
                         const float* feat, const int32_t* enc_len, int64_t B, int64_t T, int64_t A,
-                        int64_t E, int64_t D, float* q, float* att, float* ctx, void* stream);
+                        int64_t E, int64_t D, float* q, float* att, float* ctx, float* ws, int ws_phase,
+                        void* stream);
 
 /* Backward of one step given dctx [B][E] and datt [B][T] (may be NULL):
  * de [B][T] (derivative w.r.t. the masked energies) and dqpre [B][A]
@@ -229,6 +238,10 @@ typedef struct ssasr_decoder {
                                           * uploaded it with its other per-step integers)   */
   int32_t ws_armed;                      /* != 0: ws_hx1, ws_hx2, ws_qx and ctx already hold the fill
                                           * pattern 0x7FC0DEAD (written on the same stream)  */
+  float* ws_attn;                        /* optional: ssasr_attn_step_ws_floats(B, T, A, E) floats holding the fill
+                                          * pattern 0x7FC0DEAD, for the per-step loop's attention (T > 128)    */
+  int32_t ws_attn_phase;                 /* phase of step 0 (step t uses ws_attn_phase + t): the buffer the
+                                          * previous call on this workspace did NOT use last                */
 } ssasr_decoder;
 
 int ssasr_decoder_fwd(const ssasr_decoder* d, void* stream);

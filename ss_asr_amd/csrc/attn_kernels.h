@@ -261,6 +261,269 @@ __global__ __launch_bounds__(256) void attn_step_fwd_long_kernel(AttnFwd p) {
   }
 }
 
+// ------------------------------ split-T form ------------------------------
+// Long encoder outputs (T > 128: BASELINE.json configs[3], T' up to 375) at A = 128, E = 512.
+// The forms above give one utterance to E / 128 workgroups -- B x 4 = 128 of them for 256 CUs, each
+// re-deriving the softmax from the whole of comp[b] -- and ran at 1.8-2.1 TB/s.  Here the FRAMES of
+// an utterance are split over NS workgroups of 8 * RPH rows: every byte of comp and feat is read by
+// exactly one workgroup, all of a workgroup's loads (RPH x 5 16-byte loads per lane) are in flight
+// before any arithmetic, and B x NS >= 256 workgroups fill the chip.  A workgroup produces a
+// partial softmax of its rows -- its own maximum m_s, S_s = sum exp(e - m_s) and the unnormalised
+// partial context sum exp(e - m_s) h_t -- publishes it, and then takes part in the combination
+//   M = max m_s,  S = sum_s exp(m_s - M) S_s,  ctx = sum_s exp(m_s - M) ctx_s / S,  alpha_t = exp(e_t - M) / S
+// (fixed order: deterministic): workgroup s gathers the (m, S) pairs of all NS records and, of their
+// partial contexts, only the column quads s, s + NS, ... (2 KB in all), writes those quads of ctx
+// and the alphas of its own rows.
+// Hand-off: the self-verifying exchange of the persistent recurrences (rnn_kernels.h).  Records are
+// stored write-through (sc1, 16-byte stores) into a buffer that holds the NaN pattern 0x7FC0DEAD;
+// readers use sc1 loads and re-fetch any 16-byte piece that still holds the pattern.  The workspace
+// is TWO such buffers: a call exchanges through buffer `phase` and, first thing, restores the
+// pattern in the other one (idle in this call: its last readers belong to the previous call), so
+// callers alternate `phase` between consecutive calls on one workspace.
+// What was measured on the way (B = 32, T' = 375, HIP-graph replay, kernel + boundary): streaming
+// and publishing alone 4.9 us (6.3 TB/s); ONE workgroup per utterance combining 11-12.8 us in every
+// form tried -- after a drain + returning atomic on an arrival counter, after a sentinel wait, or
+// with no wait at all: its 35 KB of sc1 loads alone cost 6 us (MI355X_MICROARCH.md,
+// handoff-payload: 12-20 GB/s per consumer at these sizes); a second launch for the combination
+// 10.9 us (any dependent launch with a load -> compute -> store chain costs 4.8 us here).
+// Every workgroup of an utterance waits for the other NS - 1: the host takes this form only when
+// the occupancy query says the whole grid is resident at once; spins are bounded.
+#ifndef SSASR_ATTN_VARIANT
+#define SSASR_ATTN_VARIANT 0
+#endif
+constexpr int ATTN_PART = 512 + 32;        // floats per record: partial context (16 lines), then one line (m_s, S_s, -, ...)
+#if SSASR_ATTN_VARIANT == 7                // diagnostic build: per-workgroup phase stamps (100 MHz clock)
+__device__ unsigned long long g_attn_trace[8192 * 8];
+#define ATTN_STAMP(k) do { if (threadIdx.x == 0) g_attn_trace[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ATTN_STAMP(k)
+#endif
+constexpr unsigned ATTN_SENTINEL = 0x7FC0DEADu;
+
+struct AttnSplit {
+  const float* q;        // [B][128] or null (zeros)
+  const float* comp;     // [B][T][128]
+  const float* feat;     // [B][T][512]
+  const int32_t* lens;   // [B] or null
+  float* att;            // att[b * att_sb + t]
+  int64_t att_sb;
+  float* ctx;            // ctx[b * ctx_ld + e]
+  int64_t ctx_ld;
+  float* part;           // [2][B][NS][ATTN_PART] records; buffer `phase` is this call's
+  int B, T, NS, phase;
+};
+
+typedef unsigned attn_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ attn_u32x4 attn_ld_raw(const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);        // sc1
+}
+__device__ __forceinline__ void attn_st_sc1(const __amdgpu_buffer_rsrc_t& rs, unsigned off, float4 v) {
+  const f32x4 f = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(attn_u32x4, f), rs, (int)off, 0, 16);
+}
+__device__ __forceinline__ bool attn_unset(const attn_u32x4& v) {
+  return v.x == ATTN_SENTINEL || v.y == ATTN_SENTINEL || v.z == ATTN_SENTINEL || v.w == ATTN_SENTINEL;
+}
+__device__ __forceinline__ float4 attn_f4(const attn_u32x4& v) {
+  const f32x4 f = __builtin_bit_cast(f32x4, v);
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+
+// grid (NS, B), 256 threads = 8 half-waves; half-wave hw owns rows t0 + hw + 8 i, i < RPH.  NS <= 64.
+template <int RPH>
+__global__ __launch_bounds__(256) void attn_step_fwd_split_kernel(AttnSplit p) {
+  constexpr int R = 8 * RPH;
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr unsigned MAX_TRIES = 1u << 18;
+  __shared__ __attribute__((aligned(16))) float sRed[8 * 512];
+  __shared__ __attribute__((aligned(16))) float sW[R];
+  __shared__ float sM[8], sS[8];
+  const int s = blockIdx.x, b = blockIdx.y, NS = p.NS;
+  const int tid = threadIdx.x, hw = tid >> 5, l32 = tid & 31;
+  const int T = p.T;
+  int len = p.lens ? p.lens[b] : T;
+  len = len < T ? len : T;
+  const int t0 = s * R;
+  const float* cb = p.comp + ((int64_t)b * T + t0) * 128 + 4 * l32;
+  const float* fb = p.feat + ((int64_t)b * T + t0) * 512 + 4 * l32;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (requesting rows up to T instead of waiting for the utterance's length first was tried: no gain --
+  // the workgroups' requests queue behind each other for ~3 us anyway -- and padded rows cost bandwidth)
+  float4 c[RPH], f[RPH][4];
+  const int lim = len;
+#pragma unroll
+  for (int i = 0; i < RPH; ++i) {
+    const int r = hw + 8 * i;
+    c[i] = t0 + r < lim ? aload4(cb + (int64_t)r * 128) : z4;
+  }
+#pragma unroll
+  for (int i = 0; i < RPH; ++i) {
+    const int r = hw + 8 * i;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f[i][k] = t0 + r < lim ? aload4(fb + (int64_t)r * 512 + 128 * k) : z4;
+  }
+  const float4 q4 = p.q ? aload4(p.q + (int64_t)b * 128 + 4 * l32) : z4;
+  ATTN_STAMP(0);
+
+  // the other buffer's record of this workgroup goes back to the fill pattern (nobody reads it in
+  // this call); fire and forget, behind the operand loads
+  const size_t buf_bytes = (size_t)p.B * NS * ATTN_PART * sizeof(float);
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+      p.part + ((int64_t)(p.phase & 1) * p.B + b) * NS * ATTN_PART, 0, (int)(NS * ATTN_PART * sizeof(float)), 0x00020000);
+  {
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        p.part + ((int64_t)((p.phase & 1) ^ 1) * p.B + b) * NS * ATTN_PART, 0, (int)(NS * ATTN_PART * sizeof(float)), 0x00020000);
+    const float4 fill = attn_f4(attn_u32x4{ATTN_SENTINEL, ATTN_SENTINEL, ATTN_SENTINEL, ATTN_SENTINEL});
+    if (tid < ATTN_PART / 4) attn_st_sc1(ro, (unsigned)((s * ATTN_PART + 4 * tid) * 4), fill);
+  }
+  (void)buf_bytes;
+
+  float e[RPH];
+#pragma unroll
+  for (int i = 0; i < RPH; ++i) {
+    float v = c[i].x * q4.x;
+    v = fmaf(c[i].y, q4.y, v);
+    v = fmaf(c[i].z, q4.z, v);
+    e[i] = fmaf(c[i].w, q4.w, v);
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+#pragma unroll
+    for (int i = 0; i < RPH; ++i) e[i] += __shfl_xor(e[i], o, 64);
+  }
+  if (l32 == 0) {         // raw energies of this workgroup's rows, for its alphas at the end
+#pragma unroll
+    for (int i = 0; i < RPH; ++i) sW[hw + 8 * i] = e[i];
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < RPH; ++i)
+    if (t0 + hw + 8 * i < len) m = fmaxf(m, e[i]);
+  if (l32 == 0) sM[hw] = m;
+  __syncthreads();
+  float gm = sM[0];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) gm = fmaxf(gm, sM[g]);
+  // weights relative to this workgroup's maximum, one exponential each
+  float ssum = 0.f;
+  float4 acc[4] = {z4, z4, z4, z4};
+#pragma unroll
+  for (int i = 0; i < RPH; ++i) {
+    const float w = (t0 + hw + 8 * i < len) ? __builtin_amdgcn_exp2f((e[i] - gm) * LOG2E) : 0.f;
+    ssum += w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[k].x = fmaf(w, f[i][k].x, acc[k].x);
+      acc[k].y = fmaf(w, f[i][k].y, acc[k].y);
+      acc[k].z = fmaf(w, f[i][k].z, acc[k].z);
+      acc[k].w = fmaf(w, f[i][k].w, acc[k].w);
+    }
+  }
+  if (l32 == 0) sS[hw] = ssum;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(sRed + hw * 512 + 128 * k + 4 * l32) = acc[k];
+  __syncthreads();
+  ATTN_STAMP(1);
+
+  // publish this workgroup's record, write-through
+  const unsigned rec = (unsigned)(s * ATTN_PART * 4);
+  if (tid < 128) {            // waves 0, 1: the 2 KB partial context
+    float4 v = *reinterpret_cast<const float4*>(sRed + 4 * tid);
+#pragma unroll
+    for (int g = 1; g < 8; ++g) {
+      const float4 a = *reinterpret_cast<const float4*>(sRed + g * 512 + 4 * tid);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    attn_st_sc1(rp, rec + 16 * tid, v);
+  } else if (tid < 136) {     // wave 2: the line of (m_s, S_s); a slice with no valid row says (0, 0), never -inf
+    float gs = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) gs += sS[g];
+    attn_st_sc1(rp, rec + 512 * 4 + 16 * (tid - 128), tid == 128 ? make_float4(gs > 0.f ? gm : 0.f, gs, 0.f, 0.f) : z4);
+  }
+  ATTN_STAMP(2);
+#if SSASR_ATTN_VARIANT == 6       // (timing experiment: streaming and publishing only)
+  return;
+#endif
+
+  // -------- gather: all pairs, and column quads s, s + NS, ... of every record's context --------
+  const int QW = (128 + NS - 1) / NS;         // quads this workgroup owns (the last may not exist)
+  const int L = NS * QW;                      // <= 128 + NS <= 192 pieces: thread x < L takes (record x / QW, quad x % QW)
+  const int gj = tid / QW, gi = tid - gj * QW;
+  const int quad = s + NS * gi;
+  const bool piece = tid < L && quad < 128;
+  const bool pair = tid >= 192 && tid - 192 < NS;
+  const unsigned goff = piece ? (unsigned)((gj * ATTN_PART + 4 * quad) * 4)
+                              : (unsigned)(((tid - 192) * ATTN_PART + 512) * 4);
+  const bool want = piece || pair;
+  attn_u32x4 raw = want ? attn_ld_raw(rp, goff) : attn_u32x4{0u, 0u, 0u, 0u};
+  for (unsigned tries = 0; __any(want && attn_unset(raw)); ++tries) {
+    if (tries > MAX_TRIES) break;
+    __builtin_amdgcn_s_sleep(2);
+    if (want && attn_unset(raw)) raw = attn_ld_raw(rp, goff);
+  }
+  ATTN_STAMP(3);
+  // Wave 3 holds the pairs, one per lane: M, S and every record's factor exp(m_j - M) / S by wave
+  // shuffles (a serial loop over the NS pairs in LDS cost 4 us here: latency-bound LDS reads and
+  // exponentials in every thread).
+  __shared__ float sF[64], sMI[2];
+  if (tid >= 192) {
+    const float4 ms = pair ? attn_f4(raw) : z4;
+    const bool live = pair && ms.y > 0.f;
+    const float M = wave_max(live ? ms.x : -INFINITY);
+    const float term = live ? ms.y * __builtin_amdgcn_exp2f((ms.x - M) * LOG2E) : 0.f;
+    const float S = wave_sum(term);                      // (butterfly: every lane gets the same bits)
+    const float inv = S > 0.f ? __builtin_amdgcn_rcpf(S) : 0.f;
+    sF[tid - 192] = live ? __builtin_amdgcn_exp2f((ms.x - M) * LOG2E) * inv : 0.f;
+    if (tid == 192) { sMI[0] = M; sMI[1] = inv; }
+  }
+  float* sX = sRed;                           // [NS][QW] float4 (sRed was last read before the publishing stores)
+  __syncthreads();
+  ATTN_STAMP(4);
+  if (piece) {                                // this thread's piece, scaled by its record's factor
+    const float fj = sF[gj];
+    const float4 a = attn_f4(raw);
+    *reinterpret_cast<float4*>(sX + 4 * tid) = make_float4(fj * a.x, fj * a.y, fj * a.z, fj * a.w);
+  }
+  if (tid >= 64 && tid < 64 + R) {            // the alphas of this workgroup's rows: one exponential each
+    const int t = t0 + tid - 64;
+    if (t < T) p.att[(int64_t)b * p.att_sb + t] = t < len ? __builtin_amdgcn_exp2f((sW[tid - 64] - sMI[0]) * LOG2E) * sMI[1] : 0.f;
+  }
+  __syncthreads();
+  if (tid < QW && s + NS * tid < 128) {       // this workgroup's quads of ctx, records summed in order
+    float4 v = z4;
+#pragma unroll 8
+    for (int j = 0; j < NS; ++j) {
+      const float4 a = *reinterpret_cast<const float4*>(sX + 4 * (j * QW + tid));
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    *reinterpret_cast<float4*>(p.ctx + (int64_t)b * p.ctx_ld + 4 * (s + NS * tid)) = v;
+  }
+  ATTN_STAMP(5);
+}
+
+// rows per half-wave for (B, T): the choice that leaves the least work on the busiest CU
+inline int attn_split_rph(int B, int T) {
+  int best = 4;
+  int64_t best_cost = -1;
+  for (int rph = 4; rph >= 2; --rph) {
+    const int R = 8 * rph;
+    const int64_t wgs = (int64_t)B * ((T + R - 1) / R);
+    const int64_t cost = ((wgs + 255) / 256) * R;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rph; }
+  }
+  return best;
+}
+inline int attn_split_ns(int B, int T) { const int R = 8 * attn_split_rph(B, T); return (T + R - 1) / R; }
+// the split form is taken for T > 128 at A = 128, E = 512 when the caller provides its workspace
+inline bool attn_split_ok(int64_t B, int64_t T, int64_t A, int64_t E) {
+  return A == 128 && E == 512 && T > 128 && T <= 1024 && B > 0 && B <= 1024;     // NS <= 64 (sPm / sPs)
+}
+inline int64_t attn_split_ws_floats(int64_t B, int64_t T) {
+  return 2 * B * attn_split_ns((int)B, (int)T) * (int64_t)ATTN_PART;
+}
+
 // General shapes.  grid (B, nch), 256 threads, dynamic LDS: A + T + 1024 + 16 floats
 __global__ __launch_bounds__(256) void attn_step_fwd_kernel(AttnFwd p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

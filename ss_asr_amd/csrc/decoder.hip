@@ -103,10 +103,34 @@ bool attn_dims_ok(int64_t B, int64_t T, int64_t A, int64_t E, int64_t D) {
          T <= 16384 && A <= 2048 && E <= 8192;
 }
 
-int launch_attn_fwd(const AttnFwd& p, hipStream_t st) {
+bool dec_grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t workgroups);
+
+// ws / phase: optional workspace of the split-T form (ssasr_attn_step_ws_floats) and which of its
+// two exchange buffers this call uses
+int launch_attn_fwd(const AttnFwd& p, hipStream_t st, float* ws = nullptr, int phase = 0) {
   const dim3 grid((unsigned)p.B, (unsigned)p.nch), block(256);
   const bool fast = p.A == 128 && p.E == 128 * p.nch && aligned16(p.comp) && aligned16(p.feat) &&
                     (!p.q || aligned16(p.q));
+  if (fast && ws && aligned16(ws) && aligned16(p.ctx) && p.ctx_ld % 4 == 0 && attn_split_ok(p.B, p.T, p.A, p.E)) {
+    AttnSplit sp{};
+    sp.q = p.q; sp.comp = p.comp; sp.feat = p.feat; sp.lens = p.lens;
+    sp.att = p.att; sp.att_sb = p.att_sb; sp.ctx = p.ctx; sp.ctx_ld = p.ctx_ld;
+    sp.part = ws;
+    sp.B = p.B; sp.T = p.T; sp.phase = phase & 1;
+    const int rph = attn_split_rph(p.B, p.T);
+    sp.NS = (p.T + 8 * rph - 1) / (8 * rph);
+    const dim3 sgrid((unsigned)sp.NS, (unsigned)p.B);
+    const void* fn = rph == 4 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<4>)
+                   : rph == 3 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<3>)
+                              : reinterpret_cast<const void*>(attn_step_fwd_split_kernel<2>);
+    // the workgroups of an utterance wait for each other: only when the whole grid is resident
+    if (dec_grid_fits(fn, 256, 0, (int64_t)sp.NS * p.B)) {
+      if (rph == 4) hipLaunchKernelGGL(attn_step_fwd_split_kernel<4>, sgrid, block, 0, st, sp);
+      else if (rph == 3) hipLaunchKernelGGL(attn_step_fwd_split_kernel<3>, sgrid, block, 0, st, sp);
+      else hipLaunchKernelGGL(attn_step_fwd_split_kernel<2>, sgrid, block, 0, st, sp);
+      return SSASR_OK;
+    }
+  }
   if (fast && p.T <= 128) hipLaunchKernelGGL(attn_step_fwd_fast_kernel<1>, grid, block, 0, st, p);
   else if (fast && p.T <= 256) hipLaunchKernelGGL(attn_step_fwd_fast_kernel<2>, grid, block, 0, st, p);
   else if (fast) hipLaunchKernelGGL(attn_step_fwd_long_kernel, grid, block, attn_fwd_long_lds(p.T), st, p);
@@ -131,10 +155,20 @@ int launch_attn_bwd(const AttnBwd& p, hipStream_t st) {
 
 }  // namespace
 
+#if SSASR_ATTN_VARIANT == 7
+extern "C" int ssasr_debug_attn_trace(void* host_out, int64_t words) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_trace), words * 8);
+}
+#endif
+
+extern "C" int64_t ssasr_attn_step_ws_floats(int64_t B, int64_t T, int64_t A, int64_t E) {
+  return attn_split_ok(B, T, A, E) ? attn_split_ws_floats(B, T) : 0;
+}
+
 extern "C" int ssasr_attn_step_fwd(const float* state, const float* w_phi, const float* comp,
                                    const float* feat, const int32_t* enc_len, int64_t B, int64_t T,
                                    int64_t A, int64_t E, int64_t D, float* q, float* att,
-                                   float* ctx, void* stream) {
+                                   float* ctx, float* ws, int ws_phase, void* stream) {
   if (!w_phi || !comp || !feat || !q || !att || !ctx || !attn_dims_ok(B, T, A, E, D)) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   if (state) launch_phi(state, w_phi, q, B, A, D, st);   // state == NULL: q is an input
@@ -142,7 +176,7 @@ extern "C" int ssasr_attn_step_fwd(const float* state, const float* w_phi, const
   p.q = q; p.comp = comp; p.feat = feat; p.lens = enc_len;
   p.att = att; p.att_sb = T; p.ctx = ctx; p.ctx_ld = E;
   p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.nch = attn_pick_nch((int)E);
-  launch_attn_fwd(p, st);
+  launch_attn_fwd(p, st, ws, ws_phase);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
@@ -162,12 +196,14 @@ extern "C" int ssasr_attn_step_bwd(const float* dctx, const float* datt, const f
 }
 
 // ------------------------------ decode loop --------------------------------
+namespace {
 // every workgroup of a persistent grid must be resident at once (see rnn.hip, grid_fits)
-static bool dec_grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t workgroups) {
+bool dec_grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t workgroups) {
   if (ssasr_options().no_residency_check) return true;
   const int64_t cap = ssasr_resident_capacity(kernel, threads, dyn_lds);
   return cap <= 0 || workgroups <= cap;
 }
+}  // namespace
 
 extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   if (!dp) return SSASR_EARG;
@@ -265,7 +301,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     p.att = d.att + t * T; p.att_sb = U * T;
     p.ctx = d.ctx + t * B * E; p.ctx_ld = E;
     p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.nch = nch;
-    launch_attn_fwd(p, st);
+    launch_attn_fwd(p, st, d.ws_attn, (int)((d.ws_attn_phase + t) & 1));
 
     CellFwdPair c1{};
     {

@@ -421,8 +421,9 @@ class _AttnStep(torch.autograd.Function):
         q = torch.empty(B, A, device=feat.device)
         att = torch.empty(B, T, device=feat.device)
         cx = torch.empty(B, E, device=feat.device)
+        ws, phase = attn_workspace(B, T, A, E, feat.device)
         check(lib.ssasr_attn_step_fwd(_p(state), _p(w_phi), _p(comp), _p(feat), _p(enc_len), B, T,
-                                      A, E, D, _p(q), _p(att), _p(cx), _stream()),
+                                      A, E, D, _p(q), _p(att), _p(cx), _p(ws), phase, _stream()),
               'ssasr_attn_step_fwd')
         ctx.save_for_backward(state, w_phi, comp, feat, enc_len, q, att)
         return att, cx
@@ -446,6 +447,31 @@ class _AttnStep(torch.autograd.Function):
         dcomp = gemm(de.unsqueeze(1), q.unsqueeze(1), ta=True, tb=True)        # [B,T,A]
         dfeat = gemm(att.unsqueeze(1), dctx.unsqueeze(1), ta=True, tb=True)    # [B,T,E]
         return dstate, dw_phi, dcomp, dfeat, None
+
+
+_attn_ws = {}
+
+
+def attn_workspace(B, T, A, E, device, calls=1):
+    """(workspace, phase of the next call) of the split-T attention kernel for a shape, or
+    (None, 0) when the shape has no use for one.  The workspace is two exchange buffers armed with
+    the fill pattern once and then reused by every call of that shape: a call exchanges through
+    buffer `phase` and re-arms the other (include/ssasr.h), so consecutive calls alternate.  The
+    phase is tracked here: `calls` is how many consecutive calls (phase, phase + 1, ...) the
+    caller is about to make (a decode loop's per-step launches: U).  Calls that share a workspace
+    must be ordered on one stream."""
+    n = int(_lib.load().ssasr_attn_step_ws_floats(B, T, A, E))
+    if n == 0:
+        return None, 0
+    key = (str(device), B, T, A, E)
+    ent = _attn_ws.get(key)
+    if ent is None:
+        ws = torch.empty(n, device=device, dtype=torch.float32)
+        ws.view(torch.int32).fill_(_SENTINEL_I32)
+        ent = _attn_ws[key] = [ws, 0]
+    phase = ent[1]
+    ent[1] = (ent[1] + calls) & 1
+    return ent[0], phase
 
 
 def attn_step(state, w_phi, comp, feat, enc_len):
@@ -559,6 +585,9 @@ class _DecoderLoop(torch.autograd.Function):
             _track_status(bufs['ws_sync'], 5)
         if 'ctx' not in bufs:
             bufs['ctx'] = f(U, B, E)
+            ws_attn, attn_phase = attn_workspace(B, T, A, E, dev, calls=U)     # per-step loop, long encoder outputs
+            if ws_attn is not None:
+                bufs['ws_attn'] = ws_attn
         modes = (C.c_int32 * U)(*[int(m) for m in step_mode])
         d = _lib.Decoder()
         d.B, d.T, d.E, d.A, d.D, d.V, d.U = B, T, E, A, D, V, U
@@ -575,6 +604,7 @@ class _DecoderLoop(torch.autograd.Function):
         for k, t in bufs.items():
             setattr(d, k, t.data_ptr())
         d.ws_armed = 1 if ('ws_hx1' in bufs and ctx_armed) else 0
+        d.ws_attn_phase = attn_phase if 'ws_attn' in bufs else 0
         check(lib.ssasr_decoder_fwd(C.byref(d), _stream()), 'ssasr_decoder_fwd')
         ctx.dec = d
         ctx.slots = slots
