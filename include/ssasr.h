@@ -47,7 +47,8 @@ int ssasr_abi_version(void);
  * calls.  Names: SSASR_NO_PERSISTENT, SSASR_PERSISTENT_COUNTER, SSASR_NO_FUSED_INPUT,
  * SSASR_FWD_NB, SSASR_BPTT_GATHER, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
  * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
- * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_NO_RESIDENCY_CHECK.  Unknown name: -1. */
+ * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_NO_RESIDENCY_CHECK, SSASR_BPTT_LOCAL,
+ * SSASR_XCD_ROUND_ROBIN (the probe's verdict, settable for tests).  Unknown name: -1. */
 int ssasr_set_option(const char* name, int value);
 int ssasr_get_option(const char* name, int* value);
 
@@ -55,6 +56,15 @@ int ssasr_get_option(const char* name, int* value);
  * behind the first.  One set serves all calls of its owner (one thread at a time). */
 int ssasr_events_create(void** handle);
 int ssasr_events_destroy(void* handle);
+
+/* Placement probe.  The K-split BPTT can keep each of its exchange groups on ONE XCD and hand data
+ * over through that XCD's L2 instead of the fabric (and `beside` GEMMs then keep to the other XCDs).
+ * That rests on an observed property of the dispatcher -- in a 1-D launch blocks b and b + 8 share
+ * an XCD, the classes b & 7 sit on eight different XCDs -- which this call verifies on the current
+ * device, once (synchronous; the one place where the library allocates: 8 KB of scratch, freed
+ * before it returns).  1 = holds (XCD-local placement is used unless SSASR_BPTT_LOCAL=0), 0 = does
+ * not (spread placement), negative = HIP error.  Until it has been called the spread placement is used. */
+int ssasr_probe_placement(void* stream);
 
 /* C[b] = act(alpha * op(A[b]) . op(B[b]) + bias) + beta * C[b], fp32 MFMA.
  * ta = 0: A is [M][K] (ld = lda); ta = 1: A is [K][M].
@@ -170,7 +180,7 @@ int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const float* feat
  * ssasr_attn_precompute_bwd left in dcomp: dW_psi (+)= dpre^T feat, db_psi (+)= column sums.
  * accumulate = 1 adds into the outputs (optimizer-owned gradient buffers, any stream). */
 int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat, int64_t rows, int64_t E, int64_t A,
-                                float* dw_psi, float* db_psi, int accumulate, void* stream);
+                                float* dw_psi, float* db_psi, int accumulate, int beside, void* stream);
 
 /* One Attention.forward call after the cache exists (src/asr.py:383-390).
  * state [B][D], w_phi [A][D] (phi.weight), comp [B][T][A], feat [B][T][E],
@@ -292,7 +302,8 @@ int ssasr_decoder_bwd(const ssasr_decoder* d, const ssasr_decoder_grads* g, void
 /* Parameter gradients of the decode loop from what ssasr_decoder_bwd(defer_wgrad = 1)
  * left in d / g (gate derivatives, dqpre, dlogits): 11 products over all steps, off the
  * critical path of the backward pass.  accumulate = 0 overwrites the outputs, 1 adds. */
-int ssasr_decoder_wgrad(const ssasr_decoder* d, const ssasr_decoder_grads* g, int accumulate, void* stream);
+int ssasr_decoder_wgrad(const ssasr_decoder* d, const ssasr_decoder_grads* g, int accumulate, int beside,
+                        void* stream);
 
 /* Masked cross entropy of src/trainer.py:426-434 on the label matrix itself.
  * logits [B][U][V]; y int32 [B][y_cols] with row stride y_ld (0 = padding):

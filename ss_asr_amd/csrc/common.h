@@ -81,7 +81,14 @@ struct GemmDesc {
   int splitk;          // >1: partial products are atomically added into C
   int batch;
   int64_t sa, sb, sc, sbias;
+  // cls_n != 0: run on the XCDs of launch classes cls_lo .. cls_lo + cls_n - 1 only (1-D launch in
+  // which the other classes exit at once; ssasr_launch_gemm sets gx / gy / gz): work that runs on a
+  // second stream beside an XCD-local persistent recurrence keeps to the XCDs that one leaves free
+  int cls_lo, cls_n, gx, gy, gz;
 };
+// Side-stream work beside a persistent recurrence: restricts `g` to the free XCD classes when the
+// recurrences are placed XCD-locally (options), else leaves it unrestricted.
+void ssasr_gemm_beside_recurrence(GemmDesc& g);
 int ssasr_launch_gemm(const GemmDesc& g, hipStream_t st);
 int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);
 // Persistent BPTT of `dirs` LSTM directions over S steps x N <= 32 columns (rnn.hip):
@@ -112,7 +119,11 @@ struct SsasrOptions {
   int delay_fwd, delay_bwd, delay_bwd_ksplit;   // SSASR_PERSIST_DELAY_FWD / _BWD (initial pacing, x 64 cycles; -1 = default)
   int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
   int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches
+  int bptt_local;                 // SSASR_BPTT_LOCAL (0): XCD-local placement of the K-split BPTT when the probe allows it
+  int xcd_round_robin;            // verdict of ssasr_probe_placement(): -1 not probed, 0 no, 1 yes (not an environment switch)
 };
+// true when persistent recurrences may be placed XCD-locally (option on and the probe said yes)
+bool ssasr_local_placement();
 const SsasrOptions& ssasr_options();
 // Upper bound of co-resident workgroups of `kernel` (block threads, dynamic LDS bytes) on the current
 // device: occupancy per CU x CU count, cached per (kernel, LDS).  A persistent grid larger than this

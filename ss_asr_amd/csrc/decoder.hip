@@ -62,7 +62,7 @@ extern "C" int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const 
     g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.batch = 1;
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
-  if (dw_psi || db_psi) return ssasr_attn_precompute_wgrad(dcomp, feat, rows, E, A, dw_psi, db_psi, 0, stream);
+  if (dw_psi || db_psi) return ssasr_attn_precompute_wgrad(dcomp, feat, rows, E, A, dw_psi, db_psi, 0, 0, stream);
   return SSASR_OK;
 }
 
@@ -71,7 +71,7 @@ extern "C" int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const 
 // into optimizer-owned gradient buffers.
 extern "C" int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat, int64_t rows, int64_t E,
                                            int64_t A, float* dw_psi, float* db_psi, int accumulate,
-                                           void* stream) {
+                                           int beside, void* stream) {
   if (!dcomp || !feat || rows <= 0 || E <= 0 || A <= 0) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -87,6 +87,7 @@ extern "C" int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat
       int sk = (int)(rows / 128);
       g.splitk = sk < 1 ? 1 : (sk > 16 ? 16 : sk);
     }
+    if (beside) ssasr_gemm_beside_recurrence(g);
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   if (db_psi) {
@@ -360,7 +361,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
 namespace {
 
 int gemm_tn_acc(const float* A, RowMap ma, const float* B, RowMap mb, float* C, int64_t ldc, int64_t M,
-                int64_t N, int64_t K, hipStream_t st) {
+                int64_t N, int64_t K, hipStream_t st, bool beside = false) {
   // C[M][N] += A^T . B with A stored [K][M], B stored [K][N]; C pre-zeroed.
   if (K <= 0) return SSASR_OK;
   GemmDesc g{};
@@ -371,6 +372,7 @@ int gemm_tn_acc(const float* A, RowMap ma, const float* B, RowMap mb, float* C, 
   int sk = (int)(256 / tiles); if (sk < 1) sk = 1; if (sk > 16) sk = 16;
   if (K < 128 * sk) sk = K >= 256 ? 2 : 1;
   g.splitk = sk < 2 ? 2 : sk;      // always the accumulate form
+  if (beside) ssasr_gemm_beside_recurrence(g);
   return ssasr_launch_gemm(g, st);
 }
 
@@ -576,11 +578,12 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
   if (g.defer_wgrad) return SSASR_OK;
-  return ssasr_decoder_wgrad(dp, gp, 0, stream);
+  return ssasr_decoder_wgrad(dp, gp, 0, 0, stream);
 }
 
 extern "C" int ssasr_decoder_wgrad(const ssasr_decoder* dp, const ssasr_decoder_grads* gp, int accumulate,
-                                   void* stream) {
+                                   int beside_in, void* stream) {
+  const bool beside = beside_in != 0;
   if (!dp || !gp) return SSASR_EARG;
   const ssasr_decoder& d = *dp;
   const ssasr_decoder_grads& g = *gp;
@@ -595,26 +598,26 @@ extern "C" int ssasr_decoder_wgrad(const ssasr_decoder* dp, const ssasr_decoder_
 #define SSASR_ZERO(ptr, n) do { if (!accumulate) SSASR_HIP(hipMemsetAsync((ptr), 0, sizeof(float) * (n), st)); } while (0)
   // char_trans: dW_ct = dlogits^T . h2 ; db_ct = colsum
   SSASR_ZERO(g.dw_ct, V * D);
-  if ((rc = gemm_tn_acc(g.dlogits, logit_rows, d.h2, rm_dense(D), g.dw_ct, D, V, D, rows, st))) return rc;
+  if ((rc = gemm_tn_acc(g.dlogits, logit_rows, d.h2, rm_dense(D), g.dw_ct, D, V, D, rows, st, beside))) return rc;
   SSASR_ZERO(g.db_ct, V);
   if ((rc = ssasr_launch_colsum(g.dlogits, B * U, (int)V, V, g.db_ct, st))) return rc;
   // dW_phi = sum_{t>=1} dqpre[t]^T . h1[t-1]
   SSASR_ZERO(g.dw_phi, A * D);
-  if ((rc = gemm_tn_acc(g.ws_dqpre + B * A, rm_dense(A), d.h1, rm_dense(D), g.dw_phi, D, A, D, (U - 1) * B, st))) return rc;
+  if ((rc = gemm_tn_acc(g.ws_dqpre + B * A, rm_dense(A), d.h1, rm_dense(D), g.dw_phi, D, A, D, (U - 1) * B, st, beside))) return rc;
   // cell 1: dW_ih1 = dG1^T . [emb_in | ctx], dW_hh1 = dG1[1:]^T . h1[:-1], db1
   SSASR_ZERO(g.dw_ih1, 4 * D * (D + E));
-  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.emb_in, rm_dense(D), g.dw_ih1, D + E, 4 * D, D, rows, st))) return rc;
-  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.ctx, rm_dense(E), g.dw_ih1 + D, D + E, 4 * D, E, rows, st))) return rc;
+  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.emb_in, rm_dense(D), g.dw_ih1, D + E, 4 * D, D, rows, st, beside))) return rc;
+  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.ctx, rm_dense(E), g.dw_ih1 + D, D + E, 4 * D, E, rows, st, beside))) return rc;
   SSASR_ZERO(g.dw_hh1, 4 * D * D);
-  if ((rc = gemm_tn_acc(d.gates1 + B * 4 * D, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_hh1, D, 4 * D, D, (U - 1) * B, st))) return rc;
+  if ((rc = gemm_tn_acc(d.gates1 + B * 4 * D, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_hh1, D, 4 * D, D, (U - 1) * B, st, beside))) return rc;
   SSASR_ZERO(g.db1, 4 * D);
   if (g.db1_2) SSASR_ZERO(g.db1_2, 4 * D);
   if ((rc = ssasr_launch_colsum(d.gates1, rows, (int)(4 * D), 4 * D, g.db1, st, g.db1_2))) return rc;
   // cell 2
   SSASR_ZERO(g.dw_ih2, 4 * D * D);
-  if ((rc = gemm_tn_acc(d.gates2, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_ih2, D, 4 * D, D, rows, st))) return rc;
+  if ((rc = gemm_tn_acc(d.gates2, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_ih2, D, 4 * D, D, rows, st, beside))) return rc;
   SSASR_ZERO(g.dw_hh2, 4 * D * D);
-  if ((rc = gemm_tn_acc(d.gates2 + B * 4 * D, rm_dense(4 * D), d.h2, rm_dense(D), g.dw_hh2, D, 4 * D, D, (U - 1) * B, st))) return rc;
+  if ((rc = gemm_tn_acc(d.gates2 + B * 4 * D, rm_dense(4 * D), d.h2, rm_dense(D), g.dw_hh2, D, 4 * D, D, (U - 1) * B, st, beside))) return rc;
   SSASR_ZERO(g.db2, 4 * D);
   if (g.db2_2) SSASR_ZERO(g.db2_2, 4 * D);
   if ((rc = ssasr_launch_colsum(d.gates2, rows, (int)(4 * D), 4 * D, g.db2, st, g.db2_2))) return rc;
@@ -626,6 +629,7 @@ extern "C" int ssasr_decoder_wgrad(const ssasr_decoder* dp, const ssasr_decoder_
     m.C = g.ws_demb; m.mc = rm_dense(D);
     m.M = (int)rows; m.N = (int)D; m.K = (int)(4 * D); m.ta = 0; m.tb = 1;
     m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
+    if (beside) ssasr_gemm_beside_recurrence(m);
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
   SSASR_ZERO(g.dembed, V * D);

@@ -68,7 +68,7 @@ struct PdWaiter {
     if (threadIdx.x == 0 && !broken) {
       unsigned spins = 0;
       while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins > PERSIST_MAX_SPINS) { *status = 1; broken = true; break; }
+        if (persist_give_up(++spins, status)) { broken = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -96,7 +96,7 @@ __device__ __forceinline__ void pd_fetch(float4 (&b)[NV], F ld, int lo, int hi, 
         }
       }
       if (!anybad) break;
-      if (tries > PERSIST_MAX_SPINS) { if ((threadIdx.x & 63) == 0) *status = 1; break; }
+      if (persist_give_up(tries, status)) break;
       __builtin_amdgcn_s_sleep(2);
     }
   }

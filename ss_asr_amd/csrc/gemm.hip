@@ -181,7 +181,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
   // contiguous run of tiles (N fastest, then M, then the split-K / batch
   // slice): its A row-blocks are then fetched by that XCD only.
   int bx = blockIdx.x, by = blockIdx.y, bzz = blockIdx.z;
-  {
+  if (g.cls_n) {
+    // restricted to the XCDs of launch classes cls_lo .. cls_lo + cls_n - 1 (1-D launch of
+    // 8 * ceil(tiles / cls_n) workgroups; see GemmDesc): the other classes exit at once
+    const int nx = g.gx, ny = g.gy;
+    const int total = nx * ny * g.gz;
+    const int c = (bx & 7) - g.cls_lo, j = bx >> 3;
+    if (c < 0 || c >= g.cls_n) return;
+    const int per = total / g.cls_n, rem = total % g.cls_n;
+    if (j >= per + (c < rem ? 1 : 0)) return;
+    const int t = c * per + min(c, rem) + j;
+    bx = t % nx;
+    const int u = t / nx;
+    by = u % ny;
+    bzz = u / ny;
+  } else {
     const int nx = gridDim.x, ny = gridDim.y;
     const int total = nx * ny * gridDim.z;
     const int lin = bx + nx * (by + ny * bzz);
@@ -373,9 +387,16 @@ bool map_vec_ok(const RowMap& m) {
 }
 
 template <int BM, int BN>
-int launch_tiles(const GemmDesc& g, bool vecA, bool vecB, hipStream_t st) {
+int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
+  GemmDesc g = gin;
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * g.splitk);
   dim3 block(256);
+  if (g.cls_n) {
+    if (g.cls_lo < 0 || g.cls_n < 1 || g.cls_lo + g.cls_n > 8) return SSASR_EARG;
+    g.gx = (int)grid.x; g.gy = (int)grid.y; g.gz = (int)grid.z;
+    const int64_t total = (int64_t)grid.x * grid.y * grid.z;
+    grid = dim3((unsigned)(8 * ((total + g.cls_n - 1) / g.cls_n)));
+  }
   // split-K launches add their partial products atomically: one float per lane in rows of 16
   // consecutive columns (TR = false); everything else stores 16 bytes per lane (TR = true)
 #define SSASR_GEMM_LAUNCH(A_, B_)                                                                           \
@@ -409,16 +430,19 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
     if (forced == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
     if (forced == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
   }
-  if (big < 256) return launch_tiles<64, 64>(g, vecA, vecB, st);
+  const int64_t cus = g.cls_n ? 32 * g.cls_n : 256;          // CUs this launch may use
+  // (a class-restricted launch keeps to 64 x 64 tiles: its workgroups of the idle classes must fit
+  // beside a recurrence workgroup to start and exit -- see ssasr_launch_bptt_persistent)
+  if (big < cus || g.cls_n) return launch_tiles<64, 64>(g, vecA, vecB, st);
   // Both tile shapes run at 85-110 TF once the chip is full; what differs is how the LAST round of
   // workgroups fills it.  Measured at K = 1024 (tools/gemm_tiles.py), in units of 150 us: 128 x 128
   // tiles, two per CU -- a CU's pair of tiles costs 1.0, a single one 0.9 (0.63 when every CU has at
   // most one); 64 x 64 tiles, fine grained -- 0.133 + 0.00052 per tile.  Take the cheaper.
   if (g.splitk == 1) {
-    const int64_t n = (big + 255) / 256;
+    const int64_t n = (big + cus - 1) / cus;
     const double t128 = n == 1 ? 0.63 : 1.0 * (double)(n / 2) + 0.9 * (double)(n % 2);
     const int64_t small = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch;
-    const double t64 = 0.133 + 0.00052 * (double)small;
+    const double t64 = 0.133 + 0.00052 * (double)small * (256.0 / (double)cus);
     if (t64 < t128) return launch_tiles<64, 64>(g, vecA, vecB, st);
   }
   return launch_tiles<128, 128>(g, vecA, vecB, st);

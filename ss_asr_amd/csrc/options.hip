@@ -32,6 +32,8 @@ void init_options() {
   g_opt.delay_bwd_ksplit = g_opt.delay_bwd;
   g_opt.gemm_tile = env_int("SSASR_GEMM_TILE", 0);
   g_opt.no_residency_check = env_flag("SSASR_NO_RESIDENCY_CHECK");
+  g_opt.bptt_local = env_int("SSASR_BPTT_LOCAL", 0);     // measured slower inside the train step: rnn.hip
+  g_opt.xcd_round_robin = -1;
 }
 
 struct Named { const char* name; int SsasrOptions::*field; };
@@ -49,7 +51,16 @@ const Named kNames[] = {
     {"SSASR_PERSIST_DELAY_BWD", &SsasrOptions::delay_bwd},
     {"SSASR_GEMM_TILE", &SsasrOptions::gemm_tile},
     {"SSASR_NO_RESIDENCY_CHECK", &SsasrOptions::no_residency_check},
+    {"SSASR_BPTT_LOCAL", &SsasrOptions::bptt_local},
+    {"SSASR_XCD_ROUND_ROBIN", &SsasrOptions::xcd_round_robin},
 };
+
+// One workgroup per block records the XCD it runs on (XCC_ID, 0..7).
+__global__ void xcc_probe_kernel(int32_t* out) {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(v & 0xf);
+}
 
 }  // namespace
 
@@ -76,6 +87,46 @@ extern "C" int ssasr_get_option(const char* name, int* value) {
   for (const Named& n : kNames)
     if (strcmp(n.name, name) == 0) { *value = g_opt.*(n.field); return SSASR_OK; }
   return SSASR_EARG;
+}
+
+bool ssasr_local_placement() {
+  const SsasrOptions& o = ssasr_options();
+  return o.bptt_local != 0 && o.xcd_round_robin == 1;
+}
+
+void ssasr_gemm_beside_recurrence(GemmDesc& g) {
+  if (ssasr_local_placement()) { g.cls_lo = 4; g.cls_n = 4; }
+}
+
+// XCD-local placement rests on an OBSERVED property of the dispatcher (MI355X_MICROARCH.md): in a
+// 1-D launch, blocks b and b + 8 run on the same XCD and the eight classes b & 7 on eight different
+// XCDs.  The probe checks exactly that on this device, once (a synchronous 2048-workgroup launch on
+// `stream`, a 8 KB scratch allocation of its own: the one place where the library allocates), and
+// keeps the verdict; the K-split BPTT then takes the XCD-local form only if it said yes.  Returns 1
+// (property holds), 0 (it does not; the spread placement stays), or a negative / HIP error code.
+extern "C" int ssasr_probe_placement(void* stream) {
+  std::call_once(g_opt_once, init_options);
+  if (g_opt.xcd_round_robin >= 0) return g_opt.xcd_round_robin;
+  constexpr int NB = 2048;
+  int32_t* dev = nullptr;
+  hipError_t e = hipMalloc(&dev, NB * sizeof(int32_t));
+  if (e != hipSuccess) return -(int)e;
+  int32_t host[NB];
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = true;
+  for (int rep = 0; rep < 3 && ok; ++rep) {
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(NB), dim3(64), 0, st, dev);
+    e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(dev); return -(int)e; }
+    unsigned seen = 0;
+    for (int c = 0; c < 8; ++c) seen |= 1u << host[c];
+    ok = seen == 0xffu;                                   // eight classes, eight XCDs
+    for (int b = 8; b < NB && ok; ++b) ok = host[b] == host[b & 7];
+  }
+  (void)hipFree(dev);
+  g_opt.xcd_round_robin = ok ? 1 : 0;
+  return g_opt.xcd_round_robin;
 }
 
 int64_t ssasr_resident_capacity(const void* kernel, int threads, size_t dyn_lds) {

@@ -183,7 +183,7 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
                                   const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
                                   float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
                                   float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
-                                  int accumulate, void* stream);
+                                  int accumulate, int beside, void* stream);
 
 // Exchange workspace of the persistent BPTT: the larger of the gather form's
 // per-step image and the K-split form's ring (0: no persistent form for this shape).
@@ -259,6 +259,29 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     if (!halves && !grid_fits(bptt_rs_fn(kpw, false), 320, (size_t)reserve, (H / 16) * dirs * chunks)) return SSASR_EARG;
     if (i0 == 0 && !armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
     if (halves) pgrid.z *= 2;
+    // XCD-local placement (rnn_kernels.h, persist_role; OFF by default, SSASR_BPTT_LOCAL=1): the <= 4
+    // exchange groups (direction, column chunk) of a layer on XCDs 0..3, one group per XCD, hand-offs
+    // through that XCD's L2; side-stream GEMMs then keep to XCDs 4..7 (ssasr_gemm_beside_recurrence).
+    // Needs the whole group on one XCD: (H / 16) * halves <= 32 workgroups, one per CU.
+    // Measured (tools/persistbench LOCAL=1, S = 400, N = 32): alone the kernel runs 2.52 -> 2.08 us per
+    // step (operand loads 0.72 -> 0.56, store -> release 0.40 -> 0.08); INSIDE the train step it loses,
+    // 6.7 -> 7.75 ms: a class-restricted GEMM still deals half of its workgroups to XCDs 0..3, where
+    // each has to be placed beside a recurrence workgroup just to exit (BPTT launches 220 -> 287 us,
+    // weight-gradient GEMMs 50 -> 81 us on their four XCDs); unrestricted GEMMs queue behind the
+    // recurrence instead (9.0 ms).  Kept as a measured alternative, covered by
+    // tests/test_gpu_model.py::test_backward_matches_reference_in_both_bptt_placements.
+    const int hv = halves ? 2 : 1;
+    int reserve_now = reserve;
+    if (ssasr_local_placement() && dirs * chunks <= 4 && (H / 16) * hv <= 32) {
+      p.local = dirs; p.nchunk = (int)chunks;
+      pgrid = dim3((unsigned)(8 * (H / 16) * hv), 1, 1);
+      // A `beside` GEMM is a 1-D launch of which the classes 0..3 exit at once -- but even those
+      // workgroups must first be PLACED on a CU of XCDs 0..3, all of which this launch occupies:
+      // with 118 KB reserved they (36 KB of static LDS) queue until the recurrence ends, and the
+      // whole GEMM behind them (measured: 6.8 -> 9.0 ms per train step).  40 KB stay free: room for
+      // one 64 x 64-tile workgroup to start and exit, never for a second recurrence workgroup.
+      if (reserve_now > 40 * 1024) reserve_now -= 40 * 1024;
+    }
     // (a range shorter than the hand-off distance between the two halves could rewrite dc_state early)
     if (halves && ranged && i1 < S && i1 - i0 < 4) return SSASR_EARG;
     // Placement: the weight-gradient GEMMs of the previous range / layer run beside this kernel on
@@ -270,11 +293,11 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // (the attribute is a property of the loaded code object: setting it again is idempotent and costs
     // no device work)
     if (reserve) SSASR_HIP(hipFuncSetAttribute(bptt_rs_fn(kpw, halves), hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
-    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, reserve, st, p);
-    else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, reserve, st, p);
-    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, reserve, st, p);
-    else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, reserve, st, p);
-    else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, reserve, st, p);
+    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, reserve_now, st, p);
+    else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, reserve_now, st, p);
+    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, reserve_now, st, p);
+    else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, reserve_now, st, p);
+    else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, reserve_now, st, p);
   } else if (!opt.persistent_counter) {
     SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(dirs * S * 4 * H * Np), st));
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
@@ -361,7 +384,7 @@ static int bilstm_bwd_impl(bool armed, const float* dy, int64_t ys_s, int64_t ys
   }
   if (!dw_ih_f) return SSASR_OK;      // weight gradients deferred to ssasr_bilstm_wgrad
   return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, nullptr, dw_ih_r,
-                            dw_hh_r, db_r, nullptr, 0, stream);
+                            dw_hh_r, db_r, nullptr, 0, 0, stream);
 }
 
 extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
@@ -415,7 +438,7 @@ extern "C" int ssasr_events_destroy(void* handle) {
 // outputs (which the caller zeroed if needed).
 static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgates, const float* x, int64_t xs_s,
                            int64_t xs_n, const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
-                           float* dwih, float* dwhh, float* db, float* db2, hipStream_t st) {
+                           float* dwih, float* dwhh, float* db, float* db2, hipStream_t st, bool beside) {
   const int64_t rows = S * N;
   const float* dG = dgates + d * rows * 4 * H;
   int rc;
@@ -431,6 +454,7 @@ static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgate
     int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
     if (g.K < 64 * sk) sk = 1;
     g.splitk = sk;
+    if (beside) ssasr_gemm_beside_recurrence(g);
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   {           // dW_hh += sum_s dG[s]^T . h[s_prev],  s_prev = s - 1 (forward direction) or s + 1 (reverse)
@@ -447,6 +471,7 @@ static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgate
       int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
       if (g.K < 64 * sk) sk = 1;
       g.splitk = sk;
+      if (beside) ssasr_gemm_beside_recurrence(g);
       if ((rc = ssasr_launch_gemm(g, st))) return rc;
     }
   }
@@ -457,7 +482,7 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
                                   const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
                                   float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
                                   float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
-                                  int accumulate, void* stream) {
+                                  int accumulate, int beside, void* stream) {
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dgates || !x || !hs) return SSASR_EARG;
   if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
@@ -472,7 +497,8 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
       SSASR_HIP(hipMemsetAsync(db[d], 0, sizeof(float) * 4 * H, st));
       if (db2[d]) SSASR_HIP(hipMemsetAsync(db2[d], 0, sizeof(float) * 4 * H, st));
     }
-    const int rc = wgrad_dir_range(d, 0, S, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[d], dwhh[d], db[d], db2[d], st);
+    const int rc = wgrad_dir_range(d, 0, S, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[d], dwhh[d], db[d], db2[d], st,
+                                   beside != 0);
     if (rc) return rc;
   }
   return SSASR_OK;
@@ -566,7 +592,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     SSASR_HIP(hipEventRecord(ev, st));
     SSASR_HIP(hipStreamWaitEvent(side, ev, 0));
     return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, db2_f, dw_ih_r, dw_hh_r,
-                              db_r, db2_r, 1, side_stream);
+                              db_r, db2_r, 1, 1, side_stream);
   }
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
   const float* wih[2] = {w_ih_f, w_ih_r};
@@ -600,9 +626,10 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     SSASR_HIP(hipStreamWaitEvent(side, done[k], 0));
     // iterations [i0, i1) cover steps S - i1 .. S - i0 - 1 of the forward direction and i0 .. i1 - 1 of the reverse
     if ((rc = wgrad_dir_range(0, S - i1, S - i0, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[0], dwhh[0], db[0], db2[0],
-                              side)))
+                              side, true)))
       return rc;
-    if ((rc = wgrad_dir_range(1, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], side)))
+    if ((rc = wgrad_dir_range(1, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], side,
+                              true)))
       return rc;
   }
   return SSASR_OK;

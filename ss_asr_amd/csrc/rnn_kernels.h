@@ -373,9 +373,50 @@ struct EncPersist {
   const float* wih[2];   // [4H][I] per direction
   const float* bih[2];
   const float* bhh[2];
+  // XCD-local placement (see persist_role): != 0 = the number of directions; the launch is 1-D,
+  // 8 * (H / 4) workgroups, and `nchunk` column chunks x directions <= 8 exchange groups are dealt one to an XCD
+  int local, nchunk;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Which part of a persistent recurrence a workgroup runs.
+// Spread placement (local == 0): grid (tiles, directions, chunks [* halves]); the workgroups of an
+// exchange group (one direction, one column chunk) land on all 8 XCDs, so their hand-offs go
+// through the fabric: write-through (sc1) stores, sc1 loads, ~1.3 us store -> visible -> load.
+// XCD-local placement (local != 0): workgroups are dealt to the XCDs round-robin in launch order
+// (MI355X_MICROARCH.md: blocks b and b + 8 share an XCD), so in a 1-D launch the blocks with equal
+// (index & 7) sit on ONE XCD.  Class c < groups becomes exchange group c (workgroup index >> 3
+// inside it), classes >= groups exit at once.  Within an XCD the L2 is coherent: the group's
+// hand-offs are PLAIN stores (the line stays in that L2) read by sc1 loads (L1 bypassed, L2 hit).
+// Placement is still only a speed matter for CORRECT DATA -- a load can never return anything but
+// the fill pattern or the value stored -- but a group that straddled XCDs would wait for ever on
+// lines that never leave the other L2: the launchers take this form only behind the probe of
+// ssasr_xcd_round_robin() and every wait is bounded (persist_give_up).
+struct PersistRole {
+  int tile, d, chunk, half, nchunk;
+  bool live;
+};
+__device__ __forceinline__ PersistRole persist_role(int local, int nchunk_local, int hv) {
+  PersistRole r;
+  if (local) {
+    const int lin = blockIdx.x, cls = lin & 7, idx = lin >> 3;
+    r.nchunk = nchunk_local;
+    r.live = cls < local * nchunk_local;           // local = number of directions in the launch (1 or 2)
+    r.d = cls / nchunk_local;
+    r.chunk = cls - r.d * nchunk_local;
+    r.tile = idx / hv;
+    r.half = idx - r.tile * hv;
+  } else {
+    r.nchunk = gridDim.z / hv;
+    r.live = true;
+    r.tile = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // xcd_grouped_tile
+    r.d = blockIdx.y;
+    r.chunk = blockIdx.z / hv;
+    r.half = blockIdx.z % hv;
+  }
+  return r;
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -395,6 +436,20 @@ __device__ __forceinline__ int xcd_grouped_tile(int bx, int ntile) {
 constexpr unsigned PERSIST_MAX_SPINS = 1u << 20;   // ~ a second of polling, then give up for good
 
 constexpr unsigned PERSIST_SENTINEL = 0x7FC0DEADu;   // a NaN: h = o * tanh(c) can never produce it
+
+// Bounded spins with a latch.  True when this wave should stop waiting for a hand-off: either it
+// has itself retried PERSIST_MAX_SPINS times (it then sets the launch's status word), or -- looked
+// at on the 8th retry and every 256th after it, one sc1 load -- some wave of the launch already
+// has.  Without the latch every wave of every later step would spin out its own second: a launch
+// with ONE missing producer ran for minutes on NaN data; with it the launch drains in
+// milliseconds and the status word tells the host (ops.check_persistent_status / FusedAdadelta.poll).
+__device__ __forceinline__ bool persist_give_up(unsigned tries, int* status) {
+  if (tries > PERSIST_MAX_SPINS) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+  return (tries & 255u) == 8u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
 // SENTINEL = true: no arrival counter.  The host pre-fills the exchange image
 // with PERSIST_SENTINEL; a consumer first polls one 16-byte piece per producer
@@ -456,13 +511,16 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   if (tid == 0) missed = 0;
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
-  const int tile = xcd_grouped_tile(blockIdx.x, gridDim.x), d = blockIdx.y, chunk = blockIdx.z;
+  const PersistRole role = persist_role(e.local, e.nchunk, 1);
+  if (!role.live) return;
+  const int tile = role.tile, d = role.d, chunk = role.chunk;
+  const bool local = e.local != 0;
   const int S = e.S, N = e.N, H = e.H;
   const int n0 = chunk * 16 * NB;
   const int Np = (N + 7) & ~7;                 // image columns: 128-byte lines never shared by two tiles
-  const unsigned ntile = gridDim.x;
+  const unsigned ntile = (unsigned)(H / 4);
   const int64_t rows = (int64_t)S * N;
-  unsigned* cnt = e.cnt + d * gridDim.z + chunk;
+  unsigned* cnt = e.cnt + d * role.nchunk + chunk;
   float* gbase = e.gates + (int64_t)d * rows * 4 * H;
   const size_t xbytes = (size_t)S * Np * H * sizeof(float);
   float* xbase = e.hx + (int64_t)d * S * Np * H;
@@ -553,7 +611,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
           const unsigned target = ntile * (unsigned)i;
           unsigned spins = 0;
           while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; break; }
+            if (persist_give_up(++spins, e.status)) break;
             __builtin_amdgcn_s_sleep(1);
           }
         }
@@ -638,7 +696,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
             }
           }
           if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
-          if (tries > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; break; }
+          if (persist_give_up(tries, e.status)) break;
           __builtin_amdgcn_s_sleep(2);
         }
       }
@@ -685,8 +743,10 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         u32x4 pv = {__builtin_bit_cast(unsigned, hv.x), __builtin_bit_cast(unsigned, hv.y),
                     __builtin_bit_cast(unsigned, hv.z), __builtin_bit_cast(unsigned, hv.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
-                                               (int)((int64_t)s * Np * H * 4), 16);
+        if (local) __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
+                                                          (int)((int64_t)s * Np * H * 4), 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
+                                                    (int)((int64_t)s * Np * H * 4), 16);
       }
       SSASR_PTRACE(i, 7);
       if (!SENTINEL) {
@@ -864,6 +924,7 @@ struct EncPersistBwd {
   int i0, i1;
   float* dc_state;
   const float* whh[2];   // K-split form: the untransposed [4H][H] weights per direction (whhT unused) or null
+  int local, nchunk;     // K-split form: XCD-local placement (persist_role): local = directions, 1-D launch of 8 * (H / 16) * HV workgroups
 };
 
 template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
@@ -955,7 +1016,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_persistent_kernel(EncPersist
           const unsigned target = ntile * (unsigned)i;
           unsigned spins = 0;
           while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > PERSIST_MAX_SPINS) { *e.status = 1; break; }
+            if (persist_give_up(++spins, e.status)) break;
             __builtin_amdgcn_s_sleep(1);
           }
         }
@@ -1016,7 +1077,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_persistent_kernel(EncPersist
             }
           }
           if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
-          if (tries > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; break; }
+          if (persist_give_up(tries, e.status)) break;
           __builtin_amdgcn_s_sleep(2);
         }
       }
@@ -1201,8 +1262,11 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   if (tid == 0) missed = 0;
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
-  const int tile = xcd_grouped_tile(blockIdx.x, gridDim.x), d = blockIdx.y, chunk = blockIdx.z / HV, half = blockIdx.z % HV;
-  const int nchunk = gridDim.z / HV;
+  const PersistRole role = persist_role(e.local, e.nchunk, HV);
+  if (!role.live) return;
+  const int tile = role.tile, d = role.d, chunk = role.chunk, half = role.half;
+  const int nchunk = role.nchunk;
+  const bool local = e.local != 0;
   const int S = e.S, N = e.N, H = e.H;
   const int i0 = e.i0, i1 = e.i1 > 0 ? e.i1 : S;    // this launch's iterations
   constexpr int T = 4 * TPW;                    // unit tiles = H / 16
@@ -1258,8 +1322,10 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
         // re-arm what was consumed in step i - LAG + 1: slot (i - LAG) % RING, dest = tile, all sources
         const unsigned base = (unsigned)((i - LAG) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
 #pragma unroll
-        for (int j = 0; j < T; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
+        for (int j = 0; j < T; ++j) {
+          if (local) __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
+        }
       }
       if (HV >= 2 && half == 0 && col_ok && i == i0 + 2) {
         // row-major copies of the launch's first two steps (see the note on in-place rows above)
@@ -1329,7 +1395,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
           }
         }
         if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
-        if (tries > PERSIST_MAX_SPINS) { if (lane == 0) *e.status = 1; break; }
+        if (persist_give_up(tries, e.status)) break;
         __builtin_amdgcn_s_sleep(2);
       }
       SSASR_PTRACE(i, 3);
@@ -1419,9 +1485,12 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       }
       const unsigned base = (unsigned)(i % BWD_RS_RING) * SLOT_B + (unsigned)tile * TILE_B;   // source = this tile
 #pragma unroll
-      for (int t = 0; t < OT; ++t)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t] + acc2[t]), xrs,
-                                               (int)((otile0 + t) * T * TILE_B + lane * 16), (int)base, 16);
+      for (int t = 0; t < OT; ++t) {
+        if (local) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t] + acc2[t]), xrs,
+                                                          (int)((otile0 + t) * T * TILE_B + lane * 16), (int)base, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t] + acc2[t]), xrs,
+                                                    (int)((otile0 + t) * T * TILE_B + lane * 16), (int)base, 16);
+      }
       SSASR_PTRACE(i, 7);
     }
   }

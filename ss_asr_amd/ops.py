@@ -114,6 +114,11 @@ def side_stream():
     global _side
     if _side is None:
         _side = torch.cuda.Stream()
+        # First use of the overlapped backward: verify the dispatcher property that XCD-local
+        # placement of the BPTT rests on (include/ssasr.h, ssasr_probe_placement).  Once.
+        rc = _lib.load().ssasr_probe_placement(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc < 0:
+            raise RuntimeError('ssasr_probe_placement: HIP error %d' % -rc)
     return _side
 
 
@@ -681,17 +686,17 @@ class _DecoderLoop(torch.autograd.Function):
             if sinks is None:
                 dpsi = (f(A, E), f(A))
                 check(lib.ssasr_attn_precompute_wgrad(_p(out['dcomp']), _p(feat), B * T, E, A, _p(dpsi[0]),
-                                                      _p(dpsi[1]), 0, _stream()), 'ssasr_attn_precompute_wgrad')
+                                                      _p(dpsi[1]), 0, 0, _stream()), 'ssasr_attn_precompute_wgrad')
         if sinks is not None:
             main = torch.cuda.current_stream()
             side = side_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                check(lib.ssasr_decoder_wgrad(C.byref(d), C.byref(g), 1, C.c_void_p(side.cuda_stream)),
+                check(lib.ssasr_decoder_wgrad(C.byref(d), C.byref(g), 1, 1, C.c_void_p(side.cuda_stream)),
                       'ssasr_decoder_wgrad')
                 if ctx.psi:
                     check(lib.ssasr_attn_precompute_wgrad(_p(out['dcomp']), _p(feat), B * T, E, A, _p(sinks[-2]),
-                                                          _p(sinks[-1]), 1, C.c_void_p(side.cuda_stream)),
+                                                          _p(sinks[-1]), 1, 1, C.c_void_p(side.cuda_stream)),
                           'ssasr_attn_precompute_wgrad')
             for t in list(bufs.values()) + list(ws.values()) + [dlogits, out['dcomp'], feat]:
                 t.record_stream(side)

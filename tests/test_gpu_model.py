@@ -110,6 +110,40 @@ def test_backward_and_solver_step_match_reference(golden, name):
                                        rtol=0, err_msg=k)
 
 
+def test_backward_matches_reference_in_both_bptt_placements(golden):
+    """The K-split BPTT runs XCD-locally (one exchange group per XCD, hand-offs through that XCD's
+    L2, side-stream GEMMs on the other XCDs) when the placement probe allows it, else spread over
+    all XCDs with write-through hand-offs.  Both placements against the reference's gradients."""
+    from ss_asr_amd import _lib, ops
+    from ss_asr_amd.optim import FlatParameters
+    fx = golden('full_b16_t400')
+    ops.side_stream()                            # runs the probe
+    probed = _lib.set_option('SSASR_XCD_ROUND_ROBIN', 1)
+    _lib.set_option('SSASR_XCD_ROUND_ROBIN', probed)
+    assert probed in (0, 1)
+    names = [str(n) for n in fx['param_names']]
+    for local in (1, 0):
+        old = _lib.set_option('SSASR_BPTT_LOCAL', local)
+        try:
+            model = build(fx)
+            flat = FlatParameters(model)
+            flat.zero_grad()
+            _, _, _, loss = forward(fx, model)
+            loss.backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            ops.check_persistent_status()
+        finally:
+            _lib.set_option('SSASR_BPTT_LOCAL', old)
+        params = dict(model.named_parameters())
+        got = np.array([params[n].grad.double().norm().item() for n in names])
+        np.testing.assert_allclose(got, fx['grad_norms'], rtol=1e-3, atol=1e-6, err_msg='local=%d' % local)
+        for k in fx.files:
+            if k.startswith('g_head/'):
+                np.testing.assert_allclose(params[k[7:]].grad.reshape(-1)[:256].cpu().numpy(), fx[k], atol=2e-5,
+                                           rtol=0, err_msg=k)
+
+
 def test_module_level_loop_equals_fused_loop(golden):
     """Driving Attention / Speller step by step (the way TextAutoEncoder does,
     src/text_autoencoder.py:55-88) gives the fused decode loop's result."""

@@ -13,7 +13,7 @@
 #else
 #define SSASR_CLK "s_memtime"
 #endif
-constexpr int TR_LO = 200, TR_N = 64, TR_SLOTS = 12, TR_WG = 256;
+constexpr int TR_LO = 200, TR_N = 64, TR_SLOTS = 12, TR_WG = 512;
 __device__ unsigned long long g_trace[TR_WG * TR_N * TR_SLOTS];
 #define SSASR_PTRACE(step, slot) do { if (threadIdx.x == 0 && (step) >= TR_LO && (step) < TR_LO + TR_N) { \
   unsigned long long t_; asm volatile(SSASR_CLK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
@@ -126,8 +126,11 @@ int main(int argc, char** argv) {
     CK(hipMemsetAsync(sync, 0, 32, st));
     CK(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * NpF * H), st));
     CK(hipEventRecord(e0, st));
-    if (nbF == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 1>), dim3(H / 4, 2, chF), dim3(320), 0, st, pf);
-    else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 2>), dim3(H / 4, 2, chF), dim3(320), 0, st, pf);
+    const bool localF = getenv("LOCAL") != nullptr && 2 * chF <= 8;
+    pf.local = localF ? 2 : 0; pf.nchunk = chF;
+    const dim3 gridF = localF ? dim3(8 * (H / 4)) : dim3(H / 4, 2, chF);
+    if (nbF == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 1>), gridF, dim3(320), 0, st, pf);
+    else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 2>), gridF, dim3(320), 0, st, pf);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
@@ -136,7 +139,8 @@ int main(int argc, char** argv) {
   // tick calibration: stamps span of the traced window vs the event-timed period is
   // not exact, so calibrate s_memtime against the wall clock with a sleep kernel instead
   double us_per_tick = 0.01;   // 100 MHz
-  if (report("fwd", (int)(H / 4) * 2 * chF, us_per_tick, (int)(H / 4))) return 1;
+  if (getenv("LOCAL")) { printf("(LOCAL: per-phase report skipped)\n"); }
+  else if (report("fwd", (int)(H / 4) * 2 * chF, us_per_tick, (int)(H / 4))) return 1;
   CK(hipMemset(gates, 0, sizeof(float) * 2 * rows * 4 * H));
   const bool rs = getenv("GATHER") == nullptr;
   for (int rep = 0; rep < 3; ++rep) {
@@ -146,6 +150,10 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0, st));
     if (rs && getenv("HALVES_OFF")) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
     else if (rs && getenv("QUARTERS")) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 4>), dim3(H / 16, 2, chB * 4), dim3(320), 0, st, pb);
+    else if (rs && getenv("LOCAL") && 2 * chB <= 8) {
+      pb.local = 2; pb.nchunk = chB;
+      hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), dim3(8 * (H / 16) * 2), dim3(320), 0, st, pb);
+    }
     else if (rs) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), dim3(H / 16, 2, chB * 2), dim3(320), 0, st, pb);
     else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
@@ -153,6 +161,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
     printf("bwd %s: %.3f us / step (status %d)\n", rs ? "K-split" : "gather", ms * 1e3 / S, status);
   }
+  if (getenv("LOCAL")) return report("bwd (local)", 256, us_per_tick, 256);
   if (report("bwd", (int)(H / 16) * 2 * chB * (rs && getenv("QUARTERS") ? 4 : rs && !getenv("HALVES_OFF") ? 2 : 1), us_per_tick, (int)(H / 16))) return 1;
   return 0;
 }
