@@ -210,19 +210,21 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
     gx = torch.empty(int(lib.ssasr_bilstm_bwd_gx_floats(S, N, H)), device=device)
     ws_t = torch.empty(2, H, 4 * H, device=device)
     ws_dc = torch.empty(2, 2, N, H, device=device)
+    ts_floats = int(lib.ssasr_bilstm_tsave_floats(S, N, H))          # tile-major saves, as ops.bilstm allocates them
+    tsave = torch.empty(ts_floats, device=device) if ts_floats else None
     sync = torch.zeros(8, device=device, dtype=torch.int32)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 
     def fwd():
         ops.check(lib.ssasr_bilstm_fwd(p(x), N * I, I, S, N, I, H, None, *[p(t) for t in w], p(y), N * 2 * H, 2 * H,
-                                       p(gates), p(cs), p(hs), p(hx), p(sync), 0, st), 'ssasr_bilstm_fwd')
+                                       p(gates), p(cs), p(hs), p(hx), p(sync), 0, p(tsave), st), 'ssasr_bilstm_fwd')
 
     def bwd():
         ops.check(lib.ssasr_bilstm_bwd(p(dy), N * 2 * H, 2 * H, p(x), N * I, I, S, N, I, H, None,
                                        p(w[0]), p(w[1]), p(w[4]), p(w[5]), p(gates), p(cs), p(hs),
                                        None, N * I, I, None, None, None, None, None, None,
-                                       p(ws_t), p(ws_dc), p(gx), p(sync), 0, st), 'ssasr_bilstm_bwd')
+                                       p(ws_t), p(ws_dc), p(gx), p(sync), 0, p(tsave), st), 'ssasr_bilstm_bwd')
 
     def i2h():
         # the input projection exactly as ssasr_bilstm_fwd launches it: both directions as the two

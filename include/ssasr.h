@@ -47,7 +47,7 @@ int ssasr_abi_version(void);
  * calls.  Names: SSASR_NO_PERSISTENT, SSASR_PERSISTENT_COUNTER, SSASR_NO_FUSED_INPUT,
  * SSASR_FWD_NB, SSASR_BPTT_GATHER, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
  * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
- * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_NO_RESIDENCY_CHECK, SSASR_BPTT_LOCAL,
+ * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_BPTT_LOCAL,
  * SSASR_XCD_ROUND_ROBIN (the probe's verdict, settable for tests).  Unknown name: -1. */
 int ssasr_set_option(const char* name, int value);
 int ssasr_get_option(const char* name, int* value);
@@ -95,16 +95,22 @@ int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
  * armed != 0: hx already holds the fill pattern 0x7FC0DEAD in every word, written on the same
  * stream (a caller that arms the exchange workspaces of a whole pass with ONE fill: a dependent
  * launch costs ~6 us however small); 0: the call fills it itself.
+ * tsave: optional, ssasr_bilstm_tsave_floats(S, N, H) floats (0: the shape has no use for it).
+ * With it the activated gates and cell states that the backward pass streams back are saved
+ * TILE-MAJOR there (5 KB contiguous per BPTT workgroup and step) instead of row-major in
+ * gates / cs: `gates` then keeps the input projection (and receives the derivatives in backward),
+ * cs is not touched and may be NULL.  The same pointer must be passed to the backward call.
  * Replaces: pBLSTM.forward / nn.LSTM, src/asr.py:406-427, :262. */
+int64_t ssasr_bilstm_tsave_floats(int64_t S, int64_t N, int64_t H);
 int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
                      int64_t H, const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
                      const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,
                      const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* y,
                      int64_t ys_s, int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
-                     int32_t* sync_ws, int armed, void* stream);
+                     int32_t* sync_ws, int armed, float* tsave, void* stream);
 
 /* Backward of ssasr_bilstm_fwd.  `gates` is consumed (overwritten with the
- * gate pre-activation derivatives).  dx may be NULL.  db_* is the derivative
+ * gate pre-activation derivatives).  tsave: what the forward call was given (then cs may be NULL).  dx may be NULL.  db_* is the derivative
  * of b_ih and of b_hh alike.  Workspaces: ws_whhT [2][H][4H], ws_dc [2][2][N][H].
  * dw_ih_f == NULL defers every weight gradient to ssasr_bilstm_wgrad.
  * Optional, enabling the single-launch persistent BPTT (H in {64,128,256},
@@ -125,7 +131,7 @@ int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x
                      const float* w_hh_r, float* gates, const float* cs, const float* hs, float* dx,
                      int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f, float* db_f,
                      float* dw_ih_r, float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc,
-                     float* gx, int32_t* sync_ws, int armed, void* stream);
+                     float* gx, int32_t* sync_ws, int armed, const float* tsave, void* stream);
 
 /* ssasr_bilstm_bwd with the weight gradients accumulated (+=) into dw_* / db* (db2_*: optional
  * second copy, b_ih and b_hh share theirs) on `side_stream`, overlapped with the recurrence:
@@ -140,8 +146,8 @@ int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_t ys_n, con
                                 const float* hs, float* dx, int64_t dxs_s, int64_t dxs_n, float* dw_ih_f,
                                 float* dw_hh_f, float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
                                 float* db_r, float* db2_r, float* ws_whhT, float* ws_dc, float* gx,
-                                int32_t* sync_ws, int armed, int segments, void* events, void* stream,
-                                void* side_stream);
+                                int32_t* sync_ws, int armed, const float* tsave, int segments, void* events,
+                                void* stream, void* side_stream);
 
 /* Weight gradients of a layer from the gate derivatives ssasr_bilstm_bwd left
  * in `gates`: dW_ih = dG^T X, dW_hh = sum_s dG[s]^T h[s_prev], db = column sums.

@@ -57,6 +57,23 @@ __device__ __forceinline__ float block_reduce_max(float v, float* sm, int nw) {
 
 __device__ __forceinline__ float4 aload4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Copies nquad float4 from global `src` to LDS `dst`, the block's threads striding by NT, EIGHT
+// loads in flight per thread before the first LDS store: a plain `for (i = tid; ...) dst[i] = src[i]`
+// is compiled to load -> wait -> store per iteration, i.e. one memory round trip per 4 KB of a
+// 100 KB slice (~40 us at the start of a persistent decode launch).
+template <int NT>
+__device__ __forceinline__ void lds_fill_quads(float* dst, const float* src, int nquad, int tid) {
+  int i = tid;
+  for (; i + 7 * NT < nquad; i += 8 * NT) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = aload4(src + 4 * (int64_t)(i + k * NT));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(dst + 4 * (i + k * NT)) = v[k];
+  }
+  for (; i < nquad; i += NT) *reinterpret_cast<float4*>(dst + 4 * i) = aload4(src + 4 * (int64_t)i);
+}
+
 // Fast path: A == 128, E / nch == 128, T <= 128 * NP.  grid (B, nch), 256
 // threads = 8 half-waves; half-wave hw owns rows t = hw + 8 i.  A lane holds 4
 // of the 128 columns of its rows of comp AND of this workgroup's feat slice.

@@ -102,7 +102,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0 = 0, int64_t i1 = 0,
                                  float* dc_state = nullptr, const float* whh_f = nullptr, const float* whh_r = nullptr,
-                                 bool armed = false);
+                                 bool armed = false, const float* tsave = nullptr);
 // Process-wide diagnostic switches (include/ssasr.h, ssasr_set_option): read from the environment
 // ONCE, when the first entry point runs, never per call; A/B tools change them through
 // ssasr_set_option.  Everything here selects between kernels that compute the same result.
@@ -119,6 +119,7 @@ struct SsasrOptions {
   int delay_fwd, delay_bwd, delay_bwd_ksplit;   // SSASR_PERSIST_DELAY_FWD / _BWD (initial pacing, x 64 cycles; -1 = default)
   int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
   int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches
+  int no_tsave;                   // SSASR_NO_TSAVE: saved gates / cell states row-major (in place) instead of tile-major
   int bptt_local;                 // SSASR_BPTT_LOCAL (0): XCD-local placement of the K-split BPTT when the probe allows it
   int xcd_round_robin;            // verdict of ssasr_probe_placement(): -1 not probed, 0 no, 1 yes (not an environment switch)
 };

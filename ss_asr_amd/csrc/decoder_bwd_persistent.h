@@ -169,8 +169,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
     float* sRed = sD + E;                                    // [8][A]
     float* sS = sRed + 8 * A;                                // [8] partial s, [8..] unused
     const float* fb = p.feat + ((int64_t)b * T + tau0) * E;
-    for (int i = tid; i < nrow * (E / 4); i += 256)
-      *reinterpret_cast<float4*>(sF + 4 * i) = aload4(fb + 4 * (int64_t)i);
+    lds_fill_quads<256>(sF, fb, nrow * (E / 4), tid);
     __syncthreads();
     const int c = b >> 4, bl = b & 15;
     // dctx gather: the 16 sources' rows of this utterance are one contiguous 32 KB block

@@ -162,10 +162,28 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
     int len = p.enc_len ? p.enc_len[b] : T;
     len = len < T ? len : T;
     const float* fb = p.feat + (int64_t)b * T * PD_E + chunk * 256;
-    for (int i = tid; i < T * 64; i += 256) {
-      const int t = i >> 6, c4 = i & 63;
-      *reinterpret_cast<float4*>(sF + t * 256 + 4 * c4) =
-          t < len ? aload4(fb + (int64_t)t * PD_E + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // this workgroup's [T][256] slice of feat -> LDS, eight loads in flight per thread (a one-load
+    // loop costs a memory round trip per 4 KB: ~40 us of the launch)
+    {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      int i = tid;
+      for (; i + 7 * 256 < T * 64; i += 8 * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int ii = i + 256 * k, t = ii >> 6, c4 = ii & 63;
+          v[k] = t < len ? aload4(fb + (int64_t)t * PD_E + 4 * c4) : z;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int ii = i + 256 * k;
+          *reinterpret_cast<float4*>(sF + (ii >> 6) * 256 + 4 * (ii & 63)) = v[k];
+        }
+      }
+      for (; i < T * 64; i += 256) {
+        const int t = i >> 6, c4 = i & 63;
+        *reinterpret_cast<float4*>(sF + t * 256 + 4 * c4) = t < len ? aload4(fb + (int64_t)t * PD_E + 4 * c4) : z;
+      }
     }
     __syncthreads();
     const float* cb = p.comp + (int64_t)b * T * PD_A + 4 * l32;

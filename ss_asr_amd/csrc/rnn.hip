@@ -52,10 +52,11 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
                                 const float* b_hh_f, const float* w_ih_r, const float* w_hh_r,
                                 const float* b_ih_r, const float* b_hh_r, float* y, int64_t ys_s,
                                 int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
-                                int32_t* sync_ws, int armed, void* stream) {
+                                int32_t* sync_ws, int armed, float* tsave, void* stream) {
   const SsasrOptions& opt = ssasr_options();
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
-  if (!x || !y || !gates || !cs || !hs) return SSASR_EARG;
+  if (!x || !y || !gates || (!cs && !tsave) || !hs) return SSASR_EARG;
+  if (tsave && !aligned16(tsave)) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = S * N;
   const float* wih[2] = {w_ih_f, w_ih_r};
@@ -129,12 +130,16 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     }
 #undef SSASR_FWD_FN_PICK
 #undef SSASR_FWD_FN
+    // tile-major saves exist in the persistent form only: a caller that passes the buffer was told
+    // by ssasr_bilstm_tsave_floats that this shape takes it
+    if (tsave && !fits) return SSASR_EARG;
     if (!fuse_in) {
       const int rc = input_projection();
       if (rc) return rc;
     }
     if (fits) {
       EncPersist p{};
+      p.tsave = tsave;
       p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
       p.x = x; p.xs_s = xs_s; p.xs_n = xs_n;
       for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }
@@ -168,6 +173,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       return SSASR_OK;
     }
   }
+  if (tsave) return SSASR_EARG;
   EncFwd e{};
   e.whh[0] = w_hh_f; e.whh[1] = w_hh_r;
   e.gates = gates; e.cs = cs; e.hs = hs; e.y = y; e.lens = lens;
@@ -184,6 +190,33 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
                                   float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
                                   float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
                                   int accumulate, int beside, void* stream);
+
+// The shape half of ssasr_bilstm_fwd's test for its persistent form (the pointer-alignment half is
+// the caller's: torch allocations are 256-byte aligned), residency of the grid included.
+static bool fwd_persistent_shape_ok(int64_t S, int64_t N, int64_t H) {
+  const SsasrOptions& opt = ssasr_options();
+  if (S <= 0 || N <= 0 || N > 128 || H <= 0 || H % 64 != 0 || opt.no_persistent) return false;
+  const int kpw = (int)(H / 64);
+  if (!(kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8)) return false;
+  const int64_t Np = (N + 7) & ~(int64_t)7;
+  int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
+  if (opt.fwd_nb) nb = opt.fwd_nb == 1 ? 1 : 2;
+  const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
+  if ((H / 4) * 2 * chunks > 512 || S * Np * H * 4 >= (1ll << 31)) return false;
+  const bool sen = !opt.persistent_counter;
+#define SSASR_FN(K, NBT) (sen ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, true, NBT>) \
+                              : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, false, NBT>))
+  const void* fn = nb == 1 ? (kpw == 1 ? SSASR_FN(1, 1) : kpw == 2 ? SSASR_FN(2, 1) : kpw == 4 ? SSASR_FN(4, 1) : SSASR_FN(8, 1))
+                           : (kpw == 1 ? SSASR_FN(1, 2) : kpw == 2 ? SSASR_FN(2, 2) : kpw == 4 ? SSASR_FN(4, 2) : SSASR_FN(8, 2));
+#undef SSASR_FN
+  if (!grid_fits(fn, 320, 0, (H / 4) * 2 * chunks)) return false;
+  if (kpw == 4 && sen) {      // the first layer's variant (fused input projection) is the larger kernel
+    const void* ff = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 1, 5>)
+                             : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 2, 5>);
+    if (!grid_fits(ff, 320, 0, (H / 4) * 2 * chunks)) return false;
+  }
+  return true;
+}
 
 // Exchange workspace of the persistent BPTT: the larger of the gather form's
 // per-step image and the K-split form's ring (0: no persistent form for this shape).
@@ -211,6 +244,13 @@ static const void* bptt_rs_fn(int kpw, bool halves) {
                 : reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 1>);
 }
 
+// Floats of the tile-major save buffer of a layer, 0 when the shape does not take BOTH persistent
+// forms (the forward kernel that writes it and the K-split BPTT that reads it).
+extern "C" int64_t ssasr_bilstm_tsave_floats(int64_t S, int64_t N, int64_t H) {
+  if (ssasr_options().no_tsave || !fwd_persistent_shape_ok(S, N, H) || !ssasr_bptt_ksplit_ok(S, N, H, 2)) return 0;
+  return 2 * S * ((N + 15) / 16) * 16 * H * 5;
+}
+
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
   const SsasrOptions& opt = ssasr_options();
   const int64_t chunks = (N + 15) / 16;
@@ -224,25 +264,26 @@ bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0, int64_t i1,
-                                 float* dc_state, const float* whh_f, const float* whh_r, bool armed) {
+                                 float* dc_state, const float* whh_f, const float* whh_r, bool armed,
+                                 const float* tsave) {
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int kpw = (int)(H / 16);
   const SsasrOptions& opt = ssasr_options();
   const bool ksplit = !opt.persistent_counter && !opt.bptt_gather;
   if (i1 <= 0) i1 = S;
   const bool ranged = i0 != 0 || i1 != S;
-  if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && (!ksplit || !dc_state))) return SSASR_EARG;
+  if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && (!ksplit || !dc_state)) || (tsave && !ksplit)) return SSASR_EARG;
   // every workgroup must be resident: at most one (K-split) per CU; the gather form is kept to two chunks
   if ((!whhT && !(ksplit && whh_f)) || !gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
       (ksplit ? (H / 16) * dirs * chunks > 256 : chunks > 2) ||
-      S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) || !aligned16(cs) ||
+      S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) || (!tsave && !aligned16(cs)) ||
       !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
     return SSASR_EARG;
   if (i0 == 0 && !ksplit) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 4 * sizeof(int32_t), st));   // arrival counters
   EncPersistBwd p{};
   p.i0 = (int)i0; p.i1 = (int)i1; p.dc_state = dc_state;
   if (ksplit && whh_f && (dirs == 1 || whh_r)) { p.whh[0] = whh_f; p.whh[1] = whh_r; }
-  p.whhT = whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens;
+  p.whhT = whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens; p.tsave = tsave;
   p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
   p.delay = persist_delay(opt.delay_bwd, 16);
   p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
@@ -314,7 +355,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
 
 // Backward of the layer.  `gates` is consumed: on return it holds the gate
 // pre-activation derivatives.  dw_* / db_* are overwritten.
-static int bilstm_bwd_impl(bool armed, const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
+static int bilstm_bwd_impl(bool armed, const float* tsave, const float* dy, int64_t ys_s, int64_t ys_n, const float* x,
                                 int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
                                 int64_t H, const int32_t* lens, const float* w_ih_f,
                                 const float* w_hh_f, const float* w_ih_r, const float* w_hh_r,
@@ -324,9 +365,9 @@ static int bilstm_bwd_impl(bool armed, const float* dy, int64_t ys_s, int64_t ys
                                 float* ws_whhT /* [2][H][4H] */, float* ws_dc /* [2][2][N][H] */,
                                 float* gx, int32_t* sync_ws, void* stream) {
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
-  if (!dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
+  if (!dy || !x || !gates || (!cs && !tsave) || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
   // the gate epilogue of the backward kernel uses 16-byte accesses
-  if (!aligned16(dy) || !aligned16(gates) || !aligned16(cs) || !aligned16(ws_dc) || ys_s % 4 || ys_n % 4)
+  if (!aligned16(dy) || !aligned16(gates) || (!tsave && !aligned16(cs)) || !aligned16(ws_dc) || ys_s % 4 || ys_n % 4)
     return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = S * N;
@@ -357,10 +398,11 @@ static int bilstm_bwd_impl(bool armed, const float* dy, int64_t ys_s, int64_t ys
   if (gx && sync_ws && !ssasr_options().no_persistent) {
     rc = ssasr_launch_bptt_persistent(direct ? nullptr : ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H,
                                       2, st, 0, 0, nullptr, direct ? w_hh_f : nullptr, direct ? w_hh_r : nullptr,
-                                      armed && direct);
+                                      armed && direct, tsave);
     if (rc == SSASR_OK) persistent = true;
     else if (rc != SSASR_EARG) return rc;
   }
+  if (tsave && !persistent) return SSASR_EARG;      // the saves are tile-major: only the K-split kernel reads them
   if (!persistent && (rc = transpose_whh())) return rc;
   EncBwd e{};
   e.whhT = ws_whhT; e.gates = gates; e.cs = cs; e.dy = dy; e.dc = ws_dc; e.lens = lens;
@@ -393,8 +435,8 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
                                 float* gates, const float* cs, const float* hs, float* dx, int64_t dxs_s,
                                 int64_t dxs_n, float* dw_ih_f, float* dw_hh_f, float* db_f, float* dw_ih_r,
                                 float* dw_hh_r, float* db_r, float* ws_whhT, float* ws_dc, float* gx,
-                                int32_t* sync_ws, int armed, void* stream) {
-  return bilstm_bwd_impl(armed != 0, dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r,
+                                int32_t* sync_ws, int armed, const float* tsave, void* stream) {
+  return bilstm_bwd_impl(armed != 0, tsave, dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r,
                          w_hh_r, gates, cs, hs, dx, dxs_s, dxs_n, dw_ih_f, dw_hh_f, db_f, dw_ih_r, dw_hh_r, db_r,
                          ws_whhT, ws_dc, gx, sync_ws, stream);
 }
@@ -568,8 +610,8 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
                                            int64_t dxs_s, int64_t dxs_n, float* dw_ih_f, float* dw_hh_f,
                                            float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
                                            float* db_r, float* db2_r, float* ws_whhT, float* ws_dc, float* gx,
-                                           int32_t* sync_ws, int armed_in, int segments, void* events,
-                                           void* stream, void* side_stream) {
+                                           int32_t* sync_ws, int armed_in, const float* tsave, int segments,
+                                           void* events, void* stream, void* side_stream) {
   const bool armed = armed_in != 0;
   if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r || !side_stream || !events) return SSASR_EARG;
   SsasrEvents* evs = static_cast<SsasrEvents*>(events);
@@ -584,7 +626,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
   int rc;
   if (nseg == 1) {
     // plain form: the whole backward on `stream`, then every weight gradient on the second stream
-    rc = bilstm_bwd_impl(armed, dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates,
+    rc = bilstm_bwd_impl(armed, tsave, dy, ys_s, ys_n, x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, w_ih_r, w_hh_r, gates,
                          cs, hs, dx, dxs_s, dxs_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws_whhT, ws_dc,
                          gx, sync_ws, stream);
     if (rc) return rc;
@@ -594,7 +636,8 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, db2_f, dw_ih_r, dw_hh_r,
                               db_r, db2_r, 1, 1, side_stream);
   }
-  if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dy || !x || !gates || !cs || !hs || !ws_whhT || !ws_dc) return SSASR_EARG;
+  if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dy || !x || !gates || (!cs && !tsave) || !hs || !ws_whhT || !ws_dc)
+    return SSASR_EARG;
   const float* wih[2] = {w_ih_f, w_ih_r};
   if (!w_hh_f || !w_hh_r) return SSASR_EARG;
   // Everything of `stream` is enqueued first -- the ranges' launches, an event behind each, the input
@@ -606,7 +649,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
     // the K-split kernel takes its weight slices straight from W_hh: no transposed copy
     rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
-                                      ws_dc, w_hh_f, w_hh_r, armed);
+                                      ws_dc, w_hh_f, w_hh_r, armed, tsave);
     if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
     done[k] = evs->ev[k];
     SSASR_HIP(hipEventRecord(done[k], st));

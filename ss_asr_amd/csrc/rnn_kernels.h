@@ -373,12 +373,25 @@ struct EncPersist {
   const float* wih[2];   // [4H][I] per direction
   const float* bih[2];
   const float* bhh[2];
+  // Tile-major copy of what the BPTT streams back (activated gates i, f, g, o and the cell state):
+  // [2][S][ceil(N/16)][H/16][5][4 unit quads][16 columns][4 units], i.e. 5 KB contiguous per BPTT workgroup and
+  // step, whole 128-byte lines (tsave_index).  When given, the row-major `gates` / `cs` are NOT
+  // written: the pre-activations stay in `gates`, which the BPTT later overwrites with derivatives.
+  float* tsave;
   // XCD-local placement (see persist_role): != 0 = the number of directions; the launch is 1-D,
   // 8 * (H / 4) workgroups, and `nchunk` column chunks x directions <= 8 exchange groups are dealt one to an XCD
   int local, nchunk;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Float offset of array a (0..3 = gates i, f, g, o; 4 = c) of (direction d, step s, 16-column
+// chunk, 16-unit tile) in the tile-major save buffer; element (column r, unit 4 q + e) sits at
+// + (q * 16 + r) * 4 + e: lane (q, r) = lane 16 q + r of a BPTT wave reads its 16 bytes, the wave
+// 1 KB contiguous; a forward workgroup (4 units = one q) writes 256 contiguous bytes per 16 columns.
+__device__ __forceinline__ int64_t tsave_index(int d, int s, int chunk16, int tile16, int a, int S, int C16, int T16) {
+  return (((((int64_t)d * S + s) * C16 + chunk16) * T16 + tile16) * 5 + a) * 256;
+}
 
 // Which part of a persistent recurrence a workgroup runs.
 // Spread placement (local == 0): grid (tiles, directions, chunks [* halves]); the workgroups of an
@@ -592,10 +605,14 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
         if (a < 7 && n < N) {
           const float4 v = *reinterpret_cast<const float4*>(&stage[a < 6 ? a : 5][col][0]);
           const int64_t row = (int64_t)s * N + n;
-          float* dst = a < 4 ? gbase + row * 4 * H + (int64_t)a * H + 4 * tile
-                     : a == 4 ? cbase + row * H + 4 * tile
-                     : a == 5 ? hbase + row * H + 4 * tile
-                              : e.y + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + 4 * tile;
+          float* dst;
+          if (a < 5 && e.tsave)
+            dst = e.tsave + tsave_index(d, s, n >> 4, tile >> 2, a, S, (N + 15) >> 4, H >> 4) + ((tile & 3) * 16 + (n & 15)) * 4;
+          else
+            dst = a < 4 ? gbase + row * 4 * H + (int64_t)a * H + 4 * tile
+                : a == 4 ? cbase + row * H + 4 * tile
+                : a == 5 ? hbase + row * H + 4 * tile
+                         : e.y + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + 4 * tile;
           *reinterpret_cast<float4*>(dst) = v;
         }
       }
@@ -925,6 +942,9 @@ struct EncPersistBwd {
   float* dc_state;
   const float* whh[2];   // K-split form: the untransposed [4H][H] weights per direction (whhT unused) or null
   int local, nchunk;     // K-split form: XCD-local placement (persist_role): local = directions, 1-D launch of 8 * (H / 16) * HV workgroups
+  // K-split form: tile-major saved gates and cell states written by the forward kernel (EncPersist::tsave)
+  // or null (then `gates` / `cs` hold them row-major and `gates` is overwritten in place)
+  const float* tsave;
 };
 
 template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
@@ -1191,14 +1211,31 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
     const int s = d ? i : S - 1 - i;
     const int sp = d ? s + 1 : s - 1;
     const bool has_prev = d ? (s < S - 1) : (s > 0);
-    const int64_t hu = ((int64_t)s * N + n) * H + u0;
-    const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
-    gi = ld4(gbase + g0);
-    gf = ld4(gbase + g0 + H);
-    gg = ld4(gbase + g0 + 2 * (int64_t)H);
-    go = ld4(gbase + g0 + 3 * (int64_t)H);
-    cv = ld4(cbase + hu);
-    cpv = has_prev ? ld4(cbase + ((int64_t)sp * N + n) * H + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.tsave) {
+      // tile-major saves: six contiguous 1 KB wave loads (whole lines) instead of 64-byte runs of
+      // rows that are 4 KB apart
+      const int lane = threadIdx.x & 63, C16 = (N + 15) >> 4, T16 = H >> 4;
+      const float* b0 = e.tsave + tsave_index(d, s, n >> 4, u0 >> 4, 0, S, C16, T16) + 4 * lane;
+      gi = ld4(b0);
+      gf = ld4(b0 + 256);
+      gg = ld4(b0 + 512);
+      go = ld4(b0 + 768);
+      cv = ld4(b0 + 1024);
+      // (always a load, from a valid step, so that a fetch is exactly 7 vector-memory operations: the
+      // helper wave's counted wait relies on it)
+      cpv = ld4(e.tsave + tsave_index(d, has_prev ? sp : s, n >> 4, u0 >> 4, 4, S, C16, T16) + 4 * lane);
+      if (!has_prev) cpv = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const int64_t hu = ((int64_t)s * N + n) * H + u0;
+      const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
+      gi = ld4(gbase + g0);
+      gf = ld4(gbase + g0 + H);
+      gg = ld4(gbase + g0 + 2 * (int64_t)H);
+      go = ld4(gbase + g0 + 3 * (int64_t)H);
+      cv = ld4(cbase + hu);
+      cpv = ld4(cbase + ((int64_t)(has_prev ? sp : s) * N + n) * H + u0);
+      if (!has_prev) cpv = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     ad = ld4(e.dy + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + u0);
   }
   // dh = product + dy;  dc = dc_carry + dh * A;  d_o = dh * O;  d_i = dc * I;
@@ -1267,6 +1304,9 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   const int tile = role.tile, d = role.d, chunk = role.chunk, half = role.half;
   const int nchunk = role.nchunk;
   const bool local = e.local != 0;
+  // saved gates row-major in `gates` = overwritten in place by the derivatives (the hazard the note
+  // above is about); with the forward kernel's tile-major copy there is nothing to protect
+  const bool inplace = e.tsave == nullptr;
   const int S = e.S, N = e.N, H = e.H;
   const int i0 = e.i0, i1 = e.i1 > 0 ? e.i1 : S;    // this launch's iterations
   constexpr int T = 4 * TPW;                    // unit tiles = H / 16
@@ -1288,6 +1328,9 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   if (wave == 4) {
     // ------------------------------ helper wave ------------------------------
     const int len = (col_ok && e.lens) ? e.lens[n] : 0x7fffffff;
+    // (Fetching TWO steps ahead of the use, from two register sets with a counted wait that leaves
+    // the younger fetch in flight, was tried in rounds 1 and 2: 6.67 -> 7.15 ms per train step.  More
+    // saved-activation requests in flight sit in the same CU memory path as the exchange loads.)
     BpttSaved sv;
     auto live = [&](int i) { return (d ? i : S - 1 - i) < len; };
     if (col_ok) {
@@ -1327,7 +1370,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
           else __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
         }
       }
-      if (HV >= 2 && half == 0 && col_ok && i == i0 + 2) {
+      if (HV >= 2 && inplace && half == 0 && col_ok && i == i0 + 2) {
         // row-major copies of the launch's first two steps (see the note on in-place rows above)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -1441,7 +1484,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       sG[i % NG][1][lane] = df;
       sG[i % NG][2][lane] = dg;
       sG[i % NG][3][lane] = dov;
-      if (epi && half == 0 && (HV == 1 || i >= i0 + 2)) {   // row-major copy for the dX and weight-gradient GEMMs
+      if (epi && half == 0 && (HV == 1 || !inplace || i >= i0 + 2)) {   // row-major copy for the dX and weight-gradient GEMMs
         const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
         st4(gbase + g0, di);
         st4(gbase + g0 + H, df);

@@ -284,8 +284,12 @@ class _BiLSTM(torch.autograd.Function):
             y = torch.empty(S, N, 2 * H, device=x.device, dtype=torch.float32)
             ys_s, ys_n = N * 2 * H, 2 * H
         gates = torch.empty(2, S * N, 4 * H, device=x.device, dtype=torch.float32)
-        cs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         hs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
+        # what the BPTT streams back (activated gates, cell states): tile-major when the layer takes
+        # both persistent forms (include/ssasr.h, tsave), else row-major in gates / cs
+        ts_floats = int(lib.ssasr_bilstm_tsave_floats(S, N, H))
+        tsave = torch.empty(ts_floats, device=x.device, dtype=torch.float32) if ts_floats else None
+        cs = None if ts_floats else torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         # workspaces of the persistent recurrence (exchange image + counters)
         hx_floats = 2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4 if N <= 128 and H % 64 == 0 else 0
         armed = 0
@@ -298,10 +302,10 @@ class _BiLSTM(torch.autograd.Function):
         sync = _status_words(x.device) if hx is not None else None
         check(lib.ssasr_bilstm_fwd(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
                                    _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
-                                   armed, _stream()), 'ssasr_bilstm_fwd')
+                                   armed, _p(tsave), _stream()), 'ssasr_bilstm_fwd')
         if sync is not None:
             _track_status(sync, 4)
-        ctx.save_for_backward(x, lens, gates, cs, hs, *w)
+        ctx.save_for_backward(x, lens, gates, cs, hs, tsave, *w)
         ctx.geom = (S, N, I, H, xs_s, xs_n, ys_s, ys_n, bool(batch_first))
         return y
 
@@ -312,7 +316,7 @@ class _BiLSTM(torch.autograd.Function):
             raise RuntimeError('bilstm: the saved gates were overwritten with their derivatives by the first '
                                'backward pass; a second pass over the same graph (retain_graph) is not supported')
         ctx.consumed = True
-        x, lens, gates, cs, hs, *w = ctx.saved_tensors
+        x, lens, gates, cs, hs, tsave, *w = ctx.saved_tensors
         S, N, I, H, xs_s, xs_n, ys_s, ys_n, batch_first = ctx.geom
         dy = _f32c(dy)
         dev = x.device
@@ -352,7 +356,7 @@ class _BiLSTM(torch.autograd.Function):
             check(lib.ssasr_bilstm_bwd_overlapped(
                 _p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens), _p(w[0]), _p(w[1]), _p(w[4]),
                 _p(w[5]), _p(gates), _p(cs), _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in sinks], _p(ws_t),
-                _p(ws_dc), _p(gx), _p(sync), int(armed), segments, _overlap_events(), _stream(),
+                _p(ws_dc), _p(gx), _p(sync), int(armed), _p(tsave), segments, _overlap_events(), _stream(),
                 C.c_void_p(side.cuda_stream)), 'ssasr_bilstm_bwd_overlapped')
             for t in (gates, x, hs):
                 t.record_stream(side)
@@ -361,7 +365,7 @@ class _BiLSTM(torch.autograd.Function):
         check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
                                    _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
-                                   _p(ws_dc), _p(gx), _p(sync), int(armed), _stream()), 'ssasr_bilstm_bwd')
+                                   _p(ws_dc), _p(gx), _p(sync), int(armed), _p(tsave), _stream()), 'ssasr_bilstm_bwd')
         # inputs: x, lens, steps, batch_first, sinks, then w_ih,w_hh,b_ih,b_hh per direction
         return (dx, None, None, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
                 dw[3], dw[4], dw[5], dw[5].clone())

@@ -43,7 +43,7 @@ def test_argument_errors_are_negative_and_need_no_gpu():
     from ss_asr_amd import _lib
     lib = _lib.load()
     assert lib.ssasr_bilstm_fwd(None, 0, 0, 0, 0, 0, 0, None, *([None] * 8), None, 0, 0, None,
-                                None, None, None, None, 0, None) < 0
+                                None, None, None, None, 0, None, None) < 0
     assert lib.ssasr_decoder_fwd(None, None) < 0
     assert lib.ssasr_clip_adadelta_ws(10269874) == 1 + (10269874 + 4095) // 4096
     # diagnostic switches: known names round-trip, unknown names are refused
