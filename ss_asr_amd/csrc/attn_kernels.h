@@ -520,17 +520,16 @@ __global__ __launch_bounds__(256) void attn_step_fwd_split_kernel(AttnSplit p) {
   ATTN_STAMP(5);
 }
 
-// rows per half-wave for (B, T): the choice that leaves the least work on the busiest CU
+// Rows per half-wave for (B, T): the LARGEST slice that still gives every CU a workgroup (fewer
+// slices = fewer records to exchange: at B = 32, T' = 375 slices of 16 / 24 / 32 / 48 rows took
+// 11.8 / 9.7 / 8.8 / 8.65 us, at T' = 188 6.8 / 6.2 / 6.7 / 6.4 us -- 48 rows leave half the CUs
+// idle there); when no slice size reaches 256 workgroups, the smallest (most workgroups).
 inline int attn_split_rph(int B, int T) {
-  int best = 4;
-  int64_t best_cost = -1;
-  for (int rph = 4; rph >= 2; --rph) {
-    const int R = 8 * rph;
-    const int64_t wgs = (int64_t)B * ((T + R - 1) / R);
-    const int64_t cost = ((wgs + 255) / 256) * R;
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rph; }
-  }
-  return best;
+  if (const int forced = ssasr_options().attn_rph) return forced;
+  const int sizes[4] = {6, 4, 3, 2};
+  for (int rph : sizes)
+    if ((int64_t)B * ((T + 8 * rph - 1) / (8 * rph)) >= 256) return rph;
+  return 2;
 }
 inline int attn_split_ns(int B, int T) { const int R = 8 * attn_split_rph(B, T); return (T + R - 1) / R; }
 // the split form is taken for T > 128 at A = 128, E = 512 when the caller provides its workspace

@@ -121,12 +121,14 @@ int launch_attn_fwd(const AttnFwd& p, hipStream_t st, float* ws = nullptr, int p
     const int rph = attn_split_rph(p.B, p.T);
     sp.NS = (p.T + 8 * rph - 1) / (8 * rph);
     const dim3 sgrid((unsigned)sp.NS, (unsigned)p.B);
-    const void* fn = rph == 4 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<4>)
+    const void* fn = rph == 6 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<6>)
+                   : rph == 4 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<4>)
                    : rph == 3 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<3>)
                               : reinterpret_cast<const void*>(attn_step_fwd_split_kernel<2>);
     // the workgroups of an utterance wait for each other: only when the whole grid is resident
     if (dec_grid_fits(fn, 256, 0, (int64_t)sp.NS * p.B)) {
-      if (rph == 4) hipLaunchKernelGGL(attn_step_fwd_split_kernel<4>, sgrid, block, 0, st, sp);
+      if (rph == 6) hipLaunchKernelGGL(attn_step_fwd_split_kernel<6>, sgrid, block, 0, st, sp);
+      else if (rph == 4) hipLaunchKernelGGL(attn_step_fwd_split_kernel<4>, sgrid, block, 0, st, sp);
       else if (rph == 3) hipLaunchKernelGGL(attn_step_fwd_split_kernel<3>, sgrid, block, 0, st, sp);
       else hipLaunchKernelGGL(attn_step_fwd_split_kernel<2>, sgrid, block, 0, st, sp);
       return SSASR_OK;

@@ -32,6 +32,8 @@ void init_options() {
   g_opt.delay_bwd_ksplit = g_opt.delay_bwd;
   g_opt.gemm_tile = env_int("SSASR_GEMM_TILE", 0);
   g_opt.no_residency_check = env_flag("SSASR_NO_RESIDENCY_CHECK");
+  g_opt.attn_rph = env_int("SSASR_ATTN_RPH", 0);
+  if (g_opt.attn_rph != 2 && g_opt.attn_rph != 3 && g_opt.attn_rph != 4 && g_opt.attn_rph != 6) g_opt.attn_rph = 0;
   g_opt.no_tsave = env_flag("SSASR_NO_TSAVE");
   g_opt.bptt_local = env_int("SSASR_BPTT_LOCAL", 0);     // measured slower inside the train step: rnn.hip
   g_opt.xcd_round_robin = -1;
@@ -52,6 +54,7 @@ const Named kNames[] = {
     {"SSASR_PERSIST_DELAY_BWD", &SsasrOptions::delay_bwd},
     {"SSASR_GEMM_TILE", &SsasrOptions::gemm_tile},
     {"SSASR_NO_RESIDENCY_CHECK", &SsasrOptions::no_residency_check},
+    {"SSASR_ATTN_RPH", &SsasrOptions::attn_rph},
     {"SSASR_NO_TSAVE", &SsasrOptions::no_tsave},
     {"SSASR_BPTT_LOCAL", &SsasrOptions::bptt_local},
     {"SSASR_XCD_ROUND_ROBIN", &SsasrOptions::xcd_round_robin},
