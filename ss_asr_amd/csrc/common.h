@@ -119,6 +119,7 @@ struct SsasrOptions {
   int delay_fwd, delay_bwd, delay_bwd_ksplit;   // SSASR_PERSIST_DELAY_FWD / _BWD (initial pacing, x 64 cycles; -1 = default)
   int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
   int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches
+  int test_drop_tile;             // SSASR_TEST_DROP_TILE (-1): fault injection, see EncPersist::drop_tile
   int attn_rph;                   // SSASR_ATTN_RPH: 0 model, 2 | 3 | 4 | 6 rows per half-wave of the split-T attention kernel
   int no_tsave;                   // SSASR_NO_TSAVE: saved gates / cell states row-major (in place) instead of tile-major
   int bptt_local;                 // SSASR_BPTT_LOCAL (0): XCD-local placement of the K-split BPTT when the probe allows it

@@ -136,7 +136,7 @@ __device__ __forceinline__ bool cb_fetch(u32x4 (&raw)[NV], F ld, int* status) {
     }
     if (!anybad) break;
     missed = true;
-    if (persist_give_up(tries, status)) break;
+    if (persist_give_up(tries, status, persist_code(PK_DEC_CHAIN, 0xfff))) break;
     __builtin_amdgcn_s_sleep(2);
   }
   return missed;

@@ -68,7 +68,7 @@ struct PdWaiter {
     if (threadIdx.x == 0 && !broken) {
       unsigned spins = 0;
       while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (persist_give_up(++spins, status)) { broken = true; break; }
+        if (persist_give_up(++spins, status, persist_code(PK_DEC_FWD, 0xfff))) { broken = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -96,7 +96,7 @@ __device__ __forceinline__ void pd_fetch(float4 (&b)[NV], F ld, int lo, int hi, 
         }
       }
       if (!anybad) break;
-      if (persist_give_up(tries, status)) break;
+      if (persist_give_up(tries, status, persist_code(PK_DEC_FWD, 0xfff))) break;
       __builtin_amdgcn_s_sleep(2);
     }
   }

@@ -32,6 +32,7 @@ void init_options() {
   g_opt.delay_bwd_ksplit = g_opt.delay_bwd;
   g_opt.gemm_tile = env_int("SSASR_GEMM_TILE", 0);
   g_opt.no_residency_check = env_flag("SSASR_NO_RESIDENCY_CHECK");
+  g_opt.test_drop_tile = env_int("SSASR_TEST_DROP_TILE", -1);
   g_opt.attn_rph = env_int("SSASR_ATTN_RPH", 0);
   if (g_opt.attn_rph != 2 && g_opt.attn_rph != 3 && g_opt.attn_rph != 4 && g_opt.attn_rph != 6) g_opt.attn_rph = 0;
   g_opt.no_tsave = env_flag("SSASR_NO_TSAVE");
@@ -54,6 +55,7 @@ const Named kNames[] = {
     {"SSASR_PERSIST_DELAY_BWD", &SsasrOptions::delay_bwd},
     {"SSASR_GEMM_TILE", &SsasrOptions::gemm_tile},
     {"SSASR_NO_RESIDENCY_CHECK", &SsasrOptions::no_residency_check},
+    {"SSASR_TEST_DROP_TILE", &SsasrOptions::test_drop_tile},
     {"SSASR_ATTN_RPH", &SsasrOptions::attn_rph},
     {"SSASR_NO_TSAVE", &SsasrOptions::no_tsave},
     {"SSASR_BPTT_LOCAL", &SsasrOptions::bptt_local},

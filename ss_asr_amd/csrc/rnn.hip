@@ -140,6 +140,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     if (fits) {
       EncPersist p{};
       p.tsave = tsave;
+      p.drop_tile = opt.test_drop_tile;
       p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
       p.x = x; p.xs_s = xs_s; p.xs_n = xs_n;
       for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }

@@ -373,6 +373,10 @@ struct EncPersist {
   const float* wih[2];   // [4H][I] per direction
   const float* bih[2];
   const float* bhh[2];
+  // Fault injection for tests (SSASR_TEST_DROP_TILE, -1 = off): unit tile `drop_tile` of direction 0,
+  // chunk 0 never publishes its h, so its consumers time out -- exercises the bounded spins, the
+  // latch and the status word (tests/test_gpu_kernels.py::test_a_missing_producer_times_out...).
+  int drop_tile;
   // Tile-major copy of what the BPTT streams back (activated gates i, f, g, o and the cell state):
   // [2][S][ceil(N/16)][H/16][5][4 unit quads][16 columns][4 units], i.e. 5 KB contiguous per BPTT workgroup and
   // step, whole 128-byte lines (tsave_index).  When given, the row-major `gates` / `cs` are NOT
@@ -451,14 +455,20 @@ constexpr unsigned PERSIST_MAX_SPINS = 1u << 20;   // ~ a second of polling, the
 constexpr unsigned PERSIST_SENTINEL = 0x7FC0DEADu;   // a NaN: h = o * tanh(c) can never produce it
 
 // Bounded spins with a latch.  True when this wave should stop waiting for a hand-off: either it
-// has itself retried PERSIST_MAX_SPINS times (it then sets the launch's status word), or -- looked
-// at on the 8th retry and every 256th after it, one sc1 load -- some wave of the launch already
-// has.  Without the latch every wave of every later step would spin out its own second: a launch
-// with ONE missing producer ran for minutes on NaN data; with it the launch drains in
-// milliseconds and the status word tells the host (ops.check_persistent_status / FusedAdadelta.poll).
-__device__ __forceinline__ bool persist_give_up(unsigned tries, int* status) {
+// has itself retried PERSIST_MAX_SPINS times (the first wave to do so records WHERE in the launch's
+// status word: persist_code), or -- looked at on the 8th retry and every 256th after it, one sc1
+// load -- some wave of the launch already has.  Without the latch every wave of every later step
+// would spin out its own second: a launch with ONE missing producer ran for minutes on NaN data
+// (ADVICE r1); with it the launch drains in milliseconds and the status word tells the host which
+// kernel, workgroup and step gave up first (ops.describe_status).
+enum { PK_ENC_FWD = 1, PK_ENC_BPTT = 2, PK_ENC_BPTT_GATHER = 3, PK_DEC_FWD = 4, PK_DEC_CHAIN = 5 };
+__device__ __forceinline__ int persist_code(int kernel, int step) {
+  const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  return (int)(0x40000000u | ((unsigned)kernel << 24) | ((wg & 0xfffu) << 12) | ((unsigned)step & 0xfffu));
+}
+__device__ __forceinline__ bool persist_give_up(unsigned tries, int* status, int code) {
   if (tries > PERSIST_MAX_SPINS) {
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0) atomicCAS(status, 0, code);       // the first failure stays on record
     return true;
   }
   return (tries & 255u) == 8u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
           const unsigned target = ntile * (unsigned)i;
           unsigned spins = 0;
           while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (persist_give_up(++spins, e.status)) break;
+            if (persist_give_up(++spins, e.status, persist_code(PK_ENC_FWD, i))) break;
             __builtin_amdgcn_s_sleep(1);
           }
         }
@@ -713,7 +723,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
             }
           }
           if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
-          if (persist_give_up(tries, e.status)) break;
+          if (persist_give_up(tries, e.status, persist_code(PK_ENC_FWD, i))) break;
           __builtin_amdgcn_s_sleep(2);
         }
       }
@@ -755,7 +765,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
     SSASR_PTRACE(i, 6);
     __syncthreads();                                  // epilogue done
     if (wave == 0) {
-      if (lane < 16 * NB && n0 + lane < Np) {
+      if (lane < 16 * NB && n0 + lane < Np && !(tile == e.drop_tile && d == 0 && chunk == 0)) {
         const float4 hv = n0 + lane < N ? *reinterpret_cast<const float4*>(sH + lane * 4)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         u32x4 pv = {__builtin_bit_cast(unsigned, hv.x), __builtin_bit_cast(unsigned, hv.y),
@@ -1036,7 +1046,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_persistent_kernel(EncPersist
           const unsigned target = ntile * (unsigned)i;
           unsigned spins = 0;
           while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (persist_give_up(++spins, e.status)) break;
+            if (persist_give_up(++spins, e.status, persist_code(PK_ENC_BPTT_GATHER, i))) break;
             __builtin_amdgcn_s_sleep(1);
           }
         }
@@ -1097,7 +1107,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_persistent_kernel(EncPersist
             }
           }
           if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
-          if (persist_give_up(tries, e.status)) break;
+          if (persist_give_up(tries, e.status, persist_code(PK_ENC_BPTT_GATHER, i))) break;
           __builtin_amdgcn_s_sleep(2);
         }
       }
@@ -1438,7 +1448,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
           }
         }
         if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
-        if (persist_give_up(tries, e.status)) break;
+        if (persist_give_up(tries, e.status, persist_code(PK_ENC_BPTT, i))) break;
         __builtin_amdgcn_s_sleep(2);
       }
       SSASR_PTRACE(i, 3);

@@ -16,6 +16,25 @@ from ._lib import check
 
 _persist_status = []     # int32[8] workspaces of persistent launches not yet checked
 TIMEOUT_MESSAGE = 'ss_asr_amd: a persistent recurrence / decode loop timed out'
+_KERNELS = {1: 'encoder forward recurrence', 2: 'encoder BPTT (K-split)', 3: 'encoder BPTT (gather)',
+            4: 'decode loop forward', 5: 'decoder backward chain'}
+
+
+def describe_status(words):
+    """Message for non-zero status words of persistent launches (csrc/rnn_kernels.h, persist_code):
+    which kernel, workgroup and step gave up waiting first."""
+    parts = []
+    for v in words:
+        v = int(v) & 0xffffffff
+        if v == 0:
+            continue
+        if v & 0x40000000:
+            step = v & 0xfff
+            parts.append('%s, workgroup %d, %s' % (_KERNELS.get((v >> 24) & 0x3f, 'kernel %d' % ((v >> 24) & 0x3f)),
+                                                    (v >> 12) & 0xfff, 'step %d' % step if step != 0xfff else 'step unknown'))
+        else:
+            parts.append('status %d' % v)
+    return TIMEOUT_MESSAGE + (' (' + '; '.join(parts) + ')' if parts else '')
 
 
 def check_persistent_status():
@@ -25,8 +44,10 @@ def check_persistent_status():
     synchronisation from the status row that travels with its optimizer statistics."""
     global _persist_status
     pending, _persist_status = _persist_status, []
-    if pending and any(int(v) for v in torch.stack([t[i] for t, i in pending]).cpu()):
-        raise RuntimeError(TIMEOUT_MESSAGE)
+    if pending:
+        words = torch.stack([t[i] for t, i in pending]).cpu().tolist()
+        if any(words):
+            raise RuntimeError(describe_status(words))
 
 
 _status_pools = {}

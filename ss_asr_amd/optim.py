@@ -101,6 +101,7 @@ class FusedAdadelta(torch.optim.Optimizer):
         elif not self._pending.query():
             return None
         self._pending = None
-        if self._host_words[2:].view(torch.int32).any():
-            raise RuntimeError(ops.TIMEOUT_MESSAGE)
+        status = self._host_words[2:].view(torch.int32)
+        if status.any():
+            raise RuntimeError(ops.describe_status(status.tolist()))
         return float(self._host_words[0]), bool(self._host_words[1] != 0)

@@ -178,6 +178,35 @@ def test_bilstm_sequence_major_no_lengths():
         close(a.grad, b.grad, 2e-4, 'dw')
 
 
+def test_a_missing_producer_times_out_drains_and_is_reported():
+    """Fault injection (SSASR_TEST_DROP_TILE): one unit tile of the persistent forward recurrence
+    never publishes its h.  Its consumers must give up after their bounded spins, the rest of the
+    launch must drain through the latch instead of spinning out every later step (32 steps here:
+    seconds, not minutes), and the status word must say which kernel and step gave up first."""
+    import time
+    from ss_asr_amd import _lib, ops
+    N, S, I, H = 8, 32, 64, 256
+    x = rnd(N, S, I, seed=81).float().to(dev())
+    w = [t.float().to(dev()) for t in lstm_weights(I, H, 82)]
+    ops.check_persistent_status()
+    old = _lib.set_option('SSASR_TEST_DROP_TILE', 5)
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.bilstm(x, None, S, True, w)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:
+        _lib.set_option('SSASR_TEST_DROP_TILE', old)
+    with pytest.raises(RuntimeError, match='encoder forward recurrence.*step 1'):
+        ops.check_persistent_status()
+    assert elapsed < 20.0, elapsed
+    # and the next launch is healthy again
+    y = ops.bilstm(x, None, S, True, w)
+    ops.check_persistent_status()
+    assert bool(torch.isfinite(y).all())
+
+
 # ------------------------------------------------------------ attention ----
 @pytest.mark.parametrize('B,T,A,E,D,lens', [
     (4, 8, 16, 64, 32, [8, 7, 6, 5]),

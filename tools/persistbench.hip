@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
   EncPersist pf{};
   pf.whh[0] = whh; pf.whh[1] = whh + 4 * H * H; pf.gates = gates; pf.cs = cs; pf.hs = hs; pf.hx = hx; pf.y = y;
   pf.delay = getenv("DELAY_F") ? atoi(getenv("DELAY_F")) : 24; pf.lens = nullptr; pf.cnt = (unsigned*)sync; pf.status = sync + 4;
-  pf.ys_s = (int)ys_s; pf.ys_n = (int)ys_n; pf.S = (int)S; pf.N = (int)N; pf.H = (int)H;
+  pf.ys_s = (int)ys_s; pf.ys_n = (int)ys_n; pf.S = (int)S; pf.N = (int)N; pf.H = (int)H; pf.drop_tile = -1;
   EncPersistBwd pb{};
   pb.whhT = whhT; pb.gates = gates; pb.cs = cs; pb.dy = dy; pb.gx = gx; pb.lens = nullptr;
   pb.cnt = (unsigned*)sync; pb.status = sync + 4; pb.delay = getenv("DELAY_B") ? atoi(getenv("DELAY_B")) : 16;
