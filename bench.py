@@ -423,13 +423,14 @@ def main():
         bptt, fwd_rec = recurrence_roofline(device)
         note('BPTT recurrence: %s' % bptt)
         note('forward recurrence: %s' % fwd_rec)
-        traffic = os.path.join(ROOT, 'profiles', 'r01_traffic.json')    # rocprofv3 --pmc passes, see profiles/README.md
+        traffic = os.path.join(ROOT, 'profiles', 'r02_traffic.json')    # rocprofv3 --pmc passes, see profiles/README.md
         if os.path.exists(traffic):
             with open(traffic) as f:
                 t = json.load(f)
             bptt['traffic'] = t.get('bptt_bytes_per_launch')
             fwd_rec['traffic'] = t.get('fwd_bytes_per_launch')
             att['at_training_shape']['traffic'] = t.get('attention_bytes_per_launch')
+            att['traffic'] = t.get('attention_split_bytes_per_launch')
         out['roofline'] = bptt                       # dominant kernel of the step (profiles/)
         out['roofline_forward_recurrence'] = fwd_rec
         out['roofline_attention'] = att

@@ -6,7 +6,7 @@ one pass):
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE  --kernel-trace --output-format csv -d out_f -- python3 tools/pmc_layer.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_w -- python3 tools/pmc_layer.py
-    python3 tools/pmc_to_json.py out_f out_w > profiles/r01_traffic.json
+    python3 tools/pmc_to_json.py out_f out_w > profiles/r02_traffic.json
 """
 import os
 import sys
@@ -16,5 +16,6 @@ import bench
 
 dev = torch.device('cuda', 0)
 bench.recurrence_roofline(dev, reps=int(os.environ.get('SSASR_ROOFLINE_REPS', '1')))   # 5 = what bench.py times
-bench.attention_roofline(dev, iters=4)
+bench.attention_roofline(dev, T=375, iters=4)      # split-T kernel (BASELINE configs[3]'s longest encoder output)
+bench.attention_roofline(dev, T=100, iters=4)      # the training shape
 torch.cuda.synchronize()

@@ -8,7 +8,7 @@ import sys
 
 src, tag, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-stats = glob.glob(os.path.join(src, '*', '*_kernel_stats.csv'))[0]
+stats = max(glob.glob(os.path.join(src, '*', '*_kernel_stats.csv')), key=os.path.getmtime)     # the newest run in the directory
 rows = list(csv.DictReader(open(stats)))
 out_csv = os.path.join(root, 'profiles', tag + '_kernel_stats.csv')
 with open(out_csv, 'w', newline='') as f:
