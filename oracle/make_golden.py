@@ -253,5 +253,19 @@ def main(only=None):
                 xy=(x, y), recipe=dict(n_batches=8, pick=pick, batch_size=32, corpus_seed=1))
 
 
+def long_fixture(asr_mod):
+    """BASELINE.json configs[3]'s shape at full size (32 utterances of 1500-3000 frames, 150-300
+    characters; attention loss only -- the reference has no CTC): T' = 375, ~300 decode steps."""
+    from ss_asr_amd.synthetic import config4_batch
+    x, y, lens = config4_batch()
+    ylens = [int(v) - 1 for v in (y != 0).sum(-1)]
+    capture(asr_mod, 'long_b32_t3000', (50, 256, 256, 128, 80), lens, ylens, 1.0, 10, weights_seed=16,
+            keep='compact', xy=(x, y), recipe=dict(config4=1, batch_size=32, seed=4))
+
+
 if __name__ == '__main__':
-    main(set(sys.argv[1:]))         # optional: names of the fixtures to (re)generate
+    if sys.argv[1:] == ['long_b32_t3000']:       # minutes of reference CPU time: only on request
+        sys.path.insert(0, os.path.dirname(HERE))
+        long_fixture(import_reference())
+    else:
+        main(set(sys.argv[1:]))     # optional: names of the fixtures to (re)generate

@@ -49,3 +49,13 @@ def config2_batches(n_batches, batch_size=32, feat_dim=80, n_utts=8000, seed=1, 
         out.append(make_batch(frames[sl], chars[sl], feat_dim, seed * 1000 + j + 100000 * rank,
                               device))
     return out
+
+
+def config4_batch(batch_size=32, feat_dim=80, seed=4, lo=1500, hi=3000):
+    """One batch of BASELINE.json configs[3]'s shape: frame lengths U{lo..hi} sorted
+    descending with the longest at `hi`, characters U{lo/10..hi/10}."""
+    rng = np.random.default_rng(seed)
+    frames = np.sort(rng.integers(lo, hi + 1, size=batch_size))[::-1].copy()
+    frames[0] = hi
+    chars = rng.integers(lo // 10, hi // 10 + 1, size=batch_size)
+    return make_batch(frames, chars, feat_dim, seed * 1000 + 7)

@@ -43,6 +43,13 @@ def fixture_xy(fx):
     import torch
     if 'x' in fx.files:
         return torch.from_numpy(fx['x']), torch.from_numpy(fx['y'])
+    if 'recipe_config4' in fx.files:
+        from ss_asr_amd.synthetic import config4_batch
+        x, y, lens = config4_batch(batch_size=int(fx['recipe_batch_size']), feat_dim=int(fx['dims'][4]),
+                                   seed=int(fx['recipe_seed']))
+        assert lens == [int(v) for v in fx['lens']] and np.array_equal(y.numpy(), fx['y'])
+        assert abs(float(x.double().abs().sum()) - float(fx['x_abs_sum'])) < 1e-6 * float(fx['x_abs_sum'])
+        return x, y
     from ss_asr_amd.synthetic import config2_batches
     x, y, lens = config2_batches(int(fx['recipe_n_batches']), batch_size=int(fx['recipe_batch_size']),
                                  feat_dim=int(fx['dims'][4]), seed=int(fx['recipe_corpus_seed']))[int(fx['recipe_pick'])]

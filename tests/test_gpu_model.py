@@ -17,6 +17,10 @@ pytestmark = pytest.mark.gpu
 # BASELINE.json configs[1] at its own size: bench.py's longest (32 x 800 frames, 81 label steps:
 # four BPTT segments, two-chunk recurrences, the 32-utterance persistent decode loop) and median bucket
 BENCH_SHAPES = ['bench_b32_t800', 'bench_b32_median']
+# BASELINE.json configs[3]'s shape at full size (attention loss only: the reference has no CTC): 32
+# utterances of 1500-3000 frames, T' = 375 (split-T attention inside the per-step decode loop, ~300
+# decode steps), 3000 / 1500 / 750 persistent recurrence steps with the exchange ring wrapping ~370 times
+LONG_SHAPES = ['long_b32_t3000']
 
 
 def build(fx):
@@ -48,7 +52,7 @@ def forward(fx, model):
 
 
 @pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'small_greedy',
-                                  'full_b4', 'full_b16_t400'] + BENCH_SHAPES)
+                                  'full_b4', 'full_b16_t400'] + BENCH_SHAPES + LONG_SHAPES)
 def test_forward_matches_reference(golden, name):
     fx = golden(name)
     model = build(fx)
@@ -76,7 +80,7 @@ def test_forward_matches_reference(golden, name):
 
 
 @pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'full_b4',
-                                  'full_b16_t400'] + BENCH_SHAPES)
+                                  'full_b16_t400'] + BENCH_SHAPES + LONG_SHAPES)
 def test_backward_and_solver_step_match_reference(golden, name):
     from ss_asr_amd.optim import FlatParameters, FusedAdadelta
     fx = golden(name)

@@ -10,7 +10,7 @@ import las_oracle as lo
 from conftest import fixture_att, fixture_xy
 
 CASES = ['small_tf1', 'small_odd', 'small_padded', 'small_greedy', 'small_sampled',
-         'full_b4', 'bench_b32_t800', 'bench_b32_median']
+         'full_b4', 'bench_b32_t800', 'bench_b32_median', 'long_b32_t3000']
 
 
 def build(fx):

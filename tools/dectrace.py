@@ -50,3 +50,14 @@ print('per step, medians over steps (us): last h1 publish -> last phi q seen by 
       'last ctx published -> last compute saw ctx %.2f; saw ctx -> last h1 published %.2f' % (
           np.median((a1.max(0)[1:] - c6.max(0)[:-1])) * 0.01, np.median(a4.max(0) - a1.max(0)) * 0.01,
           np.median(c4.max(0) - a4.max(0)) * 0.01, np.median(c6.max(0) - c4.max(0)) * 0.01))
+
+# start-up and wind-down: first stamp of every role's step 0 against the earliest stamp in the launch, the
+# first steps' periods, and the last stamp against the last step's start
+first = tr[:, 0, 0]
+t_begin = first[first > 0].min()
+print('loop entry after the earliest stamp (us): attention median %.1f max %.1f; compute median %.1f max %.1f' % (
+    np.median(tr[0:64, 0, 0] - t_begin) * 0.01, (tr[0:64, 0, 0] - t_begin).max() * 0.01,
+    np.median(tr[64:192, 0, 0] - t_begin) * 0.01, (tr[64:192, 0, 0] - t_begin).max() * 0.01))
+per0 = (tr[64:192, 1:9, 0] - tr[64:192, 0:8, 0]) * 0.01
+print('compute workgroups, period of steps 0..7 (us): ' + ' '.join('%.2f' % np.median(per0[:, k]) for k in range(8)))
+print('whole loop by the stamps (us): %.1f for %d steps' % ((tr[64:192, U - 1, 6].max() - t_begin) * 0.01, U))
