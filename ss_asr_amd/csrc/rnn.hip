@@ -237,7 +237,8 @@ extern "C" int64_t ssasr_bilstm_bwd_ring_floats(int64_t S, int64_t N, int64_t H,
 }
 
 // the K-split kernel instance for H (and halves), for the residency check and the launch
-static const void* bptt_rs_fn(int kpw, bool halves) {
+static const void* bptt_rs_fn(int kpw, bool halves, int nw = 4) {
+  (void)nw;
   if (kpw == 4) return reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<1, 1>);
   if (kpw == 8) return halves ? reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 2>)
                               : reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 1>);
@@ -259,7 +260,9 @@ bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
         !opt.persistent_counter && !opt.bptt_gather && !opt.no_persistent))
     return false;
   // every workgroup of the one-per-(tile, chunk) grid must be resident (the two-halves grid is checked at launch)
-  return grid_fits(bptt_rs_fn((int)(H / 16), false), 320, (size_t)opt.bptt_reserve_kb * 1024, (H / 16) * dirs * chunks);
+  const int nw = 4;
+  return grid_fits(bptt_rs_fn((int)(H / 16), false, nw), 64 * (nw + 1), (size_t)opt.bptt_reserve_kb * 1024,
+                   (H / 16) * dirs * chunks);
 }
 
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
@@ -296,9 +299,15 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     const int reserve = opt.bptt_reserve_kb * 1024;
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
     // (not for launches of fewer than three steps: see the note on in-place rows in rnn_kernels.h)
+    // (Eight recurrence waves per workgroup -- two partial tiles loaded and one unit tile multiplied per
+    // wave instead of four and two: lstm_enc_bwd_rs_kernel<4, HV, 8> -- measured the same alone (2.35
+    // against 2.33 us per step) and 0.5 % slower in the train step; not instantiated.)
+    const int nw = 4;                                                     // recurrence waves per workgroup (+ 1 helper)
+    pblock = dim3((unsigned)(64 * (nw + 1)));
     const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && i1 - i0 >= 3 && !opt.bptt_halves_off &&
-                        grid_fits(bptt_rs_fn(kpw, true), 320, (size_t)reserve, (H / 16) * dirs * chunks * 2);
-    if (!halves && !grid_fits(bptt_rs_fn(kpw, false), 320, (size_t)reserve, (H / 16) * dirs * chunks)) return SSASR_EARG;
+                        grid_fits(bptt_rs_fn(kpw, true, nw), 64 * (nw + 1), (size_t)reserve, (H / 16) * dirs * chunks * 2);
+    if (!halves && !grid_fits(bptt_rs_fn(kpw, false, nw), 64 * (nw + 1), (size_t)reserve, (H / 16) * dirs * chunks))
+      return SSASR_EARG;
     if (i0 == 0 && !armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
     if (halves) pgrid.z *= 2;
     // XCD-local placement (rnn_kernels.h, persist_role; OFF by default, SSASR_BPTT_LOCAL=1): the <= 4
@@ -334,7 +343,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // its standalone speed (+4-5 % on the train step).  SSASR_BPTT_SHARED_CU=1 turns it off.
     // (the attribute is a property of the loaded code object: setting it again is idempotent and costs
     // no device work)
-    if (reserve) SSASR_HIP(hipFuncSetAttribute(bptt_rs_fn(kpw, halves), hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
+    if (reserve) SSASR_HIP(hipFuncSetAttribute(bptt_rs_fn(kpw, halves, nw), hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, reserve_now, st, p);
     else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, reserve_now, st, p);
     else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, reserve_now, st, p);

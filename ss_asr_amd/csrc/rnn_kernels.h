@@ -1294,13 +1294,18 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
 // other half may not have started): half 0 keeps their rows in LDS and writes
 // them during the third step.  A launch of fewer than three steps must not use
 // HV = 2 (the launcher falls back to HV = 1).
-template <int TPW, int HV>   // TPW = unit tiles per wave = (H / 16) / 4; grid.z = chunks * HV
-__global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
+// NW = recurrence waves (4, or 8 for H = 256: each wave then loads 2 instead of 4 partial tiles and
+// multiplies into 1 instead of 2 unit tiles -- the product is issue bound, 32 cycles per MFMA);
+// the helper wave is wave NW: 64 * (NW + 1) threads.
+template <int TPW, int HV, int NW = 4>   // TPW = (H / 16) / 4; grid.z = chunks * HV
+__global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   if (SSASR_PERSIST_PRIO) __builtin_amdgcn_s_setprio(SSASR_PERSIST_PRIO);
-  constexpr int OT = TPW / HV;                  // product tiles per wave
+  constexpr int T = 4 * TPW;                    // unit tiles = H / 16
+  constexpr int SPW = T / NW;                   // source tiles loaded per wave
+  constexpr int OT = (T / HV) / NW;             // product tiles per wave
   constexpr int LAG = HV >= 2 ? 3 : 1;          // steps between consuming a slot and re-arming it
-  static_assert(TPW % HV == 0 && LAG + 2 <= BWD_RS_RING, "ring too short");
-  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
+  static_assert(TPW % HV == 0 && (T / HV) % NW == 0 && T % NW == 0 && OT >= 1 && LAG + 2 <= BWD_RS_RING, "ring too short");
+  __shared__ __attribute__((aligned(16))) f32x4 red[NW * 64];
   __shared__ __attribute__((aligned(16))) float4 coef[3][7][64];   // [step % 3][A, O, I, G, F, C, dy][lane]
   constexpr int NG = HV >= 2 ? 3 : 1;           // steps of gate derivatives kept in LDS
   __shared__ __attribute__((aligned(16))) float4 sG[NG][4][64];    // gate derivatives: [step % NG][gate][lane (q, r)]
@@ -1319,7 +1324,6 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   const bool inplace = e.tsave == nullptr;
   const int S = e.S, N = e.N, H = e.H;
   const int i0 = e.i0, i1 = e.i1 > 0 ? e.i1 : S;    // this launch's iterations
-  constexpr int T = 4 * TPW;                    // unit tiles = H / 16
   const int n0 = chunk * 16;
   const int64_t rows = (int64_t)S * N;
   const int u0 = 16 * tile + 4 * q;             // lane (q, r) of waves 0 and 4: units u0..u0+3 of column n
@@ -1335,7 +1339,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   const __amdgpu_buffer_rsrc_t xrs =
       __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)(BWD_RS_RING * SLOT_B), 0x00020000);
 
-  if (wave == 4) {
+  if (wave == NW) {
     // ------------------------------ helper wave ------------------------------
     const int len = (col_ok && e.lens) ? e.lens[n] : 0x7fffffff;
     // (Fetching TWO steps ahead of the use, from two register sets with a counted wait that leaves
@@ -1429,21 +1433,21 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
     if (i > 0) {
       __syncthreads();      // released by the helper wave
       SSASR_PTRACE(i, 2);
-      // partial tiles for this workgroup's units from sources TPW*wave .. (+TPW)
+      // partial tiles for this workgroup's units from sources SPW*wave .. (+SPW)
       const unsigned base = (unsigned)((i - 1) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
-      u32x4 raw[TPW];
+      u32x4 raw[SPW];
 #pragma unroll
-      for (int t = 0; t < TPW; ++t)
-        raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((TPW * wave + t) * TILE_B + lane * 16), (int)base, 16);
+      for (int t = 0; t < SPW; ++t)
+        raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((SPW * wave + t) * TILE_B + lane * 16), (int)base, 16);
       for (unsigned tries = 0;; ++tries) {
         bool anybad = false;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
+        for (int t = 0; t < SPW; ++t) {
           const bool bad = raw[t].x == PERSIST_SENTINEL || raw[t].y == PERSIST_SENTINEL ||
                            raw[t].z == PERSIST_SENTINEL || raw[t].w == PERSIST_SENTINEL;
           if (__any(bad)) {
             anybad = true;
-            raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((TPW * wave + t) * TILE_B + lane * 16),
+            raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((SPW * wave + t) * TILE_B + lane * 16),
                                                            (int)base, 16);
           }
         }
@@ -1453,7 +1457,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       }
       SSASR_PTRACE(i, 3);
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) part += __builtin_bit_cast(f32x4, raw[t]);
+      for (int t = 0; t < SPW; ++t) part += __builtin_bit_cast(f32x4, raw[t]);
     }
     red[wave * 64 + lane] = part;
     SSASR_PTRACE(i, 4);
@@ -1468,7 +1472,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
                      cC = c[5 * 64], ad1 = c[6 * 64];
         f32x4 dhv = red[lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) dhv += red[w * 64 + lane];
+        for (int w = 1; w < NW; ++w) dhv += red[w * 64 + lane];
         const float kA[4] = {cA.x, cA.y, cA.z, cA.w}, kO[4] = {cO.x, cO.y, cO.z, cO.w};
         const float kI[4] = {cI.x, cI.y, cI.z, cI.w}, kG[4] = {cG.x, cG.y, cG.z, cG.w};
         const float kF[4] = {cF.x, cF.y, cF.z, cF.w}, kC[4] = {cC.x, cC.y, cC.z, cC.w};
