@@ -309,7 +309,12 @@ def self_launch(args):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     note('starting %d ranks: %s' % (args.gpus, ' '.join(cmd)))
-    return subprocess.call(cmd)
+    # stdout carries ONE JSON line (rank 0's); anything else the ranks' libraries print there goes to stderr
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.startswith('{') else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
