@@ -25,6 +25,7 @@ class ASRTrainStep:
         self._grads_clean = False      # True right after a step that zeroed them in its update kernel
         self.last_logits = None        # [B, U, V] of the most recent step (for the trainer's logging)
         self.last_done = None          # (grad_norm, skipped) of the last step whose words have arrived
+        self.skipped_steps = 0         # steps whose update was skipped because the gradient norm was NaN
 
     def forward_loss(self, x, y, x_lens, ans_len):
         _, logits, att = self.model(x, ans_len, teacher=y, state_len=x_lens)
@@ -38,9 +39,7 @@ class ASRTrainStep:
         The verdict of the PREVIOUS step (gradient norm, NaN skip, and whether one of its
         persistent launches timed out) is picked up here when its words have reached the host
         -- no synchronisation; a timeout raises."""
-        done = self.optim.poll()
-        if done is not None:
-            self.last_done = done
+        self._note(self.optim.poll())
         if not self._grads_clean:
             self.optim.zero_grad()
         self._grads_clean = False
@@ -59,11 +58,14 @@ class ASRTrainStep:
         self._grads_clean = True
         return loss
 
-    def finish(self):
-        """Waits for the last step's words: returns its (grad_norm, skipped); raises on a timeout."""
-        done = self.optim.poll(wait=True)
+    def _note(self, done):
         if done is not None:
             self.last_done = done
+            self.skipped_steps += int(done[1])
+
+    def finish(self):
+        """Waits for the last step's words: returns its (grad_norm, skipped); raises on a timeout."""
+        self._note(self.optim.poll(wait=True))
         return self.last_done
 
 

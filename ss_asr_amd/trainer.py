@@ -209,6 +209,7 @@ class ASRTrainer(Solver):
 
     def exec(self):
         self.verbose('Training set total {} batches'.format(len(self.train_set)))
+        self._nan_reported = self.train_step.skipped_steps if self.train_step is not None else 0
         epoch = 0
         while epoch < self.n_epochs:
             self.verbose("Starting epoch {} out of {}".format(epoch + 1, self.n_epochs))
@@ -221,11 +222,10 @@ class ASRTrainer(Solver):
                 if self.train_step is not None:
                     # src/trainer.py:419-438 as one fused step; a persistent launch that timed out
                     # in the previous step raises here (its status words arrive with the optimizer's)
-                    before = self.train_step.last_done
                     loss = self.train_step(x, y, state_len, ans_len)
                     prediction = self.train_step.last_logits
-                    done = self.train_step.last_done
-                    if done is not before and done is not None and done[1]:
+                    if self.train_step.skipped_steps > self._nan_reported:
+                        self._nan_reported = self.train_step.skipped_steps
                         self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
                 else:
                     self.optim.zero_grad()
@@ -245,6 +245,8 @@ class ASRTrainer(Solver):
                                        calc_err(prediction, label, mapper=self.mapper),
                                        self.tr.step)
                     if self.tr.step % self.save_step == 0:
+                        if self.train_step is not None:
+                            self.train_step.finish()   # this step's verdict first: never checkpoint after a time-out
                         self.verbose("Model saved at step {}".format(self.tr.step))
                         torch.save(self.asr_model.state_dict(), self.ckppath)
                 if self.tr.step % self.valid_step == 0:
@@ -308,5 +310,7 @@ class ASRTrainer(Solver):
     def close(self):
         self.verbose("Finished training! The most recent model will" +
                      "be saved at step {}".format(self.tr.step))
+        if getattr(self, 'train_step', None) is not None:
+            self.train_step.finish()
         if self.rank == 0:
             torch.save(self.asr_model.state_dict(), self.ckppath)
