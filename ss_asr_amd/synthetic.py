@@ -38,8 +38,11 @@ def make_batch(frames, chars, feat_dim, seed, device='cpu', pad_to=None):
 def config2_batches(n_batches, batch_size=32, feat_dim=80, n_utts=8000, seed=1, device='cpu',
                     rank=0, hi=800):
     """`n_batches` batches spread evenly over the length-sorted ~10 h corpus of
-    BASELINE.json configs[1] (8,000 utterances, <= 800 frames)."""
-    frames, chars = corpus_lengths(n_utts, seed + 7919 * rank, hi=hi, lo=min(100, hi),
+    BASELINE.json configs[1] (8,000 utterances, <= 800 frames).  Ranks of a data-parallel run
+    hold replicas of that corpus (configs[2]: "same corpus replicated x8"): the same utterance
+    lengths and bucket picks on every rank -- so that no rank waits in the gradient all-reduce
+    for one that drew longer utterances -- with rank-specific frame and label values."""
+    frames, chars = corpus_lengths(n_utts, seed, hi=hi, lo=min(100, hi),
                                    mean=min(450.0, hi * 0.5625))
     total = n_utts // batch_size
     picks = np.linspace(0, total - 1, n_batches).astype(int)
