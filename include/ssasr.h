@@ -323,6 +323,27 @@ int ssasr_ce_loss_fwd(const float* logits, const int32_t* y, int64_t y_ld, int64
 int ssasr_ce_loss_bwd(const float* logits, const int32_t* y, int64_t y_ld, const float* lse,
                       const float* dloss, int64_t B, int64_t U, int64_t V, float* dlogits, void* stream);
 
+/* CTC negative log likelihood over the Listener's frames: the auxiliary branch of
+ * BASELINE.json configs[3] ("Joint CTC+attention loss").  BUILD-DEFINED -- the reference
+ * has no CTC (its only loss is src/trainer.py:426-434), so this replaces no reference
+ * interface; the semantics are torch.nn.functional.ctc_loss(log_softmax(logits), labels,
+ * frame_lens, label_lens, blank, reduction='mean', zero_infinity=True).
+ * logits [B][T][V] (log-softmax is taken inside); frame_lens / label_lens int32 [B];
+ * label j of row b is y[b * y_ld + j] (pass y + 1 to skip the <sos> column of prepare_y's
+ * matrix); Lmax >= every label length, 2 * Lmax + 1 <= 1024; blank is a class no label uses.
+ * ws: ssasr_ctc_ws_floats(B, T, V, Lmax) floats, 8-byte aligned (alpha lattice and per-row
+ * nll, held in double), written by _fwd and read by _bwd.  loss = mean_b(nll_b / max(label_len_b, 1)), rows with no
+ * alignment counting 0.  _bwd writes dlogits [B][T][V] (zero past frame_lens) and, when
+ * dbias is given, ADDS sum_{b,t} dlogits[b][t][:] to dbias [V]. */
+int64_t ssasr_ctc_ws_floats(int64_t B, int64_t T, int64_t V, int64_t Lmax);
+int ssasr_ctc_loss_fwd(const float* logits, const int32_t* frame_lens, const int32_t* y, int64_t y_ld,
+                       const int32_t* label_lens, int64_t B, int64_t T, int64_t V, int64_t Lmax,
+                       int blank, float* ws, float* loss, void* stream);
+int ssasr_ctc_loss_bwd(const float* logits, const int32_t* frame_lens, const int32_t* y, int64_t y_ld,
+                       const int32_t* label_lens, int64_t B, int64_t T, int64_t V, int64_t Lmax,
+                       int blank, float* ws, const float* dloss, float* dlogits, float* dbias,
+                       void* stream);
+
 /* Solver.step (src/trainer.py:131-148) with torch.optim.Adadelta
  * (src/trainer.py:401-403) on flat buffers of n floats: total L2 norm of
  * grad * grad_scale, NaN guard, clip to max_norm, Adadelta update.

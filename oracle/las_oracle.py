@@ -300,6 +300,33 @@ def train_step(model, optim, x, y):
     return float(loss.detach()), norm
 
 
+def ctc_branch_loss(model, head, x, y, lens, blank=0):
+    """CTC branch of BASELINE.json configs[3].  BUILD-DEFINED (the reference has no CTC,
+    SURVEY.md section 1; parity unpinned by the reference): the checker SURVEY.md 8(c) names,
+    torch's ctc_loss, on this oracle's Listener: Linear head on the encoder output, the
+    characters between <sos> and <eos> as labels, blank = class 0."""
+    feat, enc_len = model.encoder(x, lens)
+    lp = F.log_softmax(head(feat), dim=-1).transpose(0, 1)                 # [T', B, V]
+    label_lens = ((y != 0).sum(-1) - 1).clamp(min=0)
+    return F.ctc_loss(lp, y[:, 1:], torch.tensor([int(v) for v in enc_len]), label_lens, blank=blank,
+                      reduction='mean', zero_infinity=True)
+
+
+def joint_train_step(model, head, optim, x, y, ctc_weight):
+    """train_step with loss = ctc_weight * ctc + (1 - ctc_weight) * masked CE; optim holds the
+    model's parameters followed by the head's.  Returns (loss, attention loss, ctc loss)."""
+    lens = frame_lengths(x)
+    ans_len = max(label_lengths(y)) - 1
+    optim.zero_grad()
+    _, logits, _ = model(x, ans_len, teacher=y, state_len=lens)
+    att = masked_ce_loss(logits, y, ans_len)
+    ctc = ctc_branch_loss(model, head, x, y, lens)
+    loss = ctc_weight * ctc + (1.0 - ctc_weight) * att
+    loss.backward()
+    solver_step(list(model.parameters()) + list(head.parameters()), optim)
+    return float(loss.detach()), float(att.detach()), float(ctc.detach())
+
+
 def make_optimizer(model):
     """src/trainer.py:401-403 with conf/default.yaml:2-4."""
     return torch.optim.Adadelta(model.parameters(), lr=1.0, eps=1e-8)

@@ -246,6 +246,7 @@ class ASR(nn.Module):
         self.att_on_host = True
         self.att_event = None
         self.last_chars = self.last_modes = self.last_uniforms = None
+        self.last_encoded = None
         self.init_parameters()
 
     def init_parameters(self):
@@ -291,6 +292,8 @@ class ASR(nn.Module):
                                         A=self.attention.phi.weight.shape[0], E=self.encoder.out_dim,
                                         D=self.decoder.state_size, V=self.char_trans.weight.shape[0])
         encode_feature, encode_len = self.encoder(audio_feature, state_len, len_devs=(l1, l2, l3), arenas=arenas)
+        # what a second head on the encoder (ss_asr_amd/ctc.py) reads: output and its int32 frame counts
+        self.last_encoded = (encode_feature, enc_len_dev)
         self.decoder.init_rnn(encode_feature.shape[0], dev)
         self.attention.reset_enc_mem()
         uniforms = None

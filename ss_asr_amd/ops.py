@@ -829,6 +829,97 @@ def masked_ce_loss(logits, y, ans_len):
 
 
 # ---------------------------------------------------------------------------
+# CTC branch (build-defined: the reference has no CTC; checker = torch's ctc_loss)
+# ---------------------------------------------------------------------------
+def _ctc_geometry(logits, y32, lmax):
+    B, T, V = logits.shape
+    if y32.dtype != torch.int32 or y32.stride(-1) != 1:
+        raise TypeError('ctc: labels must be int32 with unit column stride')
+    if lmax > y32.shape[1]:
+        raise ValueError('ctc: Lmax exceeds the label matrix')
+    n = _lib.load().ssasr_ctc_ws_floats(B, T, V, lmax)
+    if n <= 0:
+        raise ValueError('ctc: shape B=%d T=%d V=%d Lmax=%d has no kernel' % (B, T, V, lmax))
+    return B, T, V, n
+
+
+def _ctc_fwd(logits, frame_lens, y32, label_lens, lmax, blank):
+    lib = _lib.load()
+    B, T, V, n = _ctc_geometry(logits, y32, lmax)
+    ws = torch.empty(n, device=logits.device, dtype=torch.float32)
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    check(lib.ssasr_ctc_loss_fwd(_p(logits), _p(frame_lens), _p(y32), y32.stride(0), _p(label_lens), B, T, V,
+                                 lmax, blank, _p(ws), _p(loss), _stream()), 'ssasr_ctc_loss_fwd')
+    return loss, ws
+
+
+def _ctc_bwd(logits, frame_lens, y32, label_lens, lmax, blank, ws, dloss, dbias=None):
+    lib = _lib.load()
+    B, T, V = logits.shape
+    dlogits = torch.empty_like(logits)
+    dloss = dloss.to(torch.float32).contiguous()
+    check(lib.ssasr_ctc_loss_bwd(_p(logits), _p(frame_lens), _p(y32), y32.stride(0), _p(label_lens), B, T, V,
+                                 lmax, blank, _p(ws), _p(dloss), _p(dlogits), _p(dbias), _stream()),
+          'ssasr_ctc_loss_bwd')
+    return dlogits
+
+
+class _CTCLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, frame_lens, y32, label_lens, lmax, blank):
+        _need_gpu(logits, frame_lens, y32, label_lens)
+        logits = _f32c(logits)
+        loss, ws = _ctc_fwd(logits, frame_lens, y32, label_lens, lmax, blank)
+        ctx.save_for_backward(logits, frame_lens, y32, label_lens, ws)
+        ctx.geom = (lmax, blank)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, frame_lens, y32, label_lens, ws = ctx.saved_tensors
+        return (_ctc_bwd(logits, frame_lens, y32, label_lens, *ctx.geom, ws, dloss),) + (None,) * 5
+
+
+class _CTCHead(torch.autograd.Function):
+    """Linear(E -> V) on the Listener's output + CTC in one node: the bias gradient comes out of
+    the CTC backward kernel, the two other products are GEMMs."""
+
+    @staticmethod
+    def forward(ctx, feat, w, b, frame_lens, y32, label_lens, lmax, blank):
+        _need_gpu(feat, w, b, frame_lens, y32, label_lens)
+        feat, w, b = _f32c(feat), _f32c(w), _f32c(b)
+        B, T, E = feat.shape
+        logits = gemm(feat.view(B * T, E), w, bias=b).view(B, T, w.shape[0])
+        loss, ws = _ctc_fwd(logits, frame_lens, y32, label_lens, lmax, blank)
+        ctx.save_for_backward(feat, w, logits, frame_lens, y32, label_lens, ws)
+        ctx.geom = (lmax, blank)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        feat, w, logits, frame_lens, y32, label_lens, ws = ctx.saved_tensors
+        B, T, E = feat.shape
+        V = w.shape[0]
+        db = torch.zeros(V, device=feat.device, dtype=torch.float32)
+        dlogits = _ctc_bwd(logits, frame_lens, y32, label_lens, *ctx.geom, ws, dloss, dbias=db).view(B * T, V)
+        dfeat = gemm(dlogits, w, tb=True).view(B, T, E)
+        dw = gemm(dlogits, feat.view(B * T, E), ta=True, tb=True)
+        return (dfeat, dw, db) + (None,) * 5
+
+
+def ctc_loss(logits, frame_lens, y, label_lens, lmax, blank=0):
+    """mean_b(nll_b / max(label_len_b, 1)) of torch's ctc_loss(reduction='mean', zero_infinity=True)
+    on log_softmax(logits).  logits [B,T,V] float32; frame_lens, label_lens int32 [B] on the device;
+    y int32 [B, >= lmax]: row b's labels are y[b, :label_lens[b]]."""
+    return _CTCLoss.apply(logits, frame_lens, y, label_lens, int(lmax), int(blank))
+
+
+def ctc_head_loss(feat, weight, bias, frame_lens, y, label_lens, lmax, blank=0):
+    """ctc_loss(feat @ weight.T + bias, ...) as one autograd node."""
+    return _CTCHead.apply(feat, weight, bias, frame_lens, y, label_lens, int(lmax), int(blank))
+
+
+# ---------------------------------------------------------------------------
 # misc
 # ---------------------------------------------------------------------------
 def frame_lengths(x):
