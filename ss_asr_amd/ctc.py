@@ -39,6 +39,14 @@ class JointCTCASR(ASR):
         self.ctc_head.weight.data.normal_(0, 1. / math.sqrt(self.encoder.out_dim))   # as init_parameters
         self.ctc_head.bias.data.zero_()
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """A checkpoint of the plain ASR (the reference's, or this build's without the branch)
+        loads too: the head then keeps its fresh initialisation."""
+        if not any(k.startswith('ctc_head.') for k in state_dict):
+            state_dict = dict(state_dict)
+            state_dict.update({'ctc_head.' + k: v for k, v in self.ctc_head.state_dict().items()})
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
     def ctc_loss(self, y):
         """CTC of the most recent forward's encoder output against y [B, L] (prepare_y's matrix:
         <sos>, characters, <eos>, zero padding)."""

@@ -188,15 +188,23 @@ class ASRTrainer(Solver):
             yield b_ind, x, x_lens, y, y_lens
 
     def set_model(self):
-        self.asr_model = self.setup_module(ASR, self.ckppath, self.mapper.get_dim(),
+        # `ctc_weight` under asr.mdl is a key of this build (BASELINE.json configs[3], ss_asr_amd/ctc.py);
+        # the reference's configs do not carry it and get the reference's model and loss
+        joint = 'ctc_weight' in self.config['asr']['mdl']
+        if joint:
+            from .ctc import JointCTCASR, JointCTCTrainStep
+        self.asr_model = self.setup_module(JointCTCASR if joint else ASR, self.ckppath, self.mapper.get_dim(),
                                            **self.config['asr']['mdl'])
         opt = self.config['asr']['opt']
         self.train_step = None
         if opt['type'] == 'Adadelta' and self.device.type == 'cuda':
             # the fused step (engine.ASRTrainStep): what bench.py times is what trains
             from .engine import ASRTrainStep
-            self.train_step = ASRTrainStep(self.asr_model, lr=opt['learning_rate'], eps=1e-8, grad_clip=5.0)
+            step_cls = JointCTCTrainStep if joint else ASRTrainStep
+            self.train_step = step_cls(self.asr_model, lr=opt['learning_rate'], eps=1e-8, grad_clip=5.0)
             self.flat, self.optim = self.train_step.flat, self.train_step.optim
+        elif joint:
+            raise RuntimeError('the joint CTC+attention loss runs on the fused step only (Adadelta on the GPU)')
         else:
             self.optim = getattr(torch.optim, opt['type'])(
                 self.asr_model.parameters(), lr=opt['learning_rate'], eps=1e-8)

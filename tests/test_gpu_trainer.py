@@ -149,3 +149,51 @@ def test_asr_trainer_steps_follow_the_oracle_trajectory(tmp_path):
     got = tr.asr_model.state_dict()
     worst = max(float((got[k].cpu() - v).abs().max()) for k, v in ref.state_dict().items())
     assert worst < 5e-4, worst
+
+
+def test_asr_trainer_with_the_joint_ctc_attention_loss(tmp_path):
+    """`ctc_weight` under asr.mdl (a key of this build, BASELINE.json configs[3]) makes
+    ASRTrainer train JointCTCASR through JointCTCTrainStep: first logged loss against the
+    oracle's joint loss (torch's ctc_loss on the oracle's Listener) from the same start,
+    checkpoint with the head's keys, and a plain-ASR checkpoint still loads."""
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_x, prepare_y
+    from ss_asr_amd.ctc import JointCTCASR, JointCTCTrainStep
+    from ss_asr_amd.trainer import ASRTrainer
+    root = str(tmp_path)
+    index, lens = make_corpus(root, n=16, t_max=160, feat=80, seed=4)
+    cfg = config_for(index)
+    cfg['asr'].update(valid_step=10 ** 9, wer_step=10 ** 9, n_epochs=2)
+    cfg['asr']['mdl'].update(encoder_state_size=64, decoder_state_size=64, mlp_out_size=32, ctc_weight=0.3)
+    paras = types.SimpleNamespace(name='joint', logdir=os.path.join(root, 'runs'),
+                                  ckpdir=os.path.join(root, 'result'), verbose=False, seed=1)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = ASRTrainer(cfg, paras)
+    tr.load_data()
+    tr.set_model()
+    assert isinstance(tr.asr_model, JointCTCASR) and isinstance(tr.train_step, JointCTCTrainStep)
+    start = {k: v.detach().cpu().clone() for k, v in tr.asr_model.state_dict().items()}
+    tr.exec()
+    tr.close()
+    torch.cuda.synchronize()
+    events = [json.loads(l) for l in open(os.path.join(root, 'runs', 'joint', 'asr', 'events.jsonl'))]
+    losses = [e['value'] for e in events if e['key'] == 'asr_train_loss']
+    assert len(losses) == 2 and all(np.isfinite(losses))
+
+    _, _, loader = load_asr_dataset(index, batch_size=16, n_jobs=0)
+    x, y = next(iter(loader))
+    x, x_lens = prepare_x(x)
+    y, _ = prepare_y(y)
+    ref = lo.OracleASR(50, 64, 64, 32, 80, 1.0)
+    ref.load_state_dict({k: v for k, v in start.items() if not k.startswith('ctc_head.')})
+    head = torch.nn.Linear(128, 50)
+    head.load_state_dict({'weight': start['ctc_head.weight'], 'bias': start['ctc_head.bias']})
+    ropt = torch.optim.Adadelta(list(ref.parameters()) + list(head.parameters()), lr=1.0, eps=1e-8)
+    want = lo.joint_train_step(ref, head, ropt, x[:, :max(x_lens)].contiguous(), y, 0.3)
+    assert abs(losses[0] - want[0]) < 1e-4 * max(1.0, want[0]), (losses[0], want)
+
+    saved = torch.load(os.path.join(root, 'result', 'joint', 'asr.cpt'), map_location='cpu')
+    assert 'ctc_head.weight' in saved and 'ctc_head.bias' in saved
+    plain = {k: v for k, v in saved.items() if not k.startswith('ctc_head.')}
+    fresh = JointCTCASR(50, 64, 64, 32, 80, 1.0, ctc_weight=0.3)
+    fresh.load_state_dict(plain)                     # the reference's key set: head keeps its initialisation
+    assert torch.equal(fresh.encoder.blstm_1.layer.weight_ih_l0, saved['encoder.blstm_1.layer.weight_ih_l0'])
