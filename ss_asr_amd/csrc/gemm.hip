@@ -165,34 +165,22 @@ __device__ __forceinline__ bool map_vec_ok_dev(const RowMap& m) {
   return m.inner ? (m.so % 4 == 0 && m.si % 4 == 0) : (m.ld % 4 == 0);
 }
 
-template <int BM, int BN, bool TA, bool TB, bool TR>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bool vecB) {
-  constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
-  constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 fragments per wave
-  using GA = TileGeom<BM, TA>;
-  using GB = TileGeom<BN, TB>;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (GA::FLOATS + GB::FLOATS)];
-  constexpr int STAGE = GA::FLOATS + GB::FLOATS;   // A image then B image, two stages
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int r = lane & 15, q = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // Workgroups are handed to the 8 XCDs round-robin in launch order and each
-  // XCD has its own L2.  Re-map the launch index so that one XCD works on a
-  // contiguous run of tiles (N fastest, then M, then the split-K / batch
-  // slice): its A row-blocks are then fetched by that XCD only.
-  int bx = blockIdx.x, by = blockIdx.y, bzz = blockIdx.z;
+// Workgroups are handed to the 8 XCDs round-robin in launch order and each
+// XCD has its own L2.  Re-map the launch index so that one XCD works on a
+// contiguous run of tiles (N fastest, then M, then the split-K / batch
+// slice): its A row-blocks are then fetched by that XCD only.  Returns false for a workgroup
+// of a class-restricted launch that has nothing to do.
+__device__ __forceinline__ bool gemm_tile_of_block(const GemmDesc& g, int& bx, int& by, int& bzz) {
+  bx = blockIdx.x; by = blockIdx.y; bzz = blockIdx.z;
   if (g.cls_n) {
     // restricted to the XCDs of launch classes cls_lo .. cls_lo + cls_n - 1 (1-D launch of
     // 8 * ceil(tiles / cls_n) workgroups; see GemmDesc): the other classes exit at once
     const int nx = g.gx, ny = g.gy;
     const int total = nx * ny * g.gz;
     const int c = (bx & 7) - g.cls_lo, j = bx >> 3;
-    if (c < 0 || c >= g.cls_n) return;
+    if (c < 0 || c >= g.cls_n) return false;
     const int per = total / g.cls_n, rem = total % g.cls_n;
-    if (j >= per + (c < rem ? 1 : 0)) return;
+    if (j >= per + (c < rem ? 1 : 0)) return false;
     const int t = c * per + min(c, rem) + j;
     bx = t % nx;
     const int u = t / nx;
@@ -210,85 +198,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
     by = u % ny;
     bzz = u / ny;
   }
-  const int bz = bzz / g.splitk;
-  const int kz = bzz - bz * g.splitk;
-  const int m0 = by * BM, n0 = bx * BN;
+  return true;
+}
 
-  int kchunk = (g.K + g.splitk - 1) / g.splitk;
-  kchunk = (kchunk + BK - 1) / BK * BK;
-  const int kbeg = kz * kchunk;
-  const int kend = min(g.K, kbeg + kchunk);
-
-  Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
-  Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
-  TileLoader<BM, TA> la;
-  TileLoader<BN, TB> lb;
-  la.init(opA, m0, kbeg, tid);
-  lb.init(opB, n0, kbeg, tid);
-  // 16-byte loads legal everywhere: the steady state is branch free, edge tiles
-  // included (their out-of-range rows alias valid ones and are dropped at the store)
-  const bool interior = vecA && vecB && (!TA || g.M % 4 == 0) && (!TB || g.N % 4 == 0);
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  float4 ra[GA::NV], rb[GB::NV];
-  if (kbeg < kend) {
-    if (interior && kbeg + BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
-    else { la.load_guarded(ra, kbeg, kend, vecA); lb.load_guarded(rb, kbeg, kend, vecB); }
-    store_tile<BM, TA>(lds, tid, ra);
-    store_tile<BN, TB>(lds + GA::FLOATS, tid, rb);
-  }
-  __syncthreads();
-
-  int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) {
-      la.advance();
-      lb.advance();
-      if (interior && k0 + 2 * BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
-      else { la.load_guarded(ra, k0 + BK, kend, vecA); lb.load_guarded(rb, k0 + BK, kend, vecB); }
-    }
-    const float* curA = lds + buf * STAGE;
-    const float* curB = curA + GA::FLOATS;
-    // Both sub-steps' fragments are read up front (one LDS wait per K step) and
-    // the next tile goes to the other LDS stage between the two MFMA blocks, so
-    // that only the barrier itself separates consecutive K steps.
-    float4 fa[BK / 16][TM], fb[BK / 16][TN];
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<BM, TA>(curA, wm * WM + i * 16, r, q, ks);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<BN, TB>(curB, wn * WN + j * 16, r, q, ks);
-    }
-#define SSASR_GEMM_STEP(KS, C)                                                          \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
-  _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
-    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(fb[KS][j].C, fa[KS][i].C, acc[i][j], 0, 0, 0)      \
-                   : __builtin_amdgcn_mfma_f32_16x16x4f32(fa[KS][i].C, fb[KS][j].C, acc[i][j], 0, 0, 0)
-    SSASR_GEMM_STEP(0, x);
-    SSASR_GEMM_STEP(0, y);
-    SSASR_GEMM_STEP(0, z);
-    SSASR_GEMM_STEP(0, w);
-    if (more) {
-      float* nxt = lds + (buf ^ 1) * STAGE;
-      store_tile<BM, TA>(nxt, tid, ra);
-      store_tile<BN, TB>(nxt + GA::FLOATS, tid, rb);
-    }
-    SSASR_GEMM_STEP(1, x);
-    SSASR_GEMM_STEP(1, y);
-    SSASR_GEMM_STEP(1, z);
-    SSASR_GEMM_STEP(1, w);
-#undef SSASR_GEMM_STEP
-    __syncthreads();
-    buf ^= 1;
-  }
-
+// Epilogue of both GEMM kernels: acc holds the wave's TM x TN fragments of 16 x 16 (D layout of
+// v_mfma_f32_16x16x4_f32 and of v_mfma_f32_16x16x32_bf16 alike).
+template <int TM, int TN, int WM, int WN, bool TR>
+__device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x4 (&acc)[TM][TN], int m0, int n0,
+                                              int wm, int wn, int r, int q, int bz, int kz) {
   if (!TR) {
     // Epilogue.  D fragment: column = lane & 15, row = 4 * (lane >> 4) + reg.
     float* C = g.C + (int64_t)bz * g.sc;
@@ -384,6 +301,355 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
   }
 }
 
+template <int BM, int BN, bool TA, bool TB, bool TR>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bool vecB) {
+  constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
+  constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 fragments per wave
+  using GA = TileGeom<BM, TA>;
+  using GB = TileGeom<BN, TB>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (GA::FLOATS + GB::FLOATS)];
+  constexpr int STAGE = GA::FLOATS + GB::FLOATS;   // A image then B image, two stages
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bx, by, bzz;
+  if (!gemm_tile_of_block(g, bx, by, bzz)) return;
+  const int bz = bzz / g.splitk;
+  const int kz = bzz - bz * g.splitk;
+  const int m0 = by * BM, n0 = bx * BN;
+
+  int kchunk = (g.K + g.splitk - 1) / g.splitk;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  const int kbeg = kz * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+
+  Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
+  Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
+  TileLoader<BM, TA> la;
+  TileLoader<BN, TB> lb;
+  la.init(opA, m0, kbeg, tid);
+  lb.init(opB, n0, kbeg, tid);
+  // 16-byte loads legal everywhere: the steady state is branch free, edge tiles
+  // included (their out-of-range rows alias valid ones and are dropped at the store)
+  const bool interior = vecA && vecB && (!TA || g.M % 4 == 0) && (!TB || g.N % 4 == 0);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[GA::NV], rb[GB::NV];
+  if (kbeg < kend) {
+    if (interior && kbeg + BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
+    else { la.load_guarded(ra, kbeg, kend, vecA); lb.load_guarded(rb, kbeg, kend, vecB); }
+    store_tile<BM, TA>(lds, tid, ra);
+    store_tile<BN, TB>(lds + GA::FLOATS, tid, rb);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) {
+      la.advance();
+      lb.advance();
+      if (interior && k0 + 2 * BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
+      else { la.load_guarded(ra, k0 + BK, kend, vecA); lb.load_guarded(rb, k0 + BK, kend, vecB); }
+    }
+    const float* curA = lds + buf * STAGE;
+    const float* curB = curA + GA::FLOATS;
+    // Both sub-steps' fragments are read up front (one LDS wait per K step) and
+    // the next tile goes to the other LDS stage between the two MFMA blocks, so
+    // that only the barrier itself separates consecutive K steps.
+    float4 fa[BK / 16][TM], fb[BK / 16][TN];
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<BM, TA>(curA, wm * WM + i * 16, r, q, ks);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<BN, TB>(curB, wn * WN + j * 16, r, q, ks);
+    }
+#define SSASR_GEMM_STEP(KS, C)                                                          \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                        \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j)                                        \
+    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(fb[KS][j].C, fa[KS][i].C, acc[i][j], 0, 0, 0)      \
+                   : __builtin_amdgcn_mfma_f32_16x16x4f32(fa[KS][i].C, fb[KS][j].C, acc[i][j], 0, 0, 0)
+    SSASR_GEMM_STEP(0, x);
+    SSASR_GEMM_STEP(0, y);
+    SSASR_GEMM_STEP(0, z);
+    SSASR_GEMM_STEP(0, w);
+    if (more) {
+      float* nxt = lds + (buf ^ 1) * STAGE;
+      store_tile<BM, TA>(nxt, tid, ra);
+      store_tile<BN, TB>(nxt + GA::FLOATS, tid, rb);
+    }
+    SSASR_GEMM_STEP(1, x);
+    SSASR_GEMM_STEP(1, y);
+    SSASR_GEMM_STEP(1, z);
+    SSASR_GEMM_STEP(1, w);
+#undef SSASR_GEMM_STEP
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  gemm_epilogue<TM, TN, WM, WN, TR>(g, acc, m0, n0, wm, wn, r, q, bz, kz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same fp32 product on the bf16 matrix pipeline ("bf16 x 6").
+//
+// gfx950 has no fast fp32 matrix path: v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (32
+// cycles for 1,024 multiply-adds), while v_mfma_f32_16x16x32_bf16 does 8,192 in 16 cycles with
+// fp32 accumulation -- sixteen times the rate.  An fp32 value is the exact sum of three bf16 pieces
+// (8 significant bits each, round-to-nearest residuals: a = a1 + a2 + a3), a product of two bf16
+// values is exact in fp32, so
+//     a * b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + [a2 b3 + a3 b2 + a3 b3],
+// and the bracket is below 2^-24 |a b| -- the size of the ONE rounding an fp32 multiply makes.
+// Six bf16 MFMAs (small terms first) therefore give the fp32 product at 96 cycles per 16 x 16 x 32
+// block against 256 on the fp32 instruction; accumulation is fp32 in both.  Same interface, same
+// epilogues, same results to fp32 rounding (tests/test_gpu_kernels.py compares both kernels with
+// float64): this is a choice of instruction, not of precision.
+//
+// Operands are split where the tile goes from registers to LDS.  LDS image per operand: three
+// planes [rows][32 k] of bf16, 64-byte rows, K contiguous whatever the source orientation (an
+// MN-contiguous source is transposed in registers: a thread loads the same four mn at four
+// consecutive k), rows r and r ^ 1 swapped where bit 2 of r is set so that those column-wise stores
+// spread over all banks, and the four 16-byte chunks of a row XOR-ed with bits 2-3 of r so that the
+// sixteen rows a ds_read_b128 fragment read takes at one k offset fall on different banks (without
+// it rows r and r + 4 collide: SQ_LDS_BANK_CONFLICT was a third of the LDS-active cycles).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int XROW = BK * 2;                                  // bytes per LDS row of one plane
+template <int BMN> struct XGeom {
+  static constexpr int PLANE = BMN * XROW;
+  static constexpr int BYTES = 3 * PLANE;
+};
+__device__ __forceinline__ int x_row(int row) { return row ^ ((row >> 2) & 1); }
+
+// (a, b) -> the three packed bf16 pairs of their split
+__device__ __forceinline__ void x_split2(float a, float b, uint32_t& u1, uint32_t& u2, uint32_t& u3) {
+  u1 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
+  const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
+  u2 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){ra, rb}, bf16x2));
+  const float sa = ra - __uint_as_float(u2 << 16), sb = rb - __uint_as_float(u2 & 0xffff0000u);
+  u3 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){sa, sb}, bf16x2));
+}
+
+// four consecutive k of one row -> 8 bytes in each plane
+template <int BMN>
+__device__ __forceinline__ void x_store4(char* img, int row, int slot, float k0, float k1, float k2, float k3) {
+  uint32_t a1, a2, a3, b1, b2, b3;
+  x_split2(k0, k1, a1, a2, a3);
+  x_split2(k2, k3, b1, b2, b3);
+  char* dst = img + x_row(row) * XROW + ((slot ^ ((row >> 1) & 6)) * 8);    // chunk (slot >> 1) ^ ((row >> 2) & 3)
+  *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
+  *reinterpret_cast<uint2*>(dst + XGeom<BMN>::PLANE) = make_uint2(a2, b2);
+  *reinterpret_cast<uint2*>(dst + 2 * XGeom<BMN>::PLANE) = make_uint2(a3, b3);
+}
+
+// Loader of an MN-contiguous operand for this kernel: thread (g, kq) takes the four mn 4g .. 4g + 3 at
+// the four k 4 kq .. 4 kq + 3 of the K step (a wave-instruction reads 128-byte runs of eight k rows).
+// A 64-wide tile needs 128 threads: `shift` picks which half of the workgroup (A: lower, B: upper).
+template <int BMN>
+struct XTLoader {
+  const float* ptr[4];
+  int64_t kin[4];
+  int g, kq, extent;
+  bool active;
+  RowMap m;
+
+  __device__ __forceinline__ void init(const Operand& op, int mn0, int k0, int tid, int shift) {
+    const int t = BMN == 64 ? (tid + shift) & 255 : tid;
+    active = t < BMN * 2;
+    g = t >> 3;
+    kq = t & 7;
+    extent = op.extent;
+    m = op.m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = (int64_t)k0 + 4 * kq + i;
+      const int mn = mn0 + 4 * g;
+      ptr[i] = op.p + rm_off(op.m, k) + (mn + 3 < extent || !op.vec ? mn : 0);
+      kin[i] = op.m.inner ? k % op.m.inner : 0;
+    }
+    mn_first = mn0 + 4 * g;
+  }
+  int mn_first;
+
+  __device__ __forceinline__ void advance() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (m.inner == 0) {
+        ptr[i] += (int64_t)BK * m.ld;
+      } else {
+        int64_t in = kin[i] + BK;
+        int64_t off = (int64_t)BK * m.si;
+        while (in >= m.inner) { in -= m.inner; off += m.so - m.inner * m.si; }
+        kin[i] = in;
+        ptr[i] += off;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load_fast(float4 (&v)[4]) const {
+    if (!active) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(ptr[i]);
+  }
+
+  __device__ __forceinline__ void load_guarded(float4 (&v)[4], int k0, int kend, bool vec) const {
+    if (!active) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k = k0 + 4 * kq + i;
+      if (k < kend && mn_first < extent) {
+        const int left = extent - mn_first;
+        if (vec && left >= 4) {
+          x = *reinterpret_cast<const float4*>(ptr[i]);
+        } else {
+          const float* qp = vec ? ptr[i] + mn_first : ptr[i];   // vec: ptr was redirected to group 0
+          x.x = qp[0];
+          if (left > 1) x.y = qp[1];
+          if (left > 2) x.z = qp[2];
+          if (left > 3) x.w = qp[3];
+        }
+      }
+      v[i] = x;
+    }
+  }
+
+  __device__ __forceinline__ void store(char* img, const float4 (&v)[4]) const {
+    if (!active) return;
+    x_store4<BMN>(img, 4 * g + 0, kq, v[0].x, v[1].x, v[2].x, v[3].x);
+    x_store4<BMN>(img, 4 * g + 1, kq, v[0].y, v[1].y, v[2].y, v[3].y);
+    x_store4<BMN>(img, 4 * g + 2, kq, v[0].z, v[1].z, v[2].z, v[3].z);
+    x_store4<BMN>(img, 4 * g + 3, kq, v[0].w, v[1].w, v[2].w, v[3].w);
+  }
+};
+
+// K-contiguous operand: the fp32 kernel's loader, stored through the split
+template <int BMN>
+struct XNLoader : TileLoader<BMN, false> {
+  static constexpr int NV = TileGeom<BMN, false>::NV;
+  __device__ __forceinline__ void init(const Operand& op, int mn0, int k0, int tid, int) {
+    TileLoader<BMN, false>::init(op, mn0, k0, tid);
+    this->tid_ = tid;
+  }
+  int tid_;
+  __device__ __forceinline__ void store(char* img, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid_ + i * 256;
+      x_store4<BMN>(img, f / (BK / 4), f % (BK / 4), v[i].x, v[i].y, v[i].z, v[i].w);
+    }
+  }
+};
+
+template <int BMN, bool T> struct XLoaderOf { using type = XNLoader<BMN>; static constexpr int NV = TileGeom<BMN, false>::NV; };
+template <int BMN> struct XLoaderOf<BMN, true> { using type = XTLoader<BMN>; static constexpr int NV = 4; };
+
+template <int BMN>
+__device__ __forceinline__ bf16x8 x_frag(const char* img, int plane, int row, int q) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + plane * XGeom<BMN>::PLANE + x_row(row) * XROW + ((q ^ ((row >> 2) & 3)) * 16)));
+}
+
+template <int BM, int BN, bool TA, bool TB, bool TR>
+__global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, bool vecB) {
+  constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
+  constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 fragments per wave
+  extern __shared__ __attribute__((aligned(16))) char xlds[];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by, bzz;
+  if (!gemm_tile_of_block(g, bx, by, bzz)) return;
+  const int bz = bzz / g.splitk;
+  const int kz = bzz - bz * g.splitk;
+  const int m0 = by * BM, n0 = bx * BN;
+
+  int kchunk = (g.K + g.splitk - 1) / g.splitk;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  const int kbeg = kz * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+
+  Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
+  Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
+  typename XLoaderOf<BM, TA>::type la;
+  typename XLoaderOf<BN, TB>::type lb;
+  la.init(opA, m0, kbeg, tid, 0);
+  lb.init(opB, n0, kbeg, tid, 128);
+  const bool interior = vecA && vecB && (!TA || g.M % 4 == 0) && (!TB || g.N % 4 == 0);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[XLoaderOf<BM, TA>::NV], rb[XLoaderOf<BN, TB>::NV];
+  if (kbeg < kend) {
+    if (interior && kbeg + BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
+    else { la.load_guarded(ra, kbeg, kend, vecA); lb.load_guarded(rb, kbeg, kend, vecB); }
+    la.store(xlds, ra);
+    lb.store(xlds + XGeom<BM>::BYTES, rb);
+  }
+  __syncthreads();
+
+  // One LDS stage (48 KB at 128 x 128, so that two workgroups share a CU and one's MFMAs cover the
+  // other's operand split): fragments -> registers, barrier, then the MFMAs with the next tile's
+  // split + store between them, barrier.  (Two stages with one workgroup per CU: 141 TF against 171
+  // on 4096^3; a second register set that loads two K steps ahead pushes the kernel past 256 VGPRs,
+  // one wave per SIMD: 109 TF.)
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) {
+      la.advance();
+      lb.advance();
+      if (interior && k0 + 2 * BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
+      else { la.load_guarded(ra, k0 + BK, kend, vecA); lb.load_guarded(rb, k0 + BK, kend, vecB); }
+    }
+    const char* curA = xlds;
+    const char* curB = curA + XGeom<BM>::BYTES;
+    bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[p][i] = x_frag<BM>(curA, p, wm * WM + i * 16 + r, q);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[p][j] = x_frag<BN>(curB, p, wn * WN + j * 16 + r, q);
+    }
+    __syncthreads();          // every wave holds its fragments: the image may be overwritten
+#define SSASR_X6_STEP(PA, PB)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
+    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PB][j], fa[PA][i], acc[i][j], 0, 0, 0)  \
+                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0)
+    SSASR_X6_STEP(2, 0);      // smallest terms first
+    SSASR_X6_STEP(0, 2);
+    SSASR_X6_STEP(1, 1);
+    if (more) {
+      la.store(xlds, ra);
+      lb.store(xlds + XGeom<BM>::BYTES, rb);
+    }
+    SSASR_X6_STEP(1, 0);
+    SSASR_X6_STEP(0, 1);
+    SSASR_X6_STEP(0, 0);
+#undef SSASR_X6_STEP
+    __syncthreads();          // the next tile is in place
+  }
+  gemm_epilogue<TM, TN, WM, WN, TR>(g, acc, m0, n0, wm, wn, r, q, bz, kz);
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool map_vec_ok(const RowMap& m) {
   return m.inner ? (m.so % 4 == 0 && m.si % 4 == 0) : (m.ld % 4 == 0);
@@ -402,6 +668,35 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
   }
   // split-K launches add their partial products atomically: one float per lane in rows of 16
   // consecutive columns (TR = false); everything else stores 16 bytes per lane (TR = true)
+  // the bf16 x 6 kernel where it is the faster one: both operands K contiguous (measured, same shapes:
+  // 118-127 TF against 92-94; with an MN-contiguous operand its column-wise staging loses, 82 against 112)
+  const int x6 = ssasr_options().gemm_x6;
+  if (x6 == 2 || (x6 == 1 && !g.ta && !g.tb)) {
+    constexpr size_t lds = XGeom<BM>::BYTES + XGeom<BN>::BYTES;
+#define SSASR_X6_LAUNCH(A_, B_, R_)                                                                         \
+  do {                                                                                                      \
+    auto fn = gemm_x6_kernel<BM, BN, A_, B_, R_>;                                                           \
+    static bool once = false;                                                                               \
+    if (!once) {                                                                                            \
+      SSASR_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      once = true;                                                                                          \
+    }                                                                                                       \
+    hipLaunchKernelGGL(fn, grid, block, lds, st, g, vecA, vecB);                                            \
+  } while (0)
+#define SSASR_X6_PICK(A_, B_)                                                                               \
+  do {                                                                                                      \
+    if (g.splitk > 1) SSASR_X6_LAUNCH(A_, B_, false);                                                       \
+    else SSASR_X6_LAUNCH(A_, B_, true);                                                                     \
+  } while (0)
+    if (!g.ta && !g.tb) SSASR_X6_PICK(false, false);
+    else if (!g.ta && g.tb) SSASR_X6_PICK(false, true);
+    else if (g.ta && !g.tb) SSASR_X6_PICK(true, false);
+    else SSASR_X6_PICK(true, true);
+#undef SSASR_X6_PICK
+#undef SSASR_X6_LAUNCH
+    SSASR_LAUNCH_CHECK();
+    return SSASR_OK;
+  }
 #define SSASR_GEMM_LAUNCH(A_, B_)                                                                           \
   do {                                                                                                      \
     if (g.splitk > 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_, B_, false>), grid, block, 0, st, g, vecA, vecB); \

@@ -53,6 +53,37 @@ def test_gemm_is_exact_fp32_fma_chain():
     assert torch.equal(got.cpu(), b.t())
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_on_bf16_pieces_is_as_exact_as_the_fp32_instruction(ta, tb):
+    """The fp32 product as six bf16 MFMAs on the exact three-way split of both operands
+    (csrc/gemm.hip, SSASR_GEMM_X6) against the same product on v_mfma_f32_16x16x4_f32, both
+    measured against float64: wide-range operands (magnitudes over 12 decades, so that an
+    operand's low pieces matter), K = 1000, edge tiles in M and N.  The split form must not be
+    less exact than the fp32 instruction's own rounding."""
+    from ss_asr_amd import _lib, ops
+    M, N, K = 200, 136, 1000
+    g = torch.Generator().manual_seed(77)
+    def wide(*shape):
+        return torch.randn(*shape, generator=g, dtype=torch.float64) * torch.exp(
+            6.0 * torch.randn(*shape, generator=g, dtype=torch.float64))
+    a = wide(K, M) if ta else wide(M, K)
+    b = wide(K, N) if tb else wide(N, K)
+    af, bf = a.float(), b.float()
+    want = (af.double().t() if ta else af.double()) @ (bf.double() if tb else bf.double().t())
+    scale = ((af.double().abs().t() if ta else af.double().abs()) @
+             (bf.double().abs() if tb else bf.double().abs().t()))           # sum |a_k b_k| per element
+    errs = {}
+    for mode in (0, 2):
+        old = _lib.set_option('SSASR_GEMM_X6', mode)
+        try:
+            got = ops.gemm(af.to(dev()), bf.to(dev()), ta=bool(ta), tb=bool(tb))
+        finally:
+            _lib.set_option('SSASR_GEMM_X6', old)
+        errs[mode] = float(((got.double().cpu() - want).abs() / scale).max())
+    assert errs[0] < 2e-6, errs               # the fp32 instruction: ~sqrt(K) roundings of 6e-8
+    assert errs[2] < max(2 * errs[0], 5e-7), errs
+
+
 def test_gemm_bias_tanh_beta_batched_splitk():
     from ss_asr_amd import ops
     a, b, bias = rnd(300, 72, seed=3), rnd(40, 72, seed=4), rnd(40, seed=5)
