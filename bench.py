@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0   # bf16 MFMA dense peak (MI355X_MICROARCH.md)
 
 DIMS = dict(output_dim=50, encoder_state_size=256, decoder_state_size=256, mlp_out_size=128,
             feature_dim=80, tf_rate=0.9)
@@ -266,6 +267,20 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
                         hbm_frac=round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         shape=dict(S=S, N=N, H=H, directions=2),
                         note='latency bound: one cross-XCD exchange per time step; see DESIGN.md 4.2'))
+    # The input projection of that layer (one launch, both directions): the one true dense contraction
+    # of the path.  fp32 operands and accumulation; products run as six bf16 MFMAs on the exact
+    # three-way split of both operands (csrc/gemm.hip), so two prices are given: algorithmic fp32 flops
+    # against the fp32-instruction peak the reference arithmetic would be bound by, and the executed
+    # bf16 flops (6 x) against the bf16 dense peak.
+    gflops = 2 * (2.0 * S * N * 4 * H * I)
+    gtf = gflops / (us_i2h * 1e-6) / 1e12
+    out.append(dict(kernel='gemm_x6_kernel<128, 128, false, false, true>', bound='mfma', achieved=round(gtf, 2),
+                    peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', frac=round(gtf / MFMA_F32_PEAK_TF, 4), traffic=None,
+                    flops_per_launch=gflops, us_per_launch=round(us_i2h, 1),
+                    executed_bf16=dict(achieved=round(6 * gtf, 1), peak=MFMA_BF16_PEAK_TF,
+                                       frac=round(6 * gtf / MFMA_BF16_PEAK_TF, 4)),
+                    shape=dict(M=S * N, N=4 * H, K=I, batch=2),
+                    note='fp32 product = a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 on bf16 pieces; DESIGN.md 4.1'))
     return out
 
 
@@ -425,7 +440,8 @@ def main():
         att['at_training_shape'] = {k: att100[k] for k in ('kernel', 'achieved', 'frac', 'bytes_per_launch', 'us_per_launch', 'shape')}
         att['in_decode_loop'] = decode_loop_attention(device)
         note('attention stage of the persistent decode loop: %s' % att['in_decode_loop'])
-        bptt, fwd_rec = recurrence_roofline(device)
+        bptt, fwd_rec, gemm_rl = recurrence_roofline(device)
+        note('input-projection GEMM: %s' % gemm_rl)
         note('BPTT recurrence: %s' % bptt)
         note('forward recurrence: %s' % fwd_rec)
         traffic = os.path.join(ROOT, 'profiles', 'r02_traffic.json')    # rocprofv3 --pmc passes, see profiles/README.md
@@ -439,6 +455,7 @@ def main():
         out['roofline'] = bptt                       # dominant kernel of the step (profiles/)
         out['roofline_forward_recurrence'] = fwd_rec
         out['roofline_attention'] = att
+        out['roofline_gemm'] = gemm_rl
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline([host_batches[k] for k in (2, 4, 6)])
     print(json.dumps(out), flush=True)
