@@ -118,7 +118,7 @@ struct SsasrOptions {
   int no_persistent_decoder_bwd;  // SSASR_NO_PERSISTENT_DECODER_BWD
   int delay_fwd, delay_bwd, delay_bwd_ksplit;   // SSASR_PERSIST_DELAY_FWD / _BWD (initial pacing, x 64 cycles; -1 = default)
   int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
-  int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs -- 0 never, 1 where it is faster (NT), 2 always
+  int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs (0: on v_mfma_f32_16x16x4_f32)
   int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches
   int test_drop_tile;             // SSASR_TEST_DROP_TILE (-1): fault injection, see EncPersist::drop_tile
   int attn_rph;                   // SSASR_ATTN_RPH: 0 model, 2 | 3 | 4 | 6 rows per half-wave of the split-T attention kernel

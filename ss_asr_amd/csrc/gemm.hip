@@ -414,11 +414,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
 // epilogues, same results to fp32 rounding (tests/test_gpu_kernels.py compares both kernels with
 // float64): this is a choice of instruction, not of precision.
 //
-// Operands are split where the tile goes from registers to LDS.  LDS image per operand: three
-// planes [rows][32 k] of bf16, 64-byte rows, K contiguous whatever the source orientation (an
-// MN-contiguous source is transposed in registers: a thread loads the same four mn at four
-// consecutive k), rows r and r ^ 1 swapped where bit 2 of r is set so that those column-wise stores
-// spread over all banks, and the four 16-byte chunks of a row XOR-ed with bits 2-3 of r so that the
+// Operands are split where the tile goes from registers to LDS.  LDS image of a K-contiguous
+// operand: three planes [rows][32 k] of bf16, 64-byte rows, and the four 16-byte chunks of a row XOR-ed with bits 2-3 of r so that the
 // sixteen rows a ds_read_b128 fragment read takes at one k offset fall on different banks (without
 // it rows r and r + 4 collide: SQ_LDS_BANK_CONFLICT was a third of the LDS-active cycles).
 // ---------------------------------------------------------------------------------------------
@@ -431,7 +428,6 @@ template <int BMN> struct XGeom {
   static constexpr int PLANE = BMN * XROW;
   static constexpr int BYTES = 3 * PLANE;
 };
-__device__ __forceinline__ int x_row(int row) { return row ^ ((row >> 2) & 1); }
 
 // (a, b) -> the three packed bf16 pairs of their split
 __device__ __forceinline__ void x_split2(float a, float b, uint32_t& u1, uint32_t& u2, uint32_t& u3) {
@@ -448,90 +444,49 @@ __device__ __forceinline__ void x_store4(char* img, int row, int slot, float k0,
   uint32_t a1, a2, a3, b1, b2, b3;
   x_split2(k0, k1, a1, a2, a3);
   x_split2(k2, k3, b1, b2, b3);
-  char* dst = img + x_row(row) * XROW + ((slot ^ ((row >> 1) & 6)) * 8);    // chunk (slot >> 1) ^ ((row >> 2) & 3)
+  char* dst = img + row * XROW + ((slot ^ ((row >> 1) & 6)) * 8);    // chunk (slot >> 1) ^ ((row >> 2) & 3)
   *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
   *reinterpret_cast<uint2*>(dst + XGeom<BMN>::PLANE) = make_uint2(a2, b2);
   *reinterpret_cast<uint2*>(dst + 2 * XGeom<BMN>::PLANE) = make_uint2(a3, b3);
 }
 
-// Loader of an MN-contiguous operand for this kernel: thread (g, kq) takes the four mn 4g .. 4g + 3 at
-// the four k 4 kq .. 4 kq + 3 of the K step (a wave-instruction reads 128-byte runs of eight k rows).
-// A 64-wide tile needs 128 threads: `shift` picks which half of the workgroup (A: lower, B: upper).
+// MN-contiguous operand: the image keeps the source orientation -- three planes [32 k][BMN mn] of bf16,
+// rows of BMN * 2 bytes, written with one 8-byte store per plane and float4 (four mn at one k; a wave
+// fills whole rows) -- and the K-contiguous MFMA fragment comes out of the hardware's transposing read:
+// ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4 (k) x 16 (mn) block, so two reads
+// give a lane its eight consecutive k.  The 32-byte blocks of a row are XOR-ed with a function of k
+// such that the eight rows a 32-lane half reads (k0 .. k0 + 3 and k0 + 8 .. k0 + 11) fall on
+// different banks.
 template <int BMN>
-struct XTLoader {
-  const float* ptr[4];
-  int64_t kin[4];
-  int g, kq, extent;
-  bool active;
-  RowMap m;
+__device__ __forceinline__ int xt_swz(int k) {
+  return BMN >= 128 ? ((k & 3) | (((k >> 3) & 1) << 2)) : ((k & 3) ^ ((k >> 3) & 1));
+}
+template <int BMN>
+__device__ __forceinline__ int xt_off(int k, int mn) {       // byte offset of (k, mn) inside a plane
+  return k * (BMN * 2) + ((((mn >> 4) ^ xt_swz<BMN>(k)) << 5) | ((mn & 15) * 2));
+}
 
-  __device__ __forceinline__ void init(const Operand& op, int mn0, int k0, int tid, int shift) {
-    const int t = BMN == 64 ? (tid + shift) & 255 : tid;
-    active = t < BMN * 2;
-    g = t >> 3;
-    kq = t & 7;
-    extent = op.extent;
-    m = op.m;
+template <int BMN>
+struct XTLoader : TileLoader<BMN, true> {
+  static constexpr int NV = TileGeom<BMN, true>::NV;
+  static constexpr int PER_ROW = BMN / 4;
+  int tid_;
+  __device__ __forceinline__ void init(const Operand& op, int mn0, int k0, int tid, int) {
+    TileLoader<BMN, true>::init(op, mn0, k0, tid);
+    tid_ = tid;
+  }
+  __device__ __forceinline__ void store(char* img, const float4 (&v)[NV]) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t k = (int64_t)k0 + 4 * kq + i;
-      const int mn = mn0 + 4 * g;
-      ptr[i] = op.p + rm_off(op.m, k) + (mn + 3 < extent || !op.vec ? mn : 0);
-      kin[i] = op.m.inner ? k % op.m.inner : 0;
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid_ + i * 256;
+      uint32_t a1, a2, a3, b1, b2, b3;
+      x_split2(v[i].x, v[i].y, a1, a2, a3);
+      x_split2(v[i].z, v[i].w, b1, b2, b3);
+      char* dst = img + xt_off<BMN>(f / PER_ROW, (f % PER_ROW) * 4);
+      *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
+      *reinterpret_cast<uint2*>(dst + XGeom<BMN>::PLANE) = make_uint2(a2, b2);
+      *reinterpret_cast<uint2*>(dst + 2 * XGeom<BMN>::PLANE) = make_uint2(a3, b3);
     }
-    mn_first = mn0 + 4 * g;
-  }
-  int mn_first;
-
-  __device__ __forceinline__ void advance() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (m.inner == 0) {
-        ptr[i] += (int64_t)BK * m.ld;
-      } else {
-        int64_t in = kin[i] + BK;
-        int64_t off = (int64_t)BK * m.si;
-        while (in >= m.inner) { in -= m.inner; off += m.so - m.inner * m.si; }
-        kin[i] = in;
-        ptr[i] += off;
-      }
-    }
-  }
-
-  __device__ __forceinline__ void load_fast(float4 (&v)[4]) const {
-    if (!active) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(ptr[i]);
-  }
-
-  __device__ __forceinline__ void load_guarded(float4 (&v)[4], int k0, int kend, bool vec) const {
-    if (!active) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int k = k0 + 4 * kq + i;
-      if (k < kend && mn_first < extent) {
-        const int left = extent - mn_first;
-        if (vec && left >= 4) {
-          x = *reinterpret_cast<const float4*>(ptr[i]);
-        } else {
-          const float* qp = vec ? ptr[i] + mn_first : ptr[i];   // vec: ptr was redirected to group 0
-          x.x = qp[0];
-          if (left > 1) x.y = qp[1];
-          if (left > 2) x.z = qp[2];
-          if (left > 3) x.w = qp[3];
-        }
-      }
-      v[i] = x;
-    }
-  }
-
-  __device__ __forceinline__ void store(char* img, const float4 (&v)[4]) const {
-    if (!active) return;
-    x_store4<BMN>(img, 4 * g + 0, kq, v[0].x, v[1].x, v[2].x, v[3].x);
-    x_store4<BMN>(img, 4 * g + 1, kq, v[0].y, v[1].y, v[2].y, v[3].y);
-    x_store4<BMN>(img, 4 * g + 2, kq, v[0].z, v[1].z, v[2].z, v[3].z);
-    x_store4<BMN>(img, 4 * g + 3, kq, v[0].w, v[1].w, v[2].w, v[3].w);
   }
 };
 
@@ -554,11 +509,31 @@ struct XNLoader : TileLoader<BMN, false> {
 };
 
 template <int BMN, bool T> struct XLoaderOf { using type = XNLoader<BMN>; static constexpr int NV = TileGeom<BMN, false>::NV; };
-template <int BMN> struct XLoaderOf<BMN, true> { using type = XTLoader<BMN>; static constexpr int NV = 4; };
+template <int BMN> struct XLoaderOf<BMN, true> { using type = XTLoader<BMN>; static constexpr int NV = TileGeom<BMN, true>::NV; };
 
 template <int BMN>
 __device__ __forceinline__ bf16x8 x_frag(const char* img, int plane, int row, int q) {
-  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + plane * XGeom<BMN>::PLANE + x_row(row) * XROW + ((q ^ ((row >> 2) & 3)) * 16)));
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + plane * XGeom<BMN>::PLANE + row * XROW + ((q ^ ((row >> 2) & 3)) * 16)));
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// fragment of the 16 rows (mn) starting at `base` from a transposed image; i = lane & 15, q = lane >> 4
+template <int BMN>
+__device__ __forceinline__ bf16x8 xt_frag(const char* img, int plane, int base, int i, int q) {
+  const int k = 8 * q + (i >> 2);
+  const char* p = img + plane * XGeom<BMN>::PLANE;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + xt_off<BMN>(k, base + 4 * (i & 3))));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + xt_off<BMN>(k + 4, base + 4 * (i & 3))));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int BMN, bool T>
+__device__ __forceinline__ bf16x8 x_operand(const char* img, int plane, int base, int r, int q) {
+  if constexpr (T) return xt_frag<BMN>(img, plane, base, r, q);
+  else return x_frag<BMN>(img, plane, base + r, q);
 }
 
 template <int BM, int BN, bool TA, bool TB, bool TR>
@@ -624,9 +599,9 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[p][i] = x_frag<BM>(curA, p, wm * WM + i * 16 + r, q);
+      for (int i = 0; i < TM; ++i) fa[p][i] = x_operand<BM, TA>(curA, p, wm * WM + i * 16, r, q);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[p][j] = x_frag<BN>(curB, p, wn * WN + j * 16 + r, q);
+      for (int j = 0; j < TN; ++j) fb[p][j] = x_operand<BN, TB>(curB, p, wn * WN + j * 16, r, q);
     }
     __syncthreads();          // every wave holds its fragments: the image may be overwritten
 #define SSASR_X6_STEP(PA, PB)                                                                      \
@@ -668,10 +643,7 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
   }
   // split-K launches add their partial products atomically: one float per lane in rows of 16
   // consecutive columns (TR = false); everything else stores 16 bytes per lane (TR = true)
-  // the bf16 x 6 kernel where it is the faster one: both operands K contiguous (measured, same shapes:
-  // 118-127 TF against 92-94; with an MN-contiguous operand its column-wise staging loses, 82 against 112)
-  const int x6 = ssasr_options().gemm_x6;
-  if (x6 == 2 || (x6 == 1 && !g.ta && !g.tb)) {
+  if (ssasr_options().gemm_x6) {
     constexpr size_t lds = XGeom<BM>::BYTES + XGeom<BN>::BYTES;
 #define SSASR_X6_LAUNCH(A_, B_, R_)                                                                         \
   do {                                                                                                      \
