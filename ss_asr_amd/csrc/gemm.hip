@@ -710,9 +710,18 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   // most one); 64 x 64 tiles, fine grained -- 0.133 + 0.00052 per tile.  Take the cheaper.
   if (g.splitk == 1) {
     const int64_t n = (big + cus - 1) / cus;
-    const double t128 = n == 1 ? 0.63 : 1.0 * (double)(n / 2) + 0.9 * (double)(n % 2);
     const int64_t small = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch;
-    const double t64 = 0.133 + 0.00052 * (double)small * (256.0 / (double)cus);
+    double t128, t64;
+    if (ssasr_options().gemm_x6) {
+      // the split-bf16 kernel, same sweep (us at K = 1024): 128-tiles 78 up to one per CU, 101 up to
+      // two, a trailing odd round ~70; 64-tiles 12 + 0.056 per tile with a floor of 45
+      t128 = n == 1 ? 78.0 : 101.0 * (double)(n / 2) + 70.0 * (double)(n % 2);
+      t64 = 12.0 + 0.056 * (double)small * (256.0 / (double)cus);
+      if (t64 < 45.0) t64 = 45.0;
+    } else {
+      t128 = n == 1 ? 0.63 : 1.0 * (double)(n / 2) + 0.9 * (double)(n % 2);
+      t64 = 0.133 + 0.00052 * (double)small * (256.0 / (double)cus);
+    }
     if (t64 < t128) return launch_tiles<64, 64>(g, vecA, vecB, st);
   }
   return launch_tiles<128, 128>(g, vecA, vecB, st);
