@@ -53,6 +53,38 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+// ---- fp32 products on the bf16 matrix pipeline (see gemm.hip, "bf16 x 6") ----
+// a = a1 + a2 + a3 exactly, each piece a bf16 (round-to-nearest residuals).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t x6_pack(float a, float b) {      // (bf16(a), bf16(b)) in one dword, a low
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ float x6_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float x6_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// (a, b) -> the three packed bf16 pairs of their split
+__device__ __forceinline__ void x_split2(float a, float b, uint32_t& u1, uint32_t& u2, uint32_t& u3) {
+  u1 = x6_pack(a, b);
+  const float ra = a - x6_lo(u1), rb = b - x6_hi(u1);
+  u2 = x6_pack(ra, rb);
+  const float sa = ra - x6_lo(u2), sb = rb - x6_hi(u2);
+  u3 = x6_pack(sa, sb);
+}
+
+// eight consecutive k (lo = k 0..3, hi = k 4..7) -> the three bf16x8 operand planes
+__device__ __forceinline__ void x6_planes(const float4& lo, const float4& hi, bf16x8 (&pl)[3]) {
+  uint32_t u[3][4];
+  x_split2(lo.x, lo.y, u[0][0], u[1][0], u[2][0]);
+  x_split2(lo.z, lo.w, u[0][1], u[1][1], u[2][1]);
+  x_split2(hi.x, hi.y, u[0][2], u[1][2], u[2][2]);
+  x_split2(hi.z, hi.w, u[0][3], u[1][3], u[2][3]);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) pl[p] = __builtin_bit_cast(bf16x8, make_uint4(u[p][0], u[p][1], u[p][2], u[p][3]));
+}
+
 // 64-lane butterfly reductions (wave64).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

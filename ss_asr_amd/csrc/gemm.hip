@@ -419,24 +419,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
 // sixteen rows a ds_read_b128 fragment read takes at one k offset fall on different banks (without
 // it rows r and r + 4 collide: SQ_LDS_BANK_CONFLICT was a third of the LDS-active cycles).
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 constexpr int XROW = BK * 2;                                  // bytes per LDS row of one plane
 template <int BMN> struct XGeom {
   static constexpr int PLANE = BMN * XROW;
   static constexpr int BYTES = 3 * PLANE;
 };
-
-// (a, b) -> the three packed bf16 pairs of their split
-__device__ __forceinline__ void x_split2(float a, float b, uint32_t& u1, uint32_t& u2, uint32_t& u3) {
-  u1 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
-  const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
-  u2 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){ra, rb}, bf16x2));
-  const float sa = ra - __uint_as_float(u2 << 16), sb = rb - __uint_as_float(u2 & 0xffff0000u);
-  u3 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){sa, sb}, bf16x2));
-}
 
 // four consecutive k of one row -> 8 bytes in each plane
 template <int BMN>

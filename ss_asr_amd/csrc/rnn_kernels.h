@@ -1421,6 +1421,17 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
       for (int g = 0; g < 4; ++g) wreg[t][g] = *reinterpret_cast<const float4*>(wp + (int64_t)g * H);
     }
   }
+  // The product runs on the bf16 matrix pipeline as six MFMAs per fp32 product (gemm.hip, "bf16 x 6":
+  // exact three-way split of both operands, fp32 accumulation): 24 instructions of 16 cycles per wave
+  // and step instead of 32 of 32 cycles.  K block b of 32 = gates 2b and 2b + 1 of this workgroup's
+  // 16 units; lane (q, r) holds k = 8q + e: e < 4 gate 2b, unit 4q + e; e >= 4 gate 2b + 1, unit
+  // 4q + e - 4 -- which is how both the weight registers above and the gate derivatives in sG
+  // already sit, lane for lane.
+  bf16x8 wA[OT][2][3];
+#pragma unroll
+  for (int t = 0; t < OT; ++t)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) x6_planes(wreg[t][2 * b], wreg[t][2 * b + 1], wA[t][b]);
   const bool epi = wave == 0 && col_ok;
   float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps
   float* dcs = e.dc_state ? e.dc_state + ((int64_t)d * N + n) * H + u0 : nullptr;
@@ -1513,31 +1524,39 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
       float4 b[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) b[g] = sG[i % NG][g][lane];
-      // two accumulators per tile: with OT = 1 a single chain would wait on its own result
+      // Split level by level, each level's MFMAs issued as soon as its pieces exist, so that the
+      // vector work of the next level runs beside them: b1 (a convert) -> a1 b1, a2 b1, a3 b1;
+      // b2 -> a1 b2, a2 b2; b3 -> a1 b3.  One accumulator per (tile, K block): four chains.
       f32x4 acc[OT], acc2[OT];
 #pragma unroll
       for (int t = 0; t < OT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      float v[2][8];
 #pragma unroll
-      for (int g = 0; g < 4; g += 2) {
+      for (int kb = 0; kb < 2; ++kb) {
+        const float4 lo = b[2 * kb], hi = b[2 * kb + 1];
+        v[kb][0] = lo.x; v[kb][1] = lo.y; v[kb][2] = lo.z; v[kb][3] = lo.w;
+        v[kb][4] = hi.x; v[kb][5] = hi.y; v[kb][6] = hi.z; v[kb][7] = hi.w;
+      }
 #pragma unroll
-        for (int t = 0; t < OT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].x, b[g].x, acc[t], 0, 0, 0);
-          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g + 1].x, b[g + 1].x, acc2[t], 0, 0, 0);
+      for (int level = 0; level < 3; ++level) {
+        bf16x8 piece[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          uint32_t u[4];
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) {
+            u[pr] = x6_pack(v[kb][2 * pr], v[kb][2 * pr + 1]);
+            if (level < 2) { v[kb][2 * pr] -= x6_lo(u[pr]); v[kb][2 * pr + 1] -= x6_hi(u[pr]); }
+          }
+          piece[kb] = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
         }
 #pragma unroll
-        for (int t = 0; t < OT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].y, b[g].y, acc[t], 0, 0, 0);
-          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g + 1].y, b[g + 1].y, acc2[t], 0, 0, 0);
-        }
+        for (int pa = 0; pa + level < 3; ++pa) {
 #pragma unroll
-        for (int t = 0; t < OT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].z, b[g].z, acc[t], 0, 0, 0);
-          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g + 1].z, b[g + 1].z, acc2[t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < OT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g].w, b[g].w, acc[t], 0, 0, 0);
-          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t][g + 1].w, b[g + 1].w, acc2[t], 0, 0, 0);
+          for (int t = 0; t < OT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[t][0][pa], piece[0], acc[t], 0, 0, 0);
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[t][1][pa], piece[1], acc2[t], 0, 0, 0);
+          }
         }
       }
       const unsigned base = (unsigned)(i % BWD_RS_RING) * SLOT_B + (unsigned)tile * TILE_B;   // source = this tile
