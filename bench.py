@@ -424,7 +424,13 @@ def main():
                                'fbanks (8000 utts, <=%d frames, 80-dim), batch %d per GPU, bucketed by length, '
                                'LAS 256/256/128, tf_rate 0.9, Adadelta' % (args.max_frames, args.batch),
                    'global_batch': world * args.batch, 'max_frames': args.max_frames,
-                   'parallelism': 'dp%d' % world, 'mean_frames_per_utt': round(frames / (args.batch * args.steps), 1)},
+                   'parallelism': 'dp%d' % world, 'mean_frames_per_utt': round(frames / (args.batch * args.steps), 1),
+                   # fp32 tensors, fp32 accumulation; where a product runs on the matrix cores it is formed as six
+                   # bf16 MFMAs over the exact three-way split of both fp32 operands unless
+                   # SSASR_GEMM_X6=0 -- same results to fp32 rounding, checked against float64 in tests/
+                   'matrix_products': ('fp32 instruction (v_mfma_f32_16x16x4_f32)'
+                                       if os.environ.get('SSASR_GEMM_X6') == '0' else
+                                       'fp32 as 6 bf16 MFMAs on exact 3-way operand split, fp32 accumulate')},
         'final_loss': round(last_loss, 5),
     }
     if not args.no_roofline:
