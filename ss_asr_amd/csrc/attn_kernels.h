@@ -128,8 +128,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_fast_kernel(AttnFwd p) {
       v = fmaf(c[i].y, q4.y, v);
       v = fmaf(c[i].z, q4.z, v);
       v = fmaf(c[i].w, q4.w, v);
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      v = half_sum(v);
       e[pz * RPT + i] = v;
       if (hw + 8 * (i + RPT * pz) < len) m = fmaxf(m, v);
     }
@@ -226,8 +225,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_long_kernel(AttnFwd p) {
       v = fmaf(c[i].y, q4.y, v);
       v = fmaf(c[i].z, q4.z, v);
       v = fmaf(c[i].w, q4.w, v);
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      v = half_sum(v);
       const int t = t0 + hw + 8 * i;
       if (l32 == 0 && t < len) sE[t] = v;
     }
@@ -405,10 +403,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_split_kernel(AttnSplit p) {
     e[i] = fmaf(c[i].w, q4.w, v);
   }
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) {
-#pragma unroll
-    for (int i = 0; i < RPH; ++i) e[i] += __shfl_xor(e[i], o, 64);
-  }
+  for (int i = 0; i < RPH; ++i) e[i] = half_sum(e[i]);      // independent DPP chains: the compiler interleaves them
   if (l32 == 0) {         // raw energies of this workgroup's rows, for its alphas at the end
 #pragma unroll
     for (int i = 0; i < RPH; ++i) sW[hw + 8 * i] = e[i];
@@ -572,8 +567,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_kernel(AttnFwd p) {
         acc = fmaf(c.z, qq.z, acc);
         acc = fmaf(c.w, qq.w, acc);
       }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      acc = half_sum(acc);
       if (l32 == 0) sE[t] = acc;
     }
   }

@@ -85,16 +85,48 @@ __device__ __forceinline__ void x6_planes(const float4& lo, const float4& hi, bf
   for (int p = 0; p < 3; ++p) pl[p] = __builtin_bit_cast(bf16x8, make_uint4(u[p][0], u[p][1], u[p][2], u[p][3]));
 }
 
-// 64-lane butterfly reductions (wave64).
+// Wave reductions on the DPP network (v_add_f32_dpp: quad_perm, row_half_mirror, row_mirror) and
+// gfx950's row / half swaps (v_permlane16_swap, v_permlane32_swap): six vector instructions and no
+// LDS round trip, where __shfl_xor compiles to one ds_bpermute_b32 per stage.  Every lane ends with
+// the same bits (each stage adds the same two partial sums in both partners).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float swap16_other(float v, float& mine) {   // the partner row's value (rows 0<->1, 2<->3)
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  mine = __uint_as_float(r[0]);
+  return __uint_as_float(r[1]);
+}
+// sum / max over each 32-lane half of the wave, result in every lane of the half
+__device__ __forceinline__ float half_sum(float v) {
+  v += dpp_move<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);      // row_half_mirror: the other quad of the 8
+  v += dpp_move<0x140>(v);      // row_mirror: the other 8 of the 16
+  float a;
+  const float b = swap16_other(v, a);
+  return a + b;
+}
+__device__ __forceinline__ float half_max(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
+  float a;
+  const float b = swap16_other(v, a);
+  return fmaxf(a, b);
+}
+// over all 64 lanes
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = half_sum(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = half_max(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 // ---- internal launchers shared between translation units -----------------

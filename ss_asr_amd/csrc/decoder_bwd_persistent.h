@@ -246,12 +246,9 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
         }
         dal[kr] = acc;
       }
-      // the 8 rows' cross-lane sums are independent chains: stage by stage, not row by row
+      // the 8 rows' cross-lane sums within their 32-lane groups: independent DPP chains (common.h, half_sum)
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-#pragma unroll
-        for (int kr = 0; kr < RPG; ++kr) dal[kr] += __shfl_xor(dal[kr], o, 64);      // within the 32-lane group
-      }
+      for (int kr = 0; kr < RPG; ++kr) dal[kr] = half_sum(dal[kr]);
 #pragma unroll
       for (int kr = 0; kr < RPG; ++kr) {
         const int tl = hw + 8 * kr;

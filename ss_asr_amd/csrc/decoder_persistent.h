@@ -248,12 +248,9 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
         v = fmaf(c[i].z, q4.z, v);
         e[i] = fmaf(c[i].w, q4.w, v);
       }
-      // the 16 rows' cross-lane sums are independent chains: stage by stage, not row by row
+      // the 16 rows' cross-lane sums: independent DPP chains (common.h, half_sum), no LDS round trips
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] += __shfl_xor(e[i], o, 64);
-      }
+      for (int i = 0; i < 16; ++i) e[i] = half_sum(e[i]);
 #pragma unroll
       for (int i = 0; i < 16; ++i)
         if (hw + 8 * i < len) m = fmaxf(m, e[i]);
