@@ -1,4 +1,5 @@
 // Development check of the DPP / permlane-swap reductions of csrc/common.h against host sums.
+// Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -I ss_asr_amd/csrc tools/dpp_check.hip -o tools/dpp_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
