@@ -570,8 +570,9 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
   // One LDS stage (48 KB at 128 x 128, so that two workgroups share a CU and one's MFMAs cover the
   // other's operand split): fragments -> registers, barrier, then the MFMAs with the next tile's
   // split + store between them, barrier.  (Two stages with one workgroup per CU: 141 TF against 171
-  // on 4096^3; a second register set that loads two K steps ahead pushes the kernel past 256 VGPRs,
-  // one wave per SIMD: 109 TF.)
+  // on 4096^3; a second register set that loads two K steps ahead pushes the 128 x 128 kernel past
+  // 256 VGPRs, one wave per SIMD: 109 TF -- and on 64 x 64 tiles, which have the registers for it, the
+  // same thing ran the layer-2 input projection at 124 instead of 144 TF.)
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) {
