@@ -345,6 +345,21 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       wc[t][g] = make_float4(w[0], w[D + E], w[2 * (D + E)], w[3 * (D + E)]);
     }
   }
+  // The two products of the step run on the bf16 matrix pipeline in the split form of gemm.hip /
+  // the encoder BPTT ("bf16 x 6": exact three-way split of both fp32 operands, fp32 accumulation):
+  // K block b of 32 = gates 2b, 2b + 1 of this workgroup's 16 units, lane (q, r) holds k = 8q + e
+  // (e < 4: gate 2b, unit 4q + e; else gate 2b + 1, unit 4q + e - 4) -- the order both the weight
+  // registers above and the gate derivatives in sG already have.  72 MFMAs of 16 cycles per wave and
+  // step instead of 96 of 32.
+  bf16x8 waA[2][2][3], wcA[4][2][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) x6_planes(wa[t][2 * b], wa[t][2 * b + 1], waA[t][b]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) x6_planes(wc[t][2 * b], wc[t][2 * b + 1], wcA[t][b]);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {    // W_phi term: A[m = unit][k = a], k-blocks 2 * wave + k
     const float* w = p.w_phi + (int64_t)(16 * (2 * wave + k) + 4 * q) * D + 16 * tile + r;
@@ -472,18 +487,47 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       float4 bg[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) bg[g] = sG[g * 64 + lane];
-      f32x4 aa[2], ac[4];
+      f32x4 aa[2], ac[4], ac2[4];
 #pragma unroll
       for (int k = 0; k < 2; ++k) aa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ac[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // dctx partial tiles first: the attention stage is next on the critical path
-#define CB_STEP(C)                                                                                   \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                  \
-        ac[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[k][g].C, bg[g].C, ac[k], 0, 0, 0);
+      for (int k = 0; k < 4; ++k) { ac[k] = f32x4{0.f, 0.f, 0.f, 0.f}; ac2[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      // dctx partial tiles first: the attention stage is next on the critical path.  The gate
+      // derivatives are split level by level, each level's MFMAs issued as soon as its pieces exist
+      // (b1 -> a1 b1, a2 b1, a3 b1; b2 -> a1 b2, a2 b2; b3 -> a1 b3); the pieces are kept for the dh1 product.
+      bf16x8 piece[3][2];
+      {
+        float v[2][8];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) { CB_STEP(x) CB_STEP(y) CB_STEP(z) CB_STEP(w) }
-#undef CB_STEP
+        for (int kb = 0; kb < 2; ++kb) {
+          const float4 lo = bg[2 * kb], hi = bg[2 * kb + 1];
+          v[kb][0] = lo.x; v[kb][1] = lo.y; v[kb][2] = lo.z; v[kb][3] = lo.w;
+          v[kb][4] = hi.x; v[kb][5] = hi.y; v[kb][6] = hi.z; v[kb][7] = hi.w;
+        }
+#pragma unroll
+        for (int level = 0; level < 3; ++level) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            uint32_t u[4];
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+              u[pr] = x6_pack(v[kb][2 * pr], v[kb][2 * pr + 1]);
+              if (level < 2) { v[kb][2 * pr] -= x6_lo(u[pr]); v[kb][2 * pr + 1] -= x6_hi(u[pr]); }
+            }
+            piece[level][kb] = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
+          }
+#pragma unroll
+          for (int pa = 0; pa + level < 3; ++pa) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              ac[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcA[k][0][pa], piece[level][0], ac[k], 0, 0, 0);
+              ac2[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcA[k][1][pa], piece[level][1], ac2[k], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ac[k] += ac2[k];
+      }
       // [chunk][utterance r][source tile][512 columns]: lane (q, r) holds columns 16 ct + 4 q ..
       const unsigned xcb = (unsigned)t * XC_STEP + (unsigned)(((chunk * 16 + r) * 16 + tile) * E + 4 * q) * 4;
 #pragma unroll
@@ -491,16 +535,19 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ac[k]), rxc,
                                                (int)(xcb + (unsigned)(16 * (half * 16 + 4 * wave + k)) * 4), 0, 16);
       if (t > 0) {
-        // two accumulators per tile: 2 tiles alone would chain each MFMA on the previous one
+        // one accumulator per (tile, K block): 2 tiles alone would chain each MFMA on the previous one
         f32x4 ab2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#define CB_STEP(C)                                                                                   \
-        _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                              \
-          aa[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k][g].C, bg[g].C, aa[k], 0, 0, 0);         \
-          ab2[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k][g + 1].C, bg[g + 1].C, ab2[k], 0, 0, 0); \
-        }
 #pragma unroll
-        for (int g = 0; g < 4; g += 2) { CB_STEP(x) CB_STEP(y) CB_STEP(z) CB_STEP(w) }
-#undef CB_STEP
+        for (int level = 0; level < 3; ++level) {
+#pragma unroll
+          for (int pa = 0; pa + level < 3; ++pa) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              aa[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(waA[k][0][pa], piece[level][0], aa[k], 0, 0, 0);
+              ab2[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(waA[k][1][pa], piece[level][1], ab2[k], 0, 0, 0);
+            }
+          }
+        }
         aa[0] += ab2[0];
         aa[1] += ab2[1];
         const unsigned xab = (unsigned)t * XA_STEP + (unsigned)chunk * (16 * 16 * TILE_B) + (unsigned)tile * TILE_B +
