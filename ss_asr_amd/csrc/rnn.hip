@@ -126,7 +126,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
                                  : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 2, 5>);
       else if (sentinel_mode) kfn = nb == 1 ? SSASR_FWD_FN_PICK(true, 1) : SSASR_FWD_FN_PICK(true, 2);
       else kfn = nb == 1 ? SSASR_FWD_FN_PICK(false, 1) : SSASR_FWD_FN_PICK(false, 2);
-      if (!grid_fits(kfn, 320, 0, (H / 4) * 2 * chunks)) { fits = false; fuse_in = false; }
+      if (!grid_fits(kfn, FWD_THREADS, 0, (H / 4) * 2 * chunks)) { fits = false; fuse_in = false; }
     }
 #undef SSASR_FWD_FN_PICK
 #undef SSASR_FWD_FN
@@ -148,7 +148,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
       p.delay = persist_delay(opt.delay_fwd, 24);
       p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
-      dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
+      dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(FWD_THREADS);   // 4 recurrence waves + the helper
       // exchange by sentinel (default) or by arrival counter (SSASR_PERSISTENT_COUNTER=1, for A/B)
       const bool sentinel = sentinel_mode;
       if (sentinel && !armed)
@@ -210,11 +210,11 @@ static bool fwd_persistent_shape_ok(int64_t S, int64_t N, int64_t H) {
   const void* fn = nb == 1 ? (kpw == 1 ? SSASR_FN(1, 1) : kpw == 2 ? SSASR_FN(2, 1) : kpw == 4 ? SSASR_FN(4, 1) : SSASR_FN(8, 1))
                            : (kpw == 1 ? SSASR_FN(1, 2) : kpw == 2 ? SSASR_FN(2, 2) : kpw == 4 ? SSASR_FN(4, 2) : SSASR_FN(8, 2));
 #undef SSASR_FN
-  if (!grid_fits(fn, 320, 0, (H / 4) * 2 * chunks)) return false;
+  if (!grid_fits(fn, FWD_THREADS, 0, (H / 4) * 2 * chunks)) return false;
   if (kpw == 4 && sen) {      // the first layer's variant (fused input projection) is the larger kernel
     const void* ff = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 1, 5>)
                              : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 2, 5>);
-    if (!grid_fits(ff, 320, 0, (H / 4) * 2 * chunks)) return false;
+    if (!grid_fits(ff, FWD_THREADS, 0, (H / 4) * 2 * chunks)) return false;
   }
   return true;
 }

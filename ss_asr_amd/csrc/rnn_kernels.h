@@ -522,8 +522,16 @@ struct PersistPacer {
 // per column tile while the recurrence waves wait for their operand loads: the input projection
 // GEMM and its 2 x 0.4 GB of pre-activation traffic disappear.  A fragment: row 4 * unit + gate of
 // this workgroup's 16 gate rows, so that D leaves unit q's four gates in lane (q, column).
+#ifndef SSASR_FWD_HELPER_WAVE
+#define SSASR_FWD_HELPER_WAVE 5
+#endif
+// Waves of a workgroup go to the four SIMDs round-robin: the helper as wave 4 shares SIMD 0 with wave
+// 0 -- the wave that also runs the gate epilogue and the publishing store.  As wave 5 (wave 4 exits
+// at once) it shares SIMD 1 with a wave that only loads and multiplies.
+constexpr int FWD_HELPER_WAVE = SSASR_FWD_HELPER_WAVE;
+constexpr int FWD_THREADS = 64 * (FWD_HELPER_WAVE + 1);
 template <int KPW, bool SENTINEL, int NB, int KI = 0>   // k-blocks per wave = H / 64; NB x 16 batch columns per workgroup
-__global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
+__global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * NB * 64];
   // step results staged for the helper wave: [i, f, g, o, c, h][column][4 units]
   __shared__ __attribute__((aligned(16))) float stage[6][16 * NB][4];
@@ -531,6 +539,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   __shared__ int missed;                         // a wave of this step had to re-fetch (feeds the pacer)
   float* sH = &stage[5][0][0];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (wave >= 4 && wave != FWD_HELPER_WAVE) return;      // filler waves: they only shift the helper's SIMD
   if (tid == 0) missed = 0;
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(320) void lstm_enc_fwd_persistent_kernel(EncPersist
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)xbytes, 0x00020000);
   const int u = 4 * tile + q;                   // epilogue lanes and helper lanes: unit u, column n0 + 16 * bt + r
 
-  if (wave == 4) {
+  if (wave == FWD_HELPER_WAVE) {
     // ------------------------------ helper wave ------------------------------
     PersistPacer pacer{e.delay, 0};
     float nadd[NB][4];

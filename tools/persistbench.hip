@@ -21,7 +21,7 @@ __device__ unsigned long long g_trace[TR_WG * TR_N * TR_SLOTS];
 __device__ unsigned g_retry[TR_WG * 4 * 4];   // per (workgroup, wave): steps needing 0, 1, 2, 3+ re-fetch rounds
 #define SSASR_PRETRY(tries) do { if ((threadIdx.x & 63) == 0) \
   atomicAdd(&g_retry[((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + (threadIdx.x >> 6)) * 4 + ((tries) > 3 ? 3 : (tries))], 1u); } while (0)
-#define SSASR_PTRACE_H(step, slot) do { if (threadIdx.x == 256 && (step) >= TR_LO && (step) < TR_LO + TR_N) { \
+#define SSASR_PTRACE_H(step, slot) do { if ((threadIdx.x & 63) == 0 && threadIdx.x >= 256 && (step) >= TR_LO && (step) < TR_LO + TR_N) { \
   unsigned long long t_; asm volatile(SSASR_CLK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
   g_trace[((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * TR_N + ((step) - TR_LO)) * TR_SLOTS + (slot)] = t_; } } while (0)
 #include "rnn_kernels.h"
@@ -129,8 +129,8 @@ int main(int argc, char** argv) {
     const bool localF = getenv("LOCAL") != nullptr && 2 * chF <= 8;
     pf.local = localF ? 2 : 0; pf.nchunk = chF;
     const dim3 gridF = localF ? dim3(8 * (H / 4)) : dim3(H / 4, 2, chF);
-    if (nbF == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 1>), gridF, dim3(320), 0, st, pf);
-    else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 2>), gridF, dim3(320), 0, st, pf);
+    if (nbF == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 1>), gridF, dim3(FWD_THREADS), 0, st, pf);
+    else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 2>), gridF, dim3(FWD_THREADS), 0, st, pf);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
