@@ -17,7 +17,7 @@ bs = []
 for x, y, lens in config2_batches(8, batch_size=32, feat_dim=80, seed=1, rank=0, hi=800):
     _, al = label_geometry(y); bs.append((x.to(dev), y.to(dev), lens, al))
 out = []
-for i in range(240):
+for i in range(int(os.environ.get("SOAK_STEPS", "240"))):
     l = st(*bs[i % 8])
     if i % 40 == 39: out.append(round(float(l), 4))
 print(os.environ.get('SSASR_GEMM_X6', '1'), out, st.finish(), st.skipped_steps)
