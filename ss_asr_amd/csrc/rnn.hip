@@ -530,6 +530,63 @@ static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgate
   return ssasr_launch_colsum(dG + s_lo * N * 4 * H, (s_hi - s_lo) * N, (int)(4 * H), 4 * H, db, st, db2);
 }
 
+// Both directions' weight gradients of one step range each ([lo0, hi0) of the forward direction,
+// [lo1, hi1) of the reverse one, equal lengths) as the two batches of ONE launch per product: these
+// products are short (a BPTT segment of the first layer: 17 us each, mostly latency), and what
+// follows the last segment of a layer is exposed time at the end of the step.
+static int wgrad_pair_range(int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1, const float* dgates, const float* x,
+                            int64_t xs_s, int64_t xs_n, const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
+                            float* const dwih[2], float* const dwhh[2], float* const db[2], float* const db2[2],
+                            hipStream_t st, bool beside) {
+  const int64_t rows = S * N;
+  // the recurrent product skips the step without a predecessor: s = 0 (forward) / s = S - 1 (reverse)
+  const int64_t a0f = lo0 > 1 ? lo0 : 1, a1f = hi0;
+  const int64_t a0r = lo1, a1r = hi1 < S - 1 ? hi1 : S - 1;
+  const bool same = hi0 - lo0 == hi1 - lo1 && a1f - a0f == a1r - a0r && hi0 > lo0;
+  if (!same) {
+    int rc = wgrad_dir_range(0, lo0, hi0, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[0], dwhh[0], db[0], db2[0], st, beside);
+    if (rc) return rc;
+    return wgrad_dir_range(1, lo1, hi1, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], st, beside);
+  }
+  int rc;
+  {           // dW_ih[d] += dG_d[range_d]^T . X[range_d]
+    GemmDesc g{};
+    g.A = dgates + lo0 * N * 4 * H; g.ma = rm_dense(4 * H);
+    g.sa = rows * 4 * H + (lo1 - lo0) * N * 4 * H;
+    g.B = x + lo0 * xs_s; g.mb = RowMap{0, N, xs_s, xs_n};
+    g.sb = (lo1 - lo0) * xs_s;
+    g.C = dwih[0]; g.mc = rm_dense(I);
+    g.sc = dwih[1] - dwih[0];
+    g.M = (int)(4 * H); g.N = (int)I; g.K = (int)((hi0 - lo0) * N);
+    g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 2;
+    const int64_t tiles = 2 * ((4 * H + 63) / 64) * ((I + 63) / 64);
+    int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
+    if (g.K < 64 * sk) sk = 1;
+    g.splitk = sk;
+    if (beside) ssasr_gemm_beside_recurrence(g);
+    if ((rc = ssasr_launch_gemm(g, st))) return rc;
+  }
+  if (a1f > a0f) {           // dW_hh[d] += sum_s dG_d[s]^T . h_d[s_prev]
+    GemmDesc g{};
+    g.A = dgates + a0f * N * 4 * H; g.ma = rm_dense(4 * H);
+    g.sa = rows * 4 * H + (a0r - a0f) * N * 4 * H;
+    g.B = hs + (a0f - 1) * N * H; g.mb = rm_dense(H);
+    g.sb = rows * H + ((a0r + 1) - (a0f - 1)) * N * H;
+    g.C = dwhh[0]; g.mc = rm_dense(H);
+    g.sc = dwhh[1] - dwhh[0];
+    g.M = (int)(4 * H); g.N = (int)H; g.K = (int)((a1f - a0f) * N);
+    g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = 2;
+    const int64_t tiles = 2 * ((4 * H + 63) / 64) * ((H + 63) / 64);
+    int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
+    if (g.K < 64 * sk) sk = 1;
+    g.splitk = sk;
+    if (beside) ssasr_gemm_beside_recurrence(g);
+    if ((rc = ssasr_launch_gemm(g, st))) return rc;
+  }
+  if ((rc = ssasr_launch_colsum(dgates + lo0 * N * 4 * H, (hi0 - lo0) * N, (int)(4 * H), 4 * H, db[0], st, db2[0]))) return rc;
+  return ssasr_launch_colsum(dgates + rows * 4 * H + lo1 * N * 4 * H, (hi1 - lo1) * N, (int)(4 * H), 4 * H, db[1], st, db2[1]);
+}
+
 extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t xs_s, int64_t xs_n,
                                   const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
                                   float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
@@ -678,11 +735,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
     SSASR_HIP(hipStreamWaitEvent(side, done[k], 0));
     // iterations [i0, i1) cover steps S - i1 .. S - i0 - 1 of the forward direction and i0 .. i1 - 1 of the reverse
-    if ((rc = wgrad_dir_range(0, S - i1, S - i0, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[0], dwhh[0], db[0], db2[0],
-                              side, true)))
-      return rc;
-    if ((rc = wgrad_dir_range(1, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], side,
-                              true)))
+    if ((rc = wgrad_pair_range(S - i1, S - i0, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih, dwhh, db, db2, side, true)))
       return rc;
   }
   return SSASR_OK;
