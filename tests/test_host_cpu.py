@@ -48,6 +48,8 @@ def test_argument_errors_are_negative_and_need_no_gpu():
     assert lib.ssasr_clip_adadelta_ws(10269874) == 1 + (10269874 + 4095) // 4096
     # diagnostic switches: known names round-trip, unknown names are refused
     assert _lib.set_option('SSASR_GEMM_TILE', 64) == 0 and _lib.set_option('SSASR_GEMM_TILE', 0) == 64
+    # matrix products default to the split-bf16 form; 0 selects the fp32 MFMA instruction
+    assert _lib.set_option('SSASR_GEMM_X6', 0) == 1 and _lib.set_option('SSASR_GEMM_X6', 1) == 0
     assert lib.ssasr_set_option(b'SSASR_NO_SUCH_SWITCH', 1) < 0
 
 
