@@ -415,9 +415,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
 // float64): this is a choice of instruction, not of precision.
 //
 // Operands are split where the tile goes from registers to LDS.  LDS image of a K-contiguous
-// operand: three planes [rows][32 k] of bf16, 64-byte rows, and the four 16-byte chunks of a row XOR-ed with bits 2-3 of r so that the
-// sixteen rows a ds_read_b128 fragment read takes at one k offset fall on different banks (without
-// it rows r and r + 4 collide: SQ_LDS_BANK_CONFLICT was a third of the LDS-active cycles).
+// operand: three planes [rows][32 k] of bf16, 64-byte rows, the four 16-byte chunks of a row XOR-ed
+// with bits 2-3 of the row so that the sixteen rows a ds_read_b128 fragment read takes at one k
+// offset fall on different banks (without it rows r and r + 4 collide and SQ_LDS_BANK_CONFLICT is a
+// third of the LDS-active cycles; the kernel's time did not change with it -- LDS is not its bound).
 // ---------------------------------------------------------------------------------------------
 constexpr int XROW = BK * 2;                                  // bytes per LDS row of one plane
 template <int BMN> struct XGeom {
