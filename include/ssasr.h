@@ -67,7 +67,9 @@ int ssasr_events_destroy(void* handle);
  * not (spread placement), negative = HIP error.  Until it has been called the spread placement is used. */
 int ssasr_probe_placement(void* stream);
 
-/* C[b] = act(alpha * op(A[b]) . op(B[b]) + bias) + beta * C[b], fp32 MFMA.
+/* C[b] = act(alpha * op(A[b]) . op(B[b]) + bias) + beta * C[b]; fp32 operands, fp32 accumulation on
+ * the matrix cores (products as six bf16 MFMAs on the exact three-way operand split, or the fp32
+ * MFMA instruction with SSASR_GEMM_X6=0: the same results to fp32 rounding).
  * ta = 0: A is [M][K] (ld = lda); ta = 1: A is [K][M].
  * tb = 0: B is [N][K] (torch Linear weight layout); tb = 1: B is [K][N].
  * act: 0 none, 1 tanh.  splitk > 1 adds partial products atomically into a
