@@ -114,6 +114,27 @@ def test_backward_and_solver_step_match_reference(golden, name):
                                        rtol=0, err_msg=k)
 
 
+def test_backward_matches_reference_on_the_fp32_mfma_instruction(golden):
+    """The GEMMs' other arithmetic form (SSASR_GEMM_X6 = 0: v_mfma_f32_16x16x4_f32 instead of six
+    bf16 MFMAs on the split operands) against the same reference fixture, same tolerances: both
+    forms are the reference's fp32 arithmetic."""
+    from ss_asr_amd import _lib
+    old = _lib.set_option('SSASR_GEMM_X6', 0)
+    try:
+        fx = golden('full_b4')
+        model = build(fx)
+        _, _, _, loss = forward(fx, model)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(fx['loss'])) < 1e-4
+        params = dict(model.named_parameters())
+        names = [str(n) for n in fx['param_names']]
+        got = np.array([params[n].grad.double().norm().item() for n in names])
+        np.testing.assert_allclose(got, fx['grad_norms'], rtol=1e-3, atol=1e-6)
+    finally:
+        _lib.set_option('SSASR_GEMM_X6', old)
+
+
 def test_backward_matches_reference_in_both_bptt_placements(golden):
     """The K-split BPTT runs XCD-locally (one exchange group per XCD, hand-offs through that XCD's
     L2, side-stream GEMMs on the other XCDs) when the placement probe allows it, else spread over
