@@ -100,14 +100,21 @@ def attention_roofline(device, B=32, T=100, A=128, E=512, D=256, iters=400):
     side.wait_stream(torch.cuda.current_stream())
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
+        # split-T form (T > 128): the workspace's two exchange buffers alternate call by call
+        # (allocated and armed before the capture, on the stream the graph replays on)
+        ws, phase = ops.attn_workspace(B, T, A, E, device)
+        wsp = C.c_void_p(ws.data_ptr()) if ws is not None else None
+        status = torch.zeros(8, device=device, dtype=torch.int32) if ws is not None else None
+        stp = C.c_void_p(status.data_ptr()) if ws is not None else None
+        side.synchronize()
         with torch.cuda.graph(graph, stream=side):
             cst = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            # split-T form (T > 128): the workspace's two exchange buffers alternate call by call
-            ws, phase = ops.attn_workspace(B, T, A, E, device, calls=iters)
-            wsp = C.c_void_p(ws.data_ptr()) if ws is not None else None
             assert iters % 2 == 0         # every replay then starts on the same, re-armed buffer
             for i in range(iters):
-                lib.ssasr_attn_step_fwd(*args, B, T, A, E, D, *outs, wsp, (phase + i) & 1, cst)
+                rc = lib.ssasr_attn_step_fwd(*args, B, T, A, E, D, *outs, wsp, (phase + i) & 1, stp, cst)
+                assert rc == 0, rc
+            if ws is not None:
+                ops.attn_workspace_advance(B, T, A, E, device, iters)
     torch.cuda.current_stream().wait_stream(side)
     graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -117,6 +124,8 @@ def attention_roofline(device, B=32, T=100, A=128, E=512, D=256, iters=400):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
+    if status is not None and int(status.abs().sum()) != 0:
+        raise RuntimeError(ops.describe_status(status.tolist()))
     s = 4
     nbytes = B * T * (A + E) * s + B * T * (s + 1) + B * (D + E) * s + D * A * s
     achieved = nbytes / (us * 1e-6) / 1e9

@@ -156,11 +156,15 @@ int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_t ys_n, con
  * in `gates`: dW_ih = dG^T X, dW_hh = sum_s dG[s]^T h[s_prev], db = column sums.
  * accumulate = 0 overwrites, 1 adds (e.g. straight into optimizer-zeroed
  * gradient buffers).  db2_* (optional) gets a second copy of the bias
- * gradient.  Not on the critical path of backward: may run on another stream. */
+ * gradient.  Not on the critical path of backward: may run on another stream.
+ * beside != 0: the products are launched while a persistent recurrence of this library runs on
+ * another stream of the same device; with the XCD-local BPTT placement (ssasr_probe_placement,
+ * SSASR_BPTT_LOCAL) their workgroups then keep to the XCDs the recurrence leaves free.  Placement
+ * only: results are the same for either value; pass 0 when nothing else is running. */
 int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t xs_s, int64_t xs_n,
                        const float* hs, int64_t S, int64_t N, int64_t I, int64_t H, float* dw_ih_f,
                        float* dw_hh_f, float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
-                       float* db_r, float* db2_r, int accumulate, void* stream);
+                       float* db_r, float* db2_r, int accumulate, int beside, void* stream);
 
 /* One nn.LSTMCell step (src/asr.py:320-324); input given as column blocks
  * x1 | x2 (x2 may be NULL).  gates [N][4H] receives the activated i,f,g,o. */
@@ -196,18 +200,25 @@ int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat, int64_t r
  * enc_len int32[B].  Two launches: q [B][A] = tanh(phi(state)) (small MFMA
  * kernel), then energies + masked softmax + context: att [B][T], ctx [B][E].
  * state == NULL skips the first launch and takes q as an input.
- * ws: optional workspace of ssasr_attn_step_ws_floats(B, T, A, E) floats (0: the shape has no
- * use for one) that enables the split-T form for long encoder outputs (T > 128 at A = 128,
- * E = 512): frames of an utterance spread over several workgroups (comp and feat are streamed
- * exactly once, by >= 256 workgroups), partial softmaxes exchanged through the workspace inside
- * the launch.  ws is two exchange buffers: a call uses buffer ws_phase & 1 and re-arms the other.
+ * ws: optional workspace of ssasr_attn_step_ws_floats(B, T, A, E) floats that selects the
+ * split-T form for long encoder outputs (T > 128 at A = 128, E = 512): frames of an utterance
+ * spread over several workgroups (comp and feat are streamed exactly once, by >= 256 workgroups),
+ * partial softmaxes exchanged through the workspace inside the launch.  The query returns 0 when
+ * the shape, the options or the device (every workgroup of the grid must be resident at once) do
+ * not take that form; then ws must be NULL.  With ws the split form is the only form: a NULL
+ * ws_status, misaligned operands (16 bytes) or a shape whose query is 0 are argument errors, so
+ * that what the caller believes about the workspace's phase is what was launched.
+ * ws is two exchange buffers: a call uses buffer ws_phase & 1 and re-arms the other.
  * EVERY word of ws must hold the fill pattern 0x7FC0DEAD before the first call, and consecutive
- * calls on one workspace must alternate ws_phase (0, 1, 0, ...) and be ordered on one stream. */
+ * calls on one workspace must alternate ws_phase (0, 1, 0, ...) and be ordered on one stream.
+ * ws_status: int32[1], zero on entry (required with ws); non-zero after the stream has drained
+ * means a hand-off of the launch timed out and att / ctx are not to be trusted (the word holds
+ * 0x40000000 | 6 << 24 | workgroup << 12 | 0xfff). */
 int64_t ssasr_attn_step_ws_floats(int64_t B, int64_t T, int64_t A, int64_t E);
 int ssasr_attn_step_fwd(const float* state, const float* w_phi, const float* comp,
                         const float* feat, const int32_t* enc_len, int64_t B, int64_t T, int64_t A,
                         int64_t E, int64_t D, float* q, float* att, float* ctx, float* ws, int ws_phase,
-                        void* stream);
+                        int32_t* ws_status, void* stream);
 
 /* Backward of one step given dctx [B][E] and datt [B][T] (may be NULL):
  * de [B][T] (derivative w.r.t. the masked energies) and dqpre [B][A]
@@ -258,7 +269,8 @@ typedef struct ssasr_decoder {
   int32_t ws_armed;                      /* != 0: ws_hx1, ws_hx2, ws_qx and ctx already hold the fill
                                           * pattern 0x7FC0DEAD (written on the same stream)  */
   float* ws_attn;                        /* optional: ssasr_attn_step_ws_floats(B, T, A, E) floats holding the fill
-                                          * pattern 0x7FC0DEAD, for the per-step loop's attention (T > 128)    */
+                                          * pattern 0x7FC0DEAD, for the per-step loop's attention (T > 128);
+                                          * needs ws_sync (time-outs are reported in ws_sync[5])                */
   int32_t ws_attn_phase;                 /* phase of step 0 (step t uses ws_attn_phase + t): the buffer the
                                           * previous call on this workspace did NOT use last                */
 } ssasr_decoder;

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -65,7 +65,7 @@ SIGNATURES = {
     'ssasr_attn_precompute_bwd': (I32, [P, P, P, P, I64, I64, I64, P, P, P, P]),
     'ssasr_attn_precompute_wgrad': (I32, [P, P, I64, I64, I64, P, P, I32, I32, P]),
     'ssasr_attn_step_ws_floats': (I64, [I64, I64, I64, I64]),
-    'ssasr_attn_step_fwd': (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, I32, P]),
+    'ssasr_attn_step_fwd': (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, I32, P, P]),
     'ssasr_attn_step_bwd': (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P, P, P]),
     'ssasr_decoder_fwd': (I32, [C.POINTER(Decoder), P]),
     'ssasr_decoder_bwd': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), P]),

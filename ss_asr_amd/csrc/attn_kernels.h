@@ -325,8 +325,26 @@ struct AttnSplit {
   float* ctx;            // ctx[b * ctx_ld + e]
   int64_t ctx_ld;
   float* part;           // [2][B][NS][ATTN_PART] records; buffer `phase` is this call's
+  int* status;           // one word, zero unless a hand-off of this (or an earlier) launch timed out
   int B, T, NS, phase;
+  int drop_slice;        // fault injection for tests (SSASR_TEST_DROP_TILE, -1 = off): slice `drop_slice`
+                         // of utterance 0 never publishes its record
 };
+
+// Bounded wait of the split kernel's gather (cf. persist_give_up, rnn_kernels.h): the first wave that
+// gives up records kernel 6 + its workgroup in the status word; every other wave looks at that word
+// on its 8th retry and every 256th after it, so a launch with a missing producer drains quickly.
+constexpr int ATTN_PK_SPLIT = 6;
+__device__ __forceinline__ bool attn_give_up(unsigned tries, unsigned max_tries, int* status) {
+  if (tries > max_tries) {
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
+      atomicCAS(status, 0, (int)(0x40000000u | ((unsigned)ATTN_PK_SPLIT << 24) | ((wg & 0xfffu) << 12) | 0xfffu));
+    }
+    return true;
+  }
+  return (tries & 255u) == 8u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
 typedef unsigned attn_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -440,7 +458,9 @@ __global__ __launch_bounds__(256) void attn_step_fwd_split_kernel(AttnSplit p) {
 
   // publish this workgroup's record, write-through
   const unsigned rec = (unsigned)(s * ATTN_PART * 4);
-  if (tid < 128) {            // waves 0, 1: the 2 KB partial context
+  if (b == 0 && s == p.drop_slice) {
+    // fault injection: this record stays unpublished
+  } else if (tid < 128) {     // waves 0, 1: the 2 KB partial context
     float4 v = *reinterpret_cast<const float4*>(sRed + 4 * tid);
 #pragma unroll
     for (int g = 1; g < 8; ++g) {
@@ -471,7 +491,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_split_kernel(AttnSplit p) {
   const bool want = piece || pair;
   attn_u32x4 raw = want ? attn_ld_raw(rp, goff) : attn_u32x4{0u, 0u, 0u, 0u};
   for (unsigned tries = 0; __any(want && attn_unset(raw)); ++tries) {
-    if (tries > MAX_TRIES) break;
+    if (attn_give_up(tries, MAX_TRIES, p.status)) break;      // reported: the host raises (ops.check_persistent_status)
     __builtin_amdgcn_s_sleep(2);
     if (want && attn_unset(raw)) raw = attn_ld_raw(rp, goff);
   }

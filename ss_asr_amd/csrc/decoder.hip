@@ -15,7 +15,7 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 10; }
+extern "C" int ssasr_abi_version(void) { return 11; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));
@@ -106,33 +106,47 @@ bool attn_dims_ok(int64_t B, int64_t T, int64_t A, int64_t E, int64_t D) {
 
 bool dec_grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t workgroups);
 
-// ws / phase: optional workspace of the split-T form (ssasr_attn_step_ws_floats) and which of its
-// two exchange buffers this call uses
-int launch_attn_fwd(const AttnFwd& p, hipStream_t st, float* ws = nullptr, int phase = 0) {
+const void* attn_split_fn(int rph) {
+  return rph == 6 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<6>)
+       : rph == 4 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<4>)
+       : rph == 3 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<3>)
+                  : reinterpret_cast<const void*>(attn_step_fwd_split_kernel<2>);
+}
+
+// Whether a shape takes the split-T form on this device with the current options: the shape test,
+// and every workgroup of the grid resident at once (the workgroups of an utterance wait for each other).
+bool attn_split_taken(int64_t B, int64_t T, int64_t A, int64_t E) {
+  if (!attn_split_ok(B, T, A, E)) return false;
+  const int rph = attn_split_rph((int)B, (int)T);
+  return dec_grid_fits(attn_split_fn(rph), 256, 0, (int64_t)attn_split_ns((int)B, (int)T) * B);
+}
+
+// ws / phase / status: workspace of the split-T form (ssasr_attn_step_ws_floats), which of its two
+// exchange buffers this call uses, and the word a timed-out hand-off is reported in.  With a
+// workspace the split form is the ONLY form: a shape, alignment or device that cannot take it is an
+// argument error (the caller's phase bookkeeping would otherwise drift from what was launched).
+int launch_attn_fwd(const AttnFwd& p, hipStream_t st, float* ws = nullptr, int phase = 0, int* status = nullptr) {
   const dim3 grid((unsigned)p.B, (unsigned)p.nch), block(256);
   const bool fast = p.A == 128 && p.E == 128 * p.nch && aligned16(p.comp) && aligned16(p.feat) &&
                     (!p.q || aligned16(p.q));
-  if (fast && ws && aligned16(ws) && aligned16(p.ctx) && p.ctx_ld % 4 == 0 && attn_split_ok(p.B, p.T, p.A, p.E)) {
+  if (ws) {
+    if (!status || !fast || !aligned16(ws) || !aligned16(p.ctx) || p.ctx_ld % 4 != 0 ||
+        !attn_split_taken(p.B, p.T, p.A, p.E))
+      return SSASR_EARG;
     AttnSplit sp{};
     sp.q = p.q; sp.comp = p.comp; sp.feat = p.feat; sp.lens = p.lens;
     sp.att = p.att; sp.att_sb = p.att_sb; sp.ctx = p.ctx; sp.ctx_ld = p.ctx_ld;
-    sp.part = ws;
+    sp.part = ws; sp.status = status;
     sp.B = p.B; sp.T = p.T; sp.phase = phase & 1;
+    sp.drop_slice = ssasr_options().test_drop_tile;
     const int rph = attn_split_rph(p.B, p.T);
     sp.NS = (p.T + 8 * rph - 1) / (8 * rph);
     const dim3 sgrid((unsigned)sp.NS, (unsigned)p.B);
-    const void* fn = rph == 6 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<6>)
-                   : rph == 4 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<4>)
-                   : rph == 3 ? reinterpret_cast<const void*>(attn_step_fwd_split_kernel<3>)
-                              : reinterpret_cast<const void*>(attn_step_fwd_split_kernel<2>);
-    // the workgroups of an utterance wait for each other: only when the whole grid is resident
-    if (dec_grid_fits(fn, 256, 0, (int64_t)sp.NS * p.B)) {
-      if (rph == 6) hipLaunchKernelGGL(attn_step_fwd_split_kernel<6>, sgrid, block, 0, st, sp);
-      else if (rph == 4) hipLaunchKernelGGL(attn_step_fwd_split_kernel<4>, sgrid, block, 0, st, sp);
-      else if (rph == 3) hipLaunchKernelGGL(attn_step_fwd_split_kernel<3>, sgrid, block, 0, st, sp);
-      else hipLaunchKernelGGL(attn_step_fwd_split_kernel<2>, sgrid, block, 0, st, sp);
-      return SSASR_OK;
-    }
+    if (rph == 6) hipLaunchKernelGGL(attn_step_fwd_split_kernel<6>, sgrid, block, 0, st, sp);
+    else if (rph == 4) hipLaunchKernelGGL(attn_step_fwd_split_kernel<4>, sgrid, block, 0, st, sp);
+    else if (rph == 3) hipLaunchKernelGGL(attn_step_fwd_split_kernel<3>, sgrid, block, 0, st, sp);
+    else hipLaunchKernelGGL(attn_step_fwd_split_kernel<2>, sgrid, block, 0, st, sp);
+    return SSASR_OK;
   }
   if (fast && p.T <= 128) hipLaunchKernelGGL(attn_step_fwd_fast_kernel<1>, grid, block, 0, st, p);
   else if (fast && p.T <= 256) hipLaunchKernelGGL(attn_step_fwd_fast_kernel<2>, grid, block, 0, st, p);
@@ -165,21 +179,22 @@ extern "C" int ssasr_debug_attn_trace(void* host_out, int64_t words) {
 #endif
 
 extern "C" int64_t ssasr_attn_step_ws_floats(int64_t B, int64_t T, int64_t A, int64_t E) {
-  return attn_split_ok(B, T, A, E) ? attn_split_ws_floats(B, T) : 0;
+  return attn_split_taken(B, T, A, E) ? attn_split_ws_floats(B, T) : 0;
 }
 
 extern "C" int ssasr_attn_step_fwd(const float* state, const float* w_phi, const float* comp,
                                    const float* feat, const int32_t* enc_len, int64_t B, int64_t T,
                                    int64_t A, int64_t E, int64_t D, float* q, float* att,
-                                   float* ctx, float* ws, int ws_phase, void* stream) {
+                                   float* ctx, float* ws, int ws_phase, int32_t* ws_status, void* stream) {
   if (!w_phi || !comp || !feat || !q || !att || !ctx || !attn_dims_ok(B, T, A, E, D)) return SSASR_EARG;
+  if (ws && (!ws_status || ssasr_attn_step_ws_floats(B, T, A, E) == 0)) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   if (state) launch_phi(state, w_phi, q, B, A, D, st);   // state == NULL: q is an input
   AttnFwd p{};
   p.q = q; p.comp = comp; p.feat = feat; p.lens = enc_len;
   p.att = att; p.att_sb = T; p.ctx = ctx; p.ctx_ld = E;
   p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.nch = attn_pick_nch((int)E);
-  launch_attn_fwd(p, st, ws, ws_phase);
+  if (const int rc = launch_attn_fwd(p, st, ws, ws_phase, ws_status)) return rc;
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
@@ -228,6 +243,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   }
   if (any_teacher && (!d.teacher || d.teacher_ld < U + 1)) return SSASR_EARG;
   if (any_sample && !d.uniforms) return SSASR_EARG;
+  if (d.ws_attn && !d.ws_sync) return SSASR_EARG;        // the split-T attention reports time-outs in ws_sync[5]
 
 
   // chars[0] = <sos> = 0 (src/asr.py:73); chars[t] = teacher[:, t] (src/asr.py:95).
@@ -304,7 +320,8 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     p.att = d.att + t * T; p.att_sb = U * T;
     p.ctx = d.ctx + t * B * E; p.ctx_ld = E;
     p.B = (int)B; p.T = (int)T; p.A = (int)A; p.E = (int)E; p.nch = nch;
-    launch_attn_fwd(p, st, d.ws_attn, (int)((d.ws_attn_phase + t) & 1));
+    if ((rc = launch_attn_fwd(p, st, d.ws_attn, (int)((d.ws_attn_phase + t) & 1), d.ws_attn ? d.ws_sync + 5 : nullptr)))
+      return rc;
 
     CellFwdPair c1{};
     {

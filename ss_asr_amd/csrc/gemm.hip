@@ -17,6 +17,7 @@
 // both operands, which lets a K-contiguous operand be fetched with a single
 // ds_read_b128 per 16x16 fragment.
 #include <cstdlib>
+#include "../../include/ssasr.h"
 #include "common.h"
 
 namespace {

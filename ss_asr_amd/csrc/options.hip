@@ -4,6 +4,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include "../../include/ssasr.h"
 #include "common.h"
 
 namespace {

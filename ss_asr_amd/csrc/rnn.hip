@@ -1,6 +1,7 @@
 // Host entry points for the BiLSTM layers and the single LSTM cell step.
 // Kernels: rnn_kernels.h.
 #include <cstdlib>
+#include "../../include/ssasr.h"
 #include "rnn_kernels.h"
 
 constexpr int SSASR_MAX_SEGMENTS = 8;
@@ -185,12 +186,6 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }
-
-extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t xs_s, int64_t xs_n,
-                                  const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
-                                  float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
-                                  float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
-                                  int accumulate, int beside, void* stream);
 
 // The shape half of ssasr_bilstm_fwd's test for its persistent form (the pointer-alignment half is
 // the caller's: torch allocations are 256-byte aligned), residency of the grid included.

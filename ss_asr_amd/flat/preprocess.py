@@ -1,6 +1,8 @@
 """Flat-import shim: the reference's scripts do `import preprocess` with src/ on
-sys.path (src/trainer.py:20-31).  Put this directory first on PYTHONPATH to run
-the reference's src/train.py unchanged against the MI355X implementation."""
+sys.path (src/trainer.py:20-31).  The launcher
+ss_asr_amd/run_reference.py puts this directory at sys.path[0] and runs the reference's
+src/train.py unchanged against the MI355X implementation (PYTHONPATH alone is not enough: the
+script's own directory comes first on sys.path -- INTEGRATION.md section 1)."""
 import os
 import sys
 

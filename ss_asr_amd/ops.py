@@ -17,7 +17,8 @@ from ._lib import check
 _persist_status = []     # int32[8] workspaces of persistent launches not yet checked
 TIMEOUT_MESSAGE = 'ss_asr_amd: a persistent recurrence / decode loop timed out'
 _KERNELS = {1: 'encoder forward recurrence', 2: 'encoder BPTT (K-split)', 3: 'encoder BPTT (gather)',
-            4: 'decode loop forward', 5: 'decoder backward chain'}
+            4: 'decode loop forward', 5: 'decoder backward chain', 6: 'split-T attention step',
+            7: 'decode loop forward (long encoder output)'}
 
 
 def describe_status(words):
@@ -131,15 +132,32 @@ def _overlap_events():
 _side = None
 
 
+_probed = None
+
+
+def probe_placement():
+    """Verifies once, on the current device, the dispatcher property that the XCD-local BPTT placement
+    rests on (include/ssasr.h, ssasr_probe_placement: an allocation and three synchronous launches);
+    returns the verdict (1 holds, 0 does not).  Until it has run the library uses the spread placement."""
+    global _probed
+    if _probed is None:
+        rc = _lib.load().ssasr_probe_placement(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc < 0:
+            raise RuntimeError('ssasr_probe_placement: HIP error %d' % -rc)
+        _probed = rc
+    return _probed
+
+
 def side_stream():
     global _side
     if _side is None:
         _side = torch.cuda.Stream()
-        # First use of the overlapped backward: verify the dispatcher property that XCD-local
-        # placement of the BPTT rests on (include/ssasr.h, ssasr_probe_placement).  Once.
-        rc = _lib.load().ssasr_probe_placement(C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        if rc < 0:
-            raise RuntimeError('ssasr_probe_placement: HIP error %d' % -rc)
+        # First use of the overlapped backward: the probe only when the XCD-local placement is asked
+        # for (SSASR_BPTT_LOCAL, default off) -- it synchronises the device.
+        local = C.c_int(0)
+        _lib.load().ssasr_get_option(b'SSASR_BPTT_LOCAL', C.byref(local))
+        if local.value:
+            probe_placement()
     return _side
 
 
@@ -452,9 +470,14 @@ class _AttnStep(torch.autograd.Function):
         att = torch.empty(B, T, device=feat.device)
         cx = torch.empty(B, E, device=feat.device)
         ws, phase = attn_workspace(B, T, A, E, feat.device)
+        sync = _status_words(feat.device) if ws is not None else None
         check(lib.ssasr_attn_step_fwd(_p(state), _p(w_phi), _p(comp), _p(feat), _p(enc_len), B, T,
-                                      A, E, D, _p(q), _p(att), _p(cx), _p(ws), phase, _stream()),
+                                      A, E, D, _p(q), _p(att), _p(cx), _p(ws), phase,
+                                      None if sync is None else C.c_void_p(sync.data_ptr() + 20), _stream()),
               'ssasr_attn_step_fwd')
+        if ws is not None:
+            attn_workspace_advance(B, T, A, E, feat.device, 1)     # only a launch that happened moves the phase
+            _track_status(sync, 5)
         ctx.save_for_backward(state, w_phi, comp, feat, enc_len, q, att)
         return att, cx
 
@@ -482,26 +505,35 @@ class _AttnStep(torch.autograd.Function):
 _attn_ws = {}
 
 
-def attn_workspace(B, T, A, E, device, calls=1):
-    """(workspace, phase of the next call) of the split-T attention kernel for a shape, or
-    (None, 0) when the shape has no use for one.  The workspace is two exchange buffers armed with
-    the fill pattern once and then reused by every call of that shape: a call exchanges through
-    buffer `phase` and re-arms the other (include/ssasr.h), so consecutive calls alternate.  The
-    phase is tracked here: `calls` is how many consecutive calls (phase, phase + 1, ...) the
-    caller is about to make (a decode loop's per-step launches: U).  Calls that share a workspace
-    must be ordered on one stream."""
+def _attn_ws_key(B, T, A, E, device):
+    return (str(device), torch.cuda.current_stream(device).cuda_stream, B, T, A, E)
+
+
+def attn_workspace(B, T, A, E, device):
+    """(workspace, phase of the next call) of the split-T attention kernel for a shape on the
+    current stream, or (None, 0) when the library does not take that form (shape, options,
+    residency: ssasr_attn_step_ws_floats).  The workspace is two exchange buffers armed with the
+    fill pattern once and then reused by every call of that (stream, shape): a call exchanges
+    through buffer `phase` and re-arms the other (include/ssasr.h), so consecutive calls alternate.
+    The phase only moves through attn_workspace_advance(), which callers invoke AFTER the library
+    accepted their launches; with a workspace the library launches the split form or fails."""
     n = int(_lib.load().ssasr_attn_step_ws_floats(B, T, A, E))
     if n == 0:
         return None, 0
-    key = (str(device), B, T, A, E)
+    key = _attn_ws_key(B, T, A, E, device)
     ent = _attn_ws.get(key)
-    if ent is None:
+    if ent is None or ent[0].numel() != n:          # (a changed SSASR_ATTN_RPH changes the record count)
         ws = torch.empty(n, device=device, dtype=torch.float32)
         ws.view(torch.int32).fill_(_SENTINEL_I32)
         ent = _attn_ws[key] = [ws, 0]
-    phase = ent[1]
+    return ent[0], ent[1]
+
+
+def attn_workspace_advance(B, T, A, E, device, calls):
+    """Records that `calls` consecutive split-T launches (phase, phase + 1, ...) were enqueued on
+    the current stream's workspace of this shape."""
+    ent = _attn_ws[_attn_ws_key(B, T, A, E, device)]
     ent[1] = (ent[1] + calls) & 1
-    return ent[0], phase
 
 
 def attn_step(state, w_phi, comp, feat, enc_len):
@@ -615,9 +647,11 @@ class _DecoderLoop(torch.autograd.Function):
             _track_status(bufs['ws_sync'], 5)
         if 'ctx' not in bufs:
             bufs['ctx'] = f(U, B, E)
-            ws_attn, attn_phase = attn_workspace(B, T, A, E, dev, calls=U)     # per-step loop, long encoder outputs
+            ws_attn, attn_phase = attn_workspace(B, T, A, E, dev)     # per-step loop, long encoder outputs
             if ws_attn is not None:
                 bufs['ws_attn'] = ws_attn
+                bufs['ws_sync'] = _status_words(dev)
+                _track_status(bufs['ws_sync'], 5)
         modes = (C.c_int32 * U)(*[int(m) for m in step_mode])
         d = _lib.Decoder()
         d.B, d.T, d.E, d.A, d.D, d.V, d.U = B, T, E, A, D, V, U
@@ -636,6 +670,8 @@ class _DecoderLoop(torch.autograd.Function):
         d.ws_armed = 1 if ('ws_hx1' in bufs and ctx_armed) else 0
         d.ws_attn_phase = attn_phase if 'ws_attn' in bufs else 0
         check(lib.ssasr_decoder_fwd(C.byref(d), _stream()), 'ssasr_decoder_fwd')
+        if 'ws_attn' in bufs:
+            attn_workspace_advance(B, T, A, E, dev, U)
         ctx.dec = d
         ctx.slots = slots
         ctx.keep = (feat, comp, enc_len, teacher, modes, uniforms, params, bufs)

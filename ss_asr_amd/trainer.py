@@ -164,7 +164,8 @@ class ASRTrainer(Solver):
         if self.device.type == 'cuda' and self.config['asr'].get('gpu_resident_loader', True):
             from .gpu_loader import GpuResidentLoader
             free, _ = torch.cuda.mem_get_info(self.device)
-            est = 4 * 80 * sum(r['unpadded_num_frames'] for r in self.train_set.dataset._rows)
+            est = 4 * int(self.config['asr']['mdl']['feature_dim']) * sum(
+                r['unpadded_num_frames'] for r in self.train_set.dataset._rows)
             if est < free // 4:
                 self.gpu_loader = GpuResidentLoader(self.config['asr']['train_index'], self.train_batch_size,
                                                     self.device, rank=self.rank, world=self.world)
@@ -284,6 +285,10 @@ class ASRTrainer(Solver):
                 total_acc += calc_acc(prediction, label)
                 total_err += calc_err(prediction, label, mapper=self.mapper)
                 num_batches += 1
+        # the persistent launches of the greedy passes report into status words of their own (they run
+        # outside a train step's shared row): a hand-off that timed out must not become a "best" model
+        # or a best_hyp.txt (float(loss) above has synchronised already)
+        ops.check_persistent_status()
         if num_batches == 0:
             self.asr_model.train()
             return

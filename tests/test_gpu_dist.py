@@ -87,3 +87,148 @@ def test_rccl_single_rank_train_steps_equal_the_plain_run():
     assert max(abs(a - b) for a, b in zip(rccl['losses'], plain['losses'])) < 1e-5
     assert abs(rccl['norm'] - plain['norm']) < 1e-5 * max(1.0, plain['norm'])
     assert abs(rccl['wsum'] - plain['wsum']) < 1e-6 * plain['wsum']
+
+
+# ---- two ranks on the one GPU, gloo between them, the REAL train step -------------
+# the section-8(e) statement had only been asserted on a linear stand-in model.
+# Here both ranks run engine.ASRTrainStep on cuda:0 (SSASR_DIST_BACKEND=gloo: RCCL cannot serve two
+# ranks on one device), over THREE batches -- an odd count, so the tail batch is dropped and both
+# ranks run the same number of steps (one).  A third, single-process child computes what 8(e) says
+# the ranks must see: the loss of each local batch on its own, and the weights after one
+# Solver.step on the MEAN of the two gradients.
+DDP_COMMON = r'''
+import json, os, random, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'oracle'))
+import las_oracle as lo
+from ss_asr_amd import dist as sdist, ops
+from ss_asr_amd.asr import ASR
+from ss_asr_amd.engine import ASRTrainStep, label_geometry
+from ss_asr_amd.gpu_loader import rank_batches
+from ss_asr_amd.synthetic import make_batch
+DIMS = (50, 256, 256, 128, 80)
+def batch(k):
+    return make_batch(np.array([216 - 16 * k, 160, 96 + 8 * k, 40]), np.array([14, 9 + k, 6, 3]), 80, seed=70 + k)
+def model():
+    m = ASR(*DIMS, 1.0)
+    lo.seeded_weights(m, 9)
+    return m.to('cuda:0')
+PROBE = ('encoder.blstm_1.layer.weight_hh_l0', 'encoder.blstm_4.weight_ih_l0_reverse', 'attention.phi.weight',
+         'decoder.layer_1.weight_ih', 'char_trans.bias')
+def report(m, **kw):
+    p = dict(m.named_parameters())
+    kw['probe'] = {n: p[n].detach().reshape(-1)[:64].double().cpu().tolist() for n in PROBE}
+    kw['wsum'] = float(torch.cat([t.detach().reshape(-1) for t in m.parameters()]).double().abs().sum())
+    print('RESULT ' + json.dumps(kw))
+'''
+
+DDP_RANK = DDP_COMMON + r'''
+rank, world, local = sdist.init_from_env()
+assert world == 2 and sdist.is_active()
+import torch.distributed as dist
+assert dist.get_backend() == 'gloo'
+torch.cuda.set_device(0)
+m = model()
+step = ASRTrainStep(m)
+mine = list(rank_batches(3, rank, world))          # three batches, two ranks: the tail batch is dropped
+# Test-only orchestration: the two ranks share ONE GPU here (in production each has its own), and two
+# persistent launches of different processes may each get part of the chip and wait for ever for the
+# rest.  A file lock keeps the ranks' forward + backward passes apart; it is released before the
+# gradient all-reduce, where the ranks must meet.
+import fcntl
+lockf = open(os.environ['SSASR_TEST_LOCK'], 'w')
+real_finish = step.reducer.finish
+def finish_after_unlock():
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    fcntl.flock(lockf, fcntl.LOCK_UN)
+    return real_finish()
+step.reducer.finish = finish_after_unlock
+losses = []
+for k in mine:
+    x, y, lens = batch(k)
+    _, ans_len = label_geometry(y)
+    random.seed(0)
+    fcntl.flock(lockf, fcntl.LOCK_EX)
+    losses.append(float(step(x.cuda(), y.cuda(), lens, ans_len)))
+norm, skipped = step.finish()
+report(m, rank=rank, mine=mine, losses=losses, norm=norm, skipped=bool(skipped))
+sdist.shutdown()
+'''
+
+DDP_SINGLE = DDP_COMMON + r'''
+from ss_asr_amd.optim import FlatParameters, FusedAdadelta
+torch.cuda.set_device(0)
+m = model()
+flat = FlatParameters(m)
+optim = FusedAdadelta(flat, lr=1.0, eps=1e-8)
+losses, total = [], torch.zeros_like(flat.grad)
+for k in (0, 1):
+    x, y, lens = batch(k)
+    _, ans_len = label_geometry(y)
+    optim.zero_grad()
+    random.seed(0)
+    _, logits, _ = m(x.cuda(), ans_len, teacher=y.cuda(), state_len=lens)
+    loss = ops.masked_ce_loss(logits, y.cuda(), ans_len)
+    loss.backward()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    ops.check_persistent_status()
+    losses.append(float(loss))
+    total += flat.grad
+flat.grad.copy_(total)
+optim.clip_and_step(max_norm=5.0, grad_scale=0.5)       # Solver.step on the mean of the two gradients
+norm, skipped = optim.poll(wait=True)
+report(m, losses=losses, norm=norm, skipped=bool(skipped))
+'''
+
+
+def _child(script, env):
+    return subprocess.Popen([sys.executable, '-c', script % dict(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True)
+
+
+def _result(proc, timeout):
+    out, _ = proc.communicate(timeout=timeout)
+    assert proc.returncode == 0, out[-3000:]
+    return json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][-1][7:])
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_follow_the_section_8e_statement_on_the_real_step(tmp_path):
+    base = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND'):
+        base.pop(k, None)
+    single = _result(_child(DDP_SINGLE, base), 420)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    lock = str(tmp_path / 'gpu.lock')
+    for r in range(2):
+        env = dict(base, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), SSASR_DIST_BACKEND='gloo', SSASR_TEST_LOCK=lock)
+        procs.append(_child(DDP_RANK, env))
+    try:
+        ranks = [_result(p, 600) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    ranks.sort(key=lambda d: d['rank'])
+    # equal step counts with an odd batch count: batch 2 is nobody's
+    assert [d['mine'] for d in ranks] == [[0], [1]]
+    assert not single['skipped'] and not any(d['skipped'] for d in ranks)
+    # rank-local loss == the single-process loss on that local batch
+    for r in range(2):
+        assert abs(ranks[r]['losses'][0] - single['losses'][r]) < 2e-6, (r, ranks[r]['losses'], single['losses'])
+    # both ranks clipped the same, reduced gradient ...
+    assert abs(ranks[0]['norm'] - ranks[1]['norm']) < 1e-6 * max(1.0, ranks[0]['norm'])
+    assert abs(ranks[0]['norm'] - single['norm']) < 2e-5 * max(1.0, single['norm'])
+    # ... and hold the weights of one Solver.step on the mean of the two single-process gradients
+    for r in range(2):
+        assert abs(ranks[r]['wsum'] - single['wsum']) < 1e-6 * single['wsum']
+        for n, want in single['probe'].items():
+            got = ranks[r]['probe'][n]
+            assert max(abs(a - b) for a, b in zip(got, want)) < 2e-5, (r, n)
+    assert ranks[0]['probe'] == ranks[1]['probe']

@@ -293,8 +293,41 @@ def test_split_attention_repeated_calls_share_one_workspace():
     torch.cuda.synchronize()
     for k in range(2, 6):
         assert torch.equal(outs[k][0], outs[k % 2][0]) and torch.equal(outs[k][1], outs[k % 2][1])
-    ws, nxt = ops.attn_workspace(B, T, A, E, dev(), calls=0)
+    ws, nxt = ops.attn_workspace(B, T, A, E, dev())
     assert ws is not None and bool((ws.view(torch.int32).view(2, -1)[nxt] == 0x7FC0DEAD).all())
+
+
+def test_split_attention_missing_slice_times_out_and_is_reported():
+    """Fault injection (SSASR_TEST_DROP_TILE): slice 2 of utterance 0 never publishes its partial
+    softmax.  The utterance's other workgroups give up after their bounded wait, say so in the
+    status word (this kernel used to `break` and consume the fill pattern silently), and
+    the next call on the same workspace is healthy."""
+    import time
+    from ss_asr_amd import _lib, ops
+    B, T, A, E, D = 32, 300, 128, 512, 256
+    feat = rnd(B, T, E, seed=61).float().to(dev())
+    comp = torch.tanh(rnd(B, T, A, seed=62)).float().to(dev())
+    w_phi = rnd(A, D, seed=63, scale=D ** -0.5).float().to(dev())
+    state = rnd(B, D, seed=64).float().to(dev())
+    ld = torch.tensor([300 - 7 * k for k in range(B)], dtype=torch.int32, device=dev())
+    good_a, good_c = ops.attn_step(state, w_phi, comp, feat, ld)
+    ops.check_persistent_status()
+    old = _lib.set_option('SSASR_TEST_DROP_TILE', 2)
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.attn_step(state, w_phi, comp, feat, ld)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:
+        _lib.set_option('SSASR_TEST_DROP_TILE', old)
+    with pytest.raises(RuntimeError, match='split-T attention'):
+        ops.check_persistent_status()
+    assert elapsed < 20.0, elapsed
+    for _ in range(2):                         # both exchange buffers
+        a, c = ops.attn_step(state, w_phi, comp, feat, ld)
+        ops.check_persistent_status()
+        assert torch.equal(a, good_a) and torch.equal(c, good_c)
 
 
 def test_attention_first_step_is_uniform_over_valid_frames():
@@ -310,6 +343,23 @@ def test_attention_first_step_is_uniform_over_valid_frames():
     for b, l in enumerate(lens):
         np.testing.assert_allclose(att[b, :l].cpu().numpy(), 1.0 / l, rtol=1e-6)
         assert float(att[b, l:].abs().sum()) == 0.0
+
+
+def test_integration_stub_computes_an_attention_step():
+    """INTEGRATION.md's documented ctypes stub, executed as written, against the oracle."""
+    from test_host_cpu import integration_stub
+    ns = integration_stub()
+    B, T, A, E, D = 3, 100, 128, 512, 256
+    lens = [100, 57, 1]
+    feat, state = rnd(B, T, E, seed=21), rnd(B, D, seed=22)
+    w_phi = rnd(A, D, seed=23, scale=D ** -0.5)
+    comp = torch.tanh(rnd(B, T, A, seed=24))
+    alpha, ctx = lo.attention_step_explicit(state, feat, comp, lens, w_phi)
+    ld = torch.tensor(lens, dtype=torch.int32, device=dev())
+    ad, cd = ns['attention_step'](state.float().to(dev()), w_phi.float().to(dev()), comp.float().to(dev()),
+                                  feat.float().to(dev()), ld)
+    close(ad, alpha, 2e-6, 'alpha')
+    close(cd, ctx, 1e-5, 'ctx')
 
 
 # ------------------------------------------------------------- LSTM cell ----

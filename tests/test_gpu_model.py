@@ -21,6 +21,7 @@ BENCH_SHAPES = ['bench_b32_t800', 'bench_b32_median']
 # utterances of 1500-3000 frames, T' = 375 (split-T attention inside the per-step decode loop, ~300
 # decode steps), 3000 / 1500 / 750 persistent recurrence steps with the exchange ring wrapping ~370 times
 LONG_SHAPES = ['long_b32_t3000']
+GRAD_NORM_RTOL = 2e-4
 
 
 def build(fx):
@@ -95,7 +96,10 @@ def test_backward_and_solver_step_match_reference(golden, name):
     torch.cuda.synchronize()          # weight-gradient GEMMs run on a side stream
     params = dict(model.named_parameters())
     got = np.array([params[n].grad.double().norm().item() for n in names])
-    np.testing.assert_allclose(got, fx['grad_norms'], rtol=1e-3, atol=1e-6)
+    # per-parameter gradient norms: GRAD_NORM_RTOL relative (VERDICT r2 found 1e-3 loose beside a loss that
+    # agrees to 2e-6; the measured maxima are printed below)
+    np.testing.assert_allclose(got, fx['grad_norms'], rtol=GRAD_NORM_RTOL, atol=1e-6)
+    print('max rel grad-norm error %s: %.3g' % (name, np.max(np.abs(got - fx['grad_norms']) / np.maximum(fx['grad_norms'], 1e-6))))
     for k in fx.files:
         if k.startswith('g/'):
             np.testing.assert_allclose(params[k[2:]].grad.cpu().numpy(), fx[k], atol=2e-5,
@@ -108,10 +112,17 @@ def test_backward_and_solver_step_match_reference(golden, name):
     assert not skipped and abs(norm - float(fx['grad_norm'])) < 1e-4
     upd = np.array([(params[n].detach() - before[n]).double().norm().item() for n in names])
     np.testing.assert_allclose(upd, fx['update_norms'], rtol=2e-3, atol=1e-6)
+    checked = 0
     for k in fx.files:
         if k.startswith('w1/'):
             np.testing.assert_allclose(params[k[3:]].detach().cpu().numpy(), fx[k], atol=1e-4,
                                        rtol=0, err_msg=k)
+            checked += 1
+        if k.startswith('w1_head/'):       # compact fixtures: the first 256 post-step weights of selected tensors
+            np.testing.assert_allclose(params[k[8:]].detach().reshape(-1)[:256].cpu().numpy(), fx[k], atol=1e-4,
+                                       rtol=0, err_msg=k)
+            checked += 1
+    assert checked > 0, 'fixture %s holds no post-step weights' % name
 
 
 def test_backward_matches_reference_on_the_fp32_mfma_instruction(golden):
@@ -142,7 +153,7 @@ def test_backward_matches_reference_in_both_bptt_placements(golden):
     from ss_asr_amd import _lib, ops
     from ss_asr_amd.optim import FlatParameters
     fx = golden('full_b16_t400')
-    ops.side_stream()                            # runs the probe
+    ops.probe_placement()                        # (side_stream() only probes when SSASR_BPTT_LOCAL is set)
     probed = _lib.set_option('SSASR_XCD_ROUND_ROBIN', 1)
     _lib.set_option('SSASR_XCD_ROUND_ROBIN', probed)
     assert probed in (0, 1)
@@ -468,6 +479,45 @@ def test_train_step_edge_shapes_match_the_oracle(frames, chars):
     assert not skipped
     assert abs(loss - ref_loss) < 1e-4, (loss, ref_loss)
     assert abs(norm - ref_norm) < 2e-3 * max(1.0, ref_norm), (norm, ref_norm)
+
+
+def test_encoder_alone_forward_backward_as_the_other_trainers_call_it():
+    """`asr.encoder(x, x_lens)` on its own with an arbitrary gradient fed into its output, at 32
+    utterances: how SAETrainer and ADVTrainer use the shared Listener (src/trainer.py:810, :988 --
+    no attention, no speller, no ASR.forward around it).  Against the oracle's Listener: features,
+    lengths, every encoder parameter's gradient, and the input gradient."""
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.synthetic import config2_batches
+    from ss_asr_amd import ops
+    dims = (50, 256, 256, 128, 80)
+    x, _, lens = config2_batches(8, batch_size=32, seed=11)[3]
+    ref = lo.OracleASR(*dims, 1.0)
+    lo.seeded_weights(ref, 21)
+    xr = x.clone().requires_grad_(True)
+    feat_r, len_r = ref.encoder(xr, lens)
+    g = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(feat_r.shape)).astype(np.float32))
+    (feat_r * g).sum().backward()
+
+    model = ASR(*dims, 1.0)
+    lo.seeded_weights(model, 21)
+    model = model.to('cuda:0')
+    xd = x.cuda().requires_grad_(True)
+    feat_d, len_d = model.encoder(xd, lens)
+    assert [int(v) for v in len_d] == [int(v) for v in len_r]
+    np.testing.assert_allclose(feat_d.detach().cpu().numpy(), feat_r.detach().numpy(), atol=2e-5, rtol=0)
+    (feat_d * g.cuda()).sum().backward()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    ops.check_persistent_status()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), atol=5e-5, rtol=0)
+    ref_p = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        if n.startswith('encoder.'):
+            want = ref_p[n].grad
+            scale = max(1.0, float(want.abs().max()))
+            np.testing.assert_allclose(p.grad.cpu().numpy(), want.numpy(), atol=2e-4 * scale, rtol=0, err_msg=n)
+        else:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n
 
 
 @pytest.mark.parametrize('name', ['tae_full_b12', 'tae_full_b40'])

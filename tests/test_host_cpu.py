@@ -16,27 +16,114 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _c_class(decl):
+    """'ptr' / 'i64' / 'i32' / 'f32' of one C parameter or field declaration."""
+    decl = decl.strip()
+    if '*' in decl:
+        return 'ptr'
+    base = re.sub(r'\bconst\b', '', decl).split()[0]
+    return {'int64_t': 'i64', 'int': 'i32', 'int32_t': 'i32', 'float': 'f32'}[base]
+
+
+def _ctypes_class(t):
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, 'contents'):
+        return 'ptr'
+    return {ctypes.c_int64: 'i64', ctypes.c_int: 'i32', ctypes.c_int32: 'i32', ctypes.c_float: 'f32'}[t]
+
+
+def header_prototypes():
+    """{name: (return class, [parameter classes])} of every function include/ssasr.h declares."""
+    header = open(os.path.join(ROOT, 'include', 'ssasr.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    protos = {}
+    for ret, name, params in re.findall(r'\b(int|int64_t)\s+(ssasr_\w+)\s*\(([^)]*)\)\s*;', header):
+        params = params.strip()
+        plist = [] if params in ('', 'void') else [_c_class(p) for p in params.split(',')]
+        protos[name] = (_c_class(ret), plist)
+    return protos, header
+
+
 def test_library_exports_every_declared_symbol():
     from ss_asr_amd import _lib
-    header = open(os.path.join(ROOT, 'include', 'ssasr.h')).read()
-    declared = set(re.findall(r'\b(?:int|int64_t)\s+(ssasr_\w+)\s*\(', header))
+    protos, header = header_prototypes()
+    declared = set(protos)
     assert len(declared) >= 17
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.ssasr_abi_version() == _lib.ABI_VERSION
-    # struct layouts bound by ctypes must match the C declarations field for field
+    # struct layouts bound by ctypes must match the C declarations field for field, name and class
     for cname, cls in (('ssasr_decoder', _lib.Decoder), ('ssasr_decoder_grads', _lib.DecoderGrads)):
         body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), header, re.S).group(1)
-        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
         fields = []
         for decl in body.split(';'):
             decl = decl.strip()
             if decl:
-                fields += [f.strip().lstrip('*').strip() for f in
-                           re.sub(r'^(const\s+)?\w+\s*\**', '', decl, count=1).split(',')]
-        assert fields == [f[0] for f in cls._fields_], cname
+                names = re.sub(r'^(const\s+)?\w+\s*\**', '', decl, count=1).split(',')
+                fields += [(f.strip().lstrip('*').strip(), _c_class(decl)) for f in names]
+        assert fields == [(f[0], _ctypes_class(f[1])) for f in cls._fields_], cname
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Per entry point: return class, parameter count and each parameter's class (pointer / int64 /
+    int / float) in include/ssasr.h == the ctypes table the product binds (VERDICT r2, row b: a
+    prototype that drifts from the definition passes a stream where an int is expected)."""
+    from ss_asr_amd import _lib
+    protos, _ = header_prototypes()
+    mismatches = []
+    for name, (res, args) in _lib.SIGNATURES.items():
+        got = (_ctypes_class(res), [_ctypes_class(a) for a in args])
+        if got != protos[name]:
+            mismatches.append((name, protos[name], got))
+    assert not mismatches, mismatches
+
+
+def test_a_c_caller_builds_against_the_header(tmp_path):
+    """A plain C program compiled from include/ssasr.h alone (gcc -Wall -Werror, no HIP headers)
+    links the shared object, reads the ABI version and gets negative codes for argument errors --
+    the header is what a C caller sees, so it has to agree with the library by itself."""
+    import shutil
+    import subprocess
+    from ss_asr_amd import _lib
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc on this box')
+    _lib.load()
+    exe = str(tmp_path / 'abi_smoke')
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'c', 'abi_smoke.c'), '-o', exe, '-L', libdir,
+                    '-lssasr_hip', '-Wl,-rpath,' + libdir], check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout
+    assert 'abi %d' % _lib.ABI_VERSION in out.stdout
+
+
+def integration_stub():
+    """The ctypes stub INTEGRATION.md section 2 documents, executed: returns its namespace."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, re.S)
+    block = [b for b in blocks if 'ssasr_attn_step_fwd.argtypes' in b]
+    assert len(block) == 1
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)                    # the stub loads "ss_asr_amd/libssasr_hip.so" relative to the repo root
+    try:
+        exec(compile(block[0], 'INTEGRATION.md', 'exec'), ns)
+    finally:
+        os.chdir(cwd)
+    return ns
+
+
+def test_integration_stub_binds_the_header_prototype():
+    """The documented drop-in stub runs against the built library and declares exactly the
+    prototype of include/ssasr.h (a stale stub passes the stream as `ws`)."""
+    ns = integration_stub()
+    protos, _ = header_prototypes()
+    fn = ns['lib'].ssasr_attn_step_fwd
+    assert (_ctypes_class(fn.restype), [_ctypes_class(a) for a in fn.argtypes]) == protos['ssasr_attn_step_fwd']
+    assert callable(ns['attention_step'])
 
 
 def test_argument_errors_are_negative_and_need_no_gpu():
