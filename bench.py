@@ -293,6 +293,82 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
     return out
 
 
+def config4_bench(device, steps=4, warmup=2, batch=32):
+    """BASELINE.json configs[3] (utt/s; attention-kernel HBM fraction): one
+    32-utterance batch of 1500-3000 frames (synthetic.config4_batch, T' = 375, ~300 label steps) through
+    engine.ASRTrainStep, and through the joint CTC + attention step (ctc.JointCTCTrainStep, ctc_weight
+    0.3); plus the decode loop of that shape on its own, forward and backward, in us per decode step
+    (HIP events around ops.decoder_loop and its backward: the attention runs INSIDE that loop)."""
+    from ss_asr_amd import ops
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.ctc import JointCTCASR, JointCTCTrainStep
+    from ss_asr_amd.engine import ASRTrainStep, label_geometry
+    from ss_asr_amd.synthetic import config4_batch
+    x, y, lens = config4_batch(batch_size=batch, feat_dim=DIMS['feature_dim'])
+    _, ans_len = label_geometry(y)
+    xd, yd = x.to(device), y.to(device)
+
+    def time_steps(stepper):
+        for _ in range(warmup):
+            stepper(xd, yd, lens, ans_len)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = None
+        for _ in range(steps):
+            loss = stepper(xd, yd, lens, ans_len)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        stepper.finish()
+        return dt, float(loss)
+
+    out = dict(workload='BASELINE.json configs[3]: %d utterances of %d-%d frames (mean %.0f), T\' = %d, %d label steps, '
+                        'bucketed padding, 1 GPU, tf_rate 0.9' % (batch, min(lens), max(lens), sum(lens) / len(lens),
+                                                                 max(lens) // 8, ans_len),
+               steps=steps, warmup=warmup)
+    random.seed(4); torch.manual_seed(4)
+    model = ASR(**DIMS).to(device)
+    dt, loss = time_steps(ASRTrainStep(model, lr=1.0, eps=1e-8, grad_clip=5.0))
+    out['attention_loss'] = dict(ms_per_step=round(dt * 1e3, 2), utterances_per_sec=round(batch / dt, 1),
+                                 final_loss=round(loss, 4))
+    random.seed(4); torch.manual_seed(4)
+    joint = JointCTCASR(ctc_weight=0.3, **DIMS).to(device)
+    dt, loss = time_steps(JointCTCTrainStep(joint, lr=1.0, eps=1e-8, grad_clip=5.0))
+    out['joint_ctc_attention_loss'] = dict(ms_per_step=round(dt * 1e3, 2), utterances_per_sec=round(batch / dt, 1),
+                                           ctc_weight=0.3, final_loss=round(loss, 4),
+                                           note='build-defined branch: the reference has no CTC (DESIGN.md 4.7)')
+    # the decode loop of this shape alone
+    T, U, E = max(lens) // 8, ans_len, 2 * DIMS['encoder_state_size']
+    g = torch.Generator(device='cpu').manual_seed(9)
+    feat = torch.randn(batch, T, E, generator=g).to(device).requires_grad_(True)
+    enc_len = torch.tensor([n // 8 for n in lens], dtype=torch.int32, device=device)
+    teacher = yd.to(torch.int32)
+    modes = [0] * U
+    psi = (model.attention.psi.weight, model.attention.psi.bias)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    fwd_us, bwd_us = [], []
+    for it in range(4):
+        torch.cuda.synchronize()
+        ev[0].record()
+        logits, _, _ = ops.decoder_loop(feat, None, enc_len, teacher, modes, None, model._decoder_params(), psi=psi)
+        ev[1].record()
+        logits.backward(torch.ones_like(logits) * 1e-3)
+        ev[2].record()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        if it:
+            fwd_us.append(ev[0].elapsed_time(ev[1]) * 1e3 / U)
+            bwd_us.append(ev[1].elapsed_time(ev[2]) * 1e3 / U)
+    ops.check_persistent_status()
+    s = 4
+    nbytes = batch * T * (128 + E) * s + batch * T * (s + 1) + batch * (256 + E) * s + 256 * 128 * s
+    out['decode_loop'] = dict(shape=dict(B=batch, T=T, U=U), us_per_decode_step_forward=round(min(fwd_us), 2),
+                              us_per_decode_step_backward=round(min(bwd_us), 2),
+                              attention_algorithmic_bytes_per_step=nbytes,
+                              note='whole ssasr_decoder_fwd / _bwd calls divided by U (psi projection, embedding gather, '
+                                   'workspace fills and the batched products after the loop included)')
+    return out
+
+
 def cpu_baseline(batches):
     """The oracle (a CPU restatement of the reference, pinned to its golden
     vectors) timed on the host cores for one train step on each of `batches`
@@ -350,6 +426,7 @@ def main():
     ap.add_argument('--max-frames', type=int, default=800)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-config4', action='store_true')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -467,10 +544,20 @@ def main():
             fwd_rec['traffic'] = t.get('fwd_bytes_per_launch')
             att['at_training_shape']['traffic'] = t.get('attention_bytes_per_launch')
             att['traffic'] = t.get('attention_split_bytes_per_launch')
+            # NOT measured by this run: PMC counters need separate rocprofv3 --pmc passes
+            src = 'profiles/%s (rocprofv3 --pmc passes of tools/pmc_layer.py on the builder\'s box; a constant of ' \
+                  'that profile, not a measurement of this run)' % os.path.basename(traffic)
+            for d in (bptt, fwd_rec, att['at_training_shape'], att):
+                d['traffic_source'] = src
         out['roofline'] = bptt                       # dominant kernel of the step (profiles/)
         out['roofline_forward_recurrence'] = fwd_rec
         out['roofline_attention'] = att
         out['roofline_gemm'] = gemm_rl
+    if world == 1 and not args.no_config4:
+        del stepper, loader
+        torch.cuda.empty_cache()
+        out['config4'] = config4_bench(device)
+        note('config 4: %s' % out['config4'])
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline([host_batches[k] for k in (2, 4, 6)])
     print(json.dumps(out), flush=True)

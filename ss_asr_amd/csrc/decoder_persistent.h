@@ -136,6 +136,223 @@ __device__ __forceinline__ void pd_mma(f32x4& acc, f32x4& acc2, const float4 (&w
 #undef PD_STEP
 }
 
+// The "compute" role of the persistent decode loops (this kernel and decoder_long.h): compute
+// workgroup group c of 128 (tile = c >> 1: 4 hidden units; chunk = c & 1: 16 utterances) with its
+// slices of [W_ih1 | W_hh1] and [W_ih2 | W_hh2] resident in registers; per step cell 2 of step t-1,
+// the next character on steps that are not teacher forced (groups c < B), and cell 1 of step t.
+// `tid` / `wave` are LOCAL to the group's 256 threads, `smem` its own 1408 floats of LDS; a workgroup
+// may hold several groups (decoder_long.h: two), which all run the same barrier sequence:
+// `any_chr` says whether ANY group of the workgroup has the character role (barriers are uniform).
+constexpr int PD_GROUP_LDS_FLOATS = 4 * 64 * 4 + 256 + 64 + 64;
+template <bool SEN>
+__device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c, const int tid, float* smem,
+                                                const bool any_chr) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int B = p.B, U = p.U;
+  PdWaiter wt{false, p.status};
+  const unsigned n_att = (unsigned)(B * PD_NATT);     // ctx publishers per step (counter form only)
+  const unsigned n_cmp = 128u, n_chr = (unsigned)B;
+  const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4 * sizeof(float);      // bytes per step
+  const int tile = c >> 1, chunk = c & 1;          // 4 hidden units, 16 utterances
+  const int r = lane & 15, q = lane >> 4;
+  const int n = 16 * chunk + r;                    // this lane's utterance (B operand / epilogue column)
+  const int nc = n < B ? n : 0;
+  f32x4* red = reinterpret_cast<f32x4*>(smem);     // [4][64]
+  float* sH = smem + 4 * 64 * 4;                   // [16][4] transpose buffer, then [256] for the char role
+  const int D = PD_D, E = PD_E;
+  const bool is_chr = c < B;
+
+  // resident weight slices (this wave's k-blocks: kb = wave + 4 j)
+  float4 w1[16], w2[8];
+  {
+    const int rowA = (r & 3) * D + 4 * tile + (r >> 2);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = 16 * (wave + 4 * j) + 4 * q;                 // 0 .. 1023 over [emb | ctx | h1]
+      w1[j] = k < D + E ? aload4(p.w_ih1 + (int64_t)rowA * (D + E) + k)
+                        : aload4(p.w_hh1 + (int64_t)rowA * D + (k - D - E));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * (wave + 4 * j) + 4 * q;                 // 0 .. 511 over [h1 | h2]
+      w2[j] = k < D ? aload4(p.w_ih2 + (int64_t)rowA * D + k) : aload4(p.w_hh2 + (int64_t)rowA * D + (k - D));
+    }
+  }
+  const int u = 4 * tile + q;                      // epilogue (wave 0): unit u, utterance n
+  const bool epi = wave == 0 && n < B;
+  float bias1[4] = {0.f, 0.f, 0.f, 0.f}, bias2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (epi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bias1[g] = p.b_ih1[g * D + u] + p.b_hh1[g * D + u];
+      bias2[g] = p.b_ih2[g * D + u] + p.b_hh2[g * D + u];
+    }
+  }
+  float cst1 = 0.f, cst2 = 0.f;
+  const __amdgpu_buffer_rsrc_t rh1 = pd_rsrc(p.hx1, img_h * U);
+  const __amdgpu_buffer_rsrc_t rh2 = pd_rsrc(p.hx2, img_h * U);
+  const __amdgpu_buffer_rsrc_t rc = pd_rsrc(p.ctx, (size_t)U * B * E * sizeof(float));
+  const __amdgpu_buffer_rsrc_t re = pd_rsrc(p.emb_in, (size_t)(U + 1) * B * D * sizeof(float));
+  const unsigned xoi = (unsigned)((q * PD_BP + nc) * 16);          // lane part of an image read
+  unsigned nsamp = 0;                                              // non-teacher steps so far
+
+  // cell epilogue shared by both cells: gates -> state, saves, image store, publish
+  auto cell_finish = [&](const f32x4& acc, const f32x4& acc2, const float (&bias)[4], float& cst, int t,
+                         float* gates, float* cs, float* hs, const __amdgpu_buffer_rsrc_t& rimg, int counter) {
+    red[wave * 64 + lane] = acc + acc2;
+    __syncthreads();
+    if (wave == 0) {
+      if (epi) {
+        f32x4 v = red[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += red[w * 64 + lane];
+        const float gi = fast_sigmoid(v[0] + bias[0]), gf = fast_sigmoid(v[1] + bias[1]);
+        const float gg = fast_tanh(v[2] + bias[2]), go = fast_sigmoid(v[3] + bias[3]);
+        const float cc = gf * cst + gi * gg;
+        const float h = go * fast_tanh(cc);
+        cst = cc;
+        sH[r * 4 + q] = h;
+        const int64_t g0 = ((int64_t)t * B + n) * 4 * D + u;
+        gates[g0] = gi; gates[g0 + D] = gf; gates[g0 + 2 * D] = gg; gates[g0 + 3 * D] = go;
+        cs[((int64_t)t * B + n) * D + u] = cc;
+        hs[((int64_t)t * B + n) * D + u] = h;
+      } else if (n >= B) {
+        sH[r * 4 + q] = 0.f;
+      }
+      // lanes of wave 0 exchange through sH without a workgroup barrier
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (lane < 16)
+        pd_st_sc1(rimg, (unsigned)(t * img_h + ((tile * PD_BP + 16 * chunk + lane) * 16)),
+                  *reinterpret_cast<const float4*>(sH + lane * 4));
+      if (!SEN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(p.cnt + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+  };
+
+  for (int t = 0; t <= U; ++t) {
+    // (A) h1_{t-1} from every compute workgroup
+    SSASR_DTRACE(t, 0);
+    if (!SEN && t > 0) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
+    SSASR_DTRACE(t, 1);
+
+    // (B) (phi_t = tanh(W_phi h1_{t-1}) is computed by the attention workgroups themselves)
+    SSASR_DTRACE(t, 2);
+    // (C) cell 2 of step t-1 (overlaps the attention workgroups' step t)
+    if (t > 0) {
+      const int s = t - 1;
+      if (!SEN && s > 0) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)s);
+      float4 b2[8];
+      {
+        const unsigned o1 = (unsigned)(s * img_h + wave * 4 * PD_BP * 16 + xoi);
+        const unsigned o2 = (unsigned)((s > 0 ? s - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
+        pd_fetch<SEN, 8>(b2, [=](int j) {      // kb = wave + 4 j: 0..15 h1_s, 16..31 h2_{s-1}
+          return j < 4 ? pd_ld_raw(rh1, o1 + (unsigned)(4 * j) * 4 * PD_BP * 16)
+                       : pd_ld_raw(rh2, o2 + (unsigned)(4 * (j - 4)) * 4 * PD_BP * 16);
+        }, 0, s > 0 ? 8 : 4, p.status);
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      pd_mma<8>(acc, acc2, w2, b2, 0, s > 0 ? 8 : 4);
+      cell_finish(acc, acc2, bias2, cst2, s, p.gates2, p.c2, p.h2, rh2, PC_H2);
+
+      // (D) next character after step s when it is not teacher forced
+      const int mode = p.modes[s];
+      if (mode != 0) {
+        ++nsamp;
+        if (any_chr && s + 1 <= U) {        // (workgroup-uniform: groups without the role only keep the barriers)
+          if (!SEN) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)(s + 1));
+          const int b = c;
+          float* sV = sH;                                       // [256] h2_s of utterance b
+          float* sL = sH + 256;                                 // [V] logits
+          if (is_chr && tid < 64) {
+            const unsigned ho = (unsigned)(s * img_h + ((tid * PD_BP + b) * 16));
+            float4 hv[1];
+            pd_fetch<SEN, 1>(hv, [=](int) { return pd_ld_raw(rh2, ho); }, 0, 1, p.status);
+            *reinterpret_cast<float4*>(sV + 4 * tid) = hv[0];
+          }
+          __syncthreads();
+          for (int v = wave; is_chr && v < p.V; v += 4) {
+            const float* wr = p.w_ct + (int64_t)v * D;
+            float a = 0.f;
+            for (int k = lane; k < D; k += 64) a = fmaf(wr[k], sV[k], a);
+            a = wave_sum(a);
+            if (lane == 0) sL[v] = a + p.b_ct[v];
+          }
+          __syncthreads();
+          if (is_chr && wave == 0) {
+            int best = 0;
+            if (lane == 0) {
+              float mx = sL[0];
+              for (int v = 1; v < p.V; ++v)
+                if (sL[v] > mx) { mx = sL[v]; best = v; }
+              if (mode == 1) {
+                float tot = 0.f;
+                for (int v = 0; v < p.V; ++v) tot += expf(sL[v] - mx);
+                const float target = p.uniforms[(int64_t)s * B + b] * tot;
+                float run = 0.f;
+                best = p.V - 1;
+                for (int v = 0; v < p.V; ++v) {
+                  run += expf(sL[v] - mx);
+                  if (run > target) { best = v; break; }
+                }
+              }
+              p.chars[(int64_t)(s + 1) * B + b] = best;
+            }
+            best = __shfl(best, 0, 64);
+            pd_st_sc1(re, (unsigned)((((int64_t)(s + 1) * B + b) * D + 4 * lane) * 4),
+                      aload4(p.embed + (int64_t)best * D + 4 * lane));
+            if (!SEN) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CHAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    if (t == U) break;
+
+    // (E) ctx_t from the attention workgroups, emb_t from the character role
+    SSASR_DTRACE(t, 3);
+    if (!SEN) {
+      wt.wait_ge(p.cnt + PC_CTX, n_att * (unsigned)(t + 1));
+      if (t > 0 && p.modes[t - 1] != 0) wt.wait_ge(p.cnt + PC_CHAR, n_chr * nsamp);
+    }
+    SSASR_DTRACE(t, 4);
+
+    // (F) cell 1 of step t: [emb_t | ctx_t | h1_{t-1}].  The emb and h1 thirds do not depend on
+    // the attention: they are fetched and multiplied while ctx_t is still on its way.
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      {
+        const float4 wA[8] = {w1[0], w1[1], w1[2], w1[3], w1[12], w1[13], w1[14], w1[15]};
+        float4 bA[8];
+        const unsigned oe = (unsigned)((((int64_t)t * B + nc) * D + 16 * wave + 4 * q) * 4);
+        const unsigned oh = (unsigned)((t > 0 ? t - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
+        pd_fetch<SEN, 8>(bA, [=](int j) {      // kb = wave + 4 j: 0..15 emb; then 48..63 h1
+          return j < 4 ? pd_ld_raw(re, oe + (unsigned)(64 * j) * 4)
+                       : pd_ld_raw(rh1, oh + (unsigned)(4 * (j - 4)) * 4 * PD_BP * 16);
+        }, 0, t > 0 ? 8 : 4, p.status);
+        pd_mma<8>(acc, acc2, wA, bA, 0, t > 0 ? 8 : 4);
+      }
+      {
+        const float4 wB[8] = {w1[4], w1[5], w1[6], w1[7], w1[8], w1[9], w1[10], w1[11]};
+        float4 bB[8];
+        const unsigned oc = (unsigned)((((int64_t)t * B + nc) * E + 16 * wave + 4 * q) * 4);
+        pd_fetch<SEN, 8>(bB, [=](int j) { return pd_ld_raw(rc, oc + (unsigned)(64 * j) * 4); }, 0, 8, p.status);   // kb 16..47
+        pd_mma<8>(acc, acc2, wB, bB, 0, 8);
+      }
+      SSASR_DTRACE(t, 5);
+      cell_finish(acc, acc2, bias1, cst1, t, p.gates1, p.c1, p.h1, rh1, PC_H1);
+      SSASR_DTRACE(t, 6);
+    }
+  }
+}
+
 // grid: 64 attention workgroups (blockIdx.x < 64: b = x >> 1, half = x & 1; only b < B work)
 //       then 128 compute workgroups (tile = c >> 1, 16-column chunk = c & 1): 192 in all.
 // The kernel needs ~256 VGPRs, i.e. one workgroup per CU: 192 leaves 64 CUs of slack.
@@ -326,204 +543,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
 
   // -------------------------------- compute role --------------------------------
   const int c = blockIdx.x - PD_NATTWG;
-  const int tile = c >> 1, chunk = c & 1;          // 4 hidden units, 16 utterances
-  const int r = lane & 15, q = lane >> 4;
-  const int n = 16 * chunk + r;                    // this lane's utterance (B operand / epilogue column)
-  const int nc = n < B ? n : 0;
-  f32x4* red = reinterpret_cast<f32x4*>(smem);     // [4][64]
-  float* sH = smem + 4 * 64 * 4;                   // [16][4] transpose buffer, then [256] for the char role
-  const int D = PD_D, E = PD_E;
-  const bool is_chr = c < B;
-
-  // resident weight slices (this wave's k-blocks: kb = wave + 4 j)
-  float4 w1[16], w2[8];
-  {
-    const int rowA = (r & 3) * D + 4 * tile + (r >> 2);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int k = 16 * (wave + 4 * j) + 4 * q;                 // 0 .. 1023 over [emb | ctx | h1]
-      w1[j] = k < D + E ? aload4(p.w_ih1 + (int64_t)rowA * (D + E) + k)
-                        : aload4(p.w_hh1 + (int64_t)rowA * D + (k - D - E));
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = 16 * (wave + 4 * j) + 4 * q;                 // 0 .. 511 over [h1 | h2]
-      w2[j] = k < D ? aload4(p.w_ih2 + (int64_t)rowA * D + k) : aload4(p.w_hh2 + (int64_t)rowA * D + (k - D));
-    }
-  }
-  const int u = 4 * tile + q;                      // epilogue (wave 0): unit u, utterance n
-  const bool epi = wave == 0 && n < B;
-  float bias1[4] = {0.f, 0.f, 0.f, 0.f}, bias2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (epi) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bias1[g] = p.b_ih1[g * D + u] + p.b_hh1[g * D + u];
-      bias2[g] = p.b_ih2[g * D + u] + p.b_hh2[g * D + u];
-    }
-  }
-  float cst1 = 0.f, cst2 = 0.f;
-  const __amdgpu_buffer_rsrc_t rh1 = pd_rsrc(p.hx1, img_h * U);
-  const __amdgpu_buffer_rsrc_t rh2 = pd_rsrc(p.hx2, img_h * U);
-  const __amdgpu_buffer_rsrc_t rc = pd_rsrc(p.ctx, (size_t)U * B * E * sizeof(float));
-  const __amdgpu_buffer_rsrc_t re = pd_rsrc(p.emb_in, (size_t)(U + 1) * B * D * sizeof(float));
-  const unsigned xoi = (unsigned)((q * PD_BP + nc) * 16);          // lane part of an image read
-  unsigned nsamp = 0;                                              // non-teacher steps so far
-
-  // cell epilogue shared by both cells: gates -> state, saves, image store, publish
-  auto cell_finish = [&](const f32x4& acc, const f32x4& acc2, const float (&bias)[4], float& cst, int t,
-                         float* gates, float* cs, float* hs, const __amdgpu_buffer_rsrc_t& rimg, int counter) {
-    red[wave * 64 + lane] = acc + acc2;
-    __syncthreads();
-    if (wave == 0) {
-      if (epi) {
-        f32x4 v = red[lane];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) v += red[w * 64 + lane];
-        const float gi = fast_sigmoid(v[0] + bias[0]), gf = fast_sigmoid(v[1] + bias[1]);
-        const float gg = fast_tanh(v[2] + bias[2]), go = fast_sigmoid(v[3] + bias[3]);
-        const float cc = gf * cst + gi * gg;
-        const float h = go * fast_tanh(cc);
-        cst = cc;
-        sH[r * 4 + q] = h;
-        const int64_t g0 = ((int64_t)t * B + n) * 4 * D + u;
-        gates[g0] = gi; gates[g0 + D] = gf; gates[g0 + 2 * D] = gg; gates[g0 + 3 * D] = go;
-        cs[((int64_t)t * B + n) * D + u] = cc;
-        hs[((int64_t)t * B + n) * D + u] = h;
-      } else if (n >= B) {
-        sH[r * 4 + q] = 0.f;
-      }
-      // lanes of wave 0 exchange through sH without a workgroup barrier
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      if (lane < 16)
-        pd_st_sc1(rimg, (unsigned)(t * img_h + ((tile * PD_BP + 16 * chunk + lane) * 16)),
-                  *reinterpret_cast<const float4*>(sH + lane * 4));
-      if (!SEN) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.cnt + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    __syncthreads();
-  };
-
-  for (int t = 0; t <= U; ++t) {
-    // (A) h1_{t-1} from every compute workgroup
-    SSASR_DTRACE(t, 0);
-    if (!SEN && t > 0) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
-    SSASR_DTRACE(t, 1);
-
-    // (B) (phi_t = tanh(W_phi h1_{t-1}) is computed by the attention workgroups themselves)
-    SSASR_DTRACE(t, 2);
-    // (C) cell 2 of step t-1 (overlaps the attention workgroups' step t)
-    if (t > 0) {
-      const int s = t - 1;
-      if (!SEN && s > 0) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)s);
-      float4 b2[8];
-      {
-        const unsigned o1 = (unsigned)(s * img_h + wave * 4 * PD_BP * 16 + xoi);
-        const unsigned o2 = (unsigned)((s > 0 ? s - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
-        pd_fetch<SEN, 8>(b2, [=](int j) {      // kb = wave + 4 j: 0..15 h1_s, 16..31 h2_{s-1}
-          return j < 4 ? pd_ld_raw(rh1, o1 + (unsigned)(4 * j) * 4 * PD_BP * 16)
-                       : pd_ld_raw(rh2, o2 + (unsigned)(4 * (j - 4)) * 4 * PD_BP * 16);
-        }, 0, s > 0 ? 8 : 4, p.status);
-      }
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-      pd_mma<8>(acc, acc2, w2, b2, 0, s > 0 ? 8 : 4);
-      cell_finish(acc, acc2, bias2, cst2, s, p.gates2, p.c2, p.h2, rh2, PC_H2);
-
-      // (D) next character after step s when it is not teacher forced
-      const int mode = p.modes[s];
-      if (mode != 0) {
-        ++nsamp;
-        if (is_chr && s + 1 <= U) {
-          if (!SEN) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)(s + 1));
-          const int b = c;
-          float* sV = sH;                                       // [256] h2_s of utterance b
-          float* sL = sH + 256;                                 // [V] logits
-          if (tid < 64) {
-            const unsigned ho = (unsigned)(s * img_h + ((tid * PD_BP + b) * 16));
-            float4 hv[1];
-            pd_fetch<SEN, 1>(hv, [=](int) { return pd_ld_raw(rh2, ho); }, 0, 1, p.status);
-            *reinterpret_cast<float4*>(sV + 4 * tid) = hv[0];
-          }
-          __syncthreads();
-          for (int v = wave; v < p.V; v += 4) {
-            const float* wr = p.w_ct + (int64_t)v * D;
-            float a = 0.f;
-            for (int k = lane; k < D; k += 64) a = fmaf(wr[k], sV[k], a);
-            a = wave_sum(a);
-            if (lane == 0) sL[v] = a + p.b_ct[v];
-          }
-          __syncthreads();
-          if (wave == 0) {
-            int best = 0;
-            if (lane == 0) {
-              float mx = sL[0];
-              for (int v = 1; v < p.V; ++v)
-                if (sL[v] > mx) { mx = sL[v]; best = v; }
-              if (mode == 1) {
-                float tot = 0.f;
-                for (int v = 0; v < p.V; ++v) tot += expf(sL[v] - mx);
-                const float target = p.uniforms[(int64_t)s * B + b] * tot;
-                float run = 0.f;
-                best = p.V - 1;
-                for (int v = 0; v < p.V; ++v) {
-                  run += expf(sL[v] - mx);
-                  if (run > target) { best = v; break; }
-                }
-              }
-              p.chars[(int64_t)(s + 1) * B + b] = best;
-            }
-            best = __shfl(best, 0, 64);
-            pd_st_sc1(re, (unsigned)((((int64_t)(s + 1) * B + b) * D + 4 * lane) * 4),
-                      aload4(p.embed + (int64_t)best * D + 4 * lane));
-            if (!SEN) {
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CHAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-          __syncthreads();
-        }
-      }
-    }
-    if (t == U) break;
-
-    // (E) ctx_t from the attention workgroups, emb_t from the character role
-    SSASR_DTRACE(t, 3);
-    if (!SEN) {
-      wt.wait_ge(p.cnt + PC_CTX, n_att * (unsigned)(t + 1));
-      if (t > 0 && p.modes[t - 1] != 0) wt.wait_ge(p.cnt + PC_CHAR, n_chr * nsamp);
-    }
-    SSASR_DTRACE(t, 4);
-
-    // (F) cell 1 of step t: [emb_t | ctx_t | h1_{t-1}].  The emb and h1 thirds do not depend on
-    // the attention: they are fetched and multiplied while ctx_t is still on its way.
-    {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-      {
-        const float4 wA[8] = {w1[0], w1[1], w1[2], w1[3], w1[12], w1[13], w1[14], w1[15]};
-        float4 bA[8];
-        const unsigned oe = (unsigned)((((int64_t)t * B + nc) * D + 16 * wave + 4 * q) * 4);
-        const unsigned oh = (unsigned)((t > 0 ? t - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
-        pd_fetch<SEN, 8>(bA, [=](int j) {      // kb = wave + 4 j: 0..15 emb; then 48..63 h1
-          return j < 4 ? pd_ld_raw(re, oe + (unsigned)(64 * j) * 4)
-                       : pd_ld_raw(rh1, oh + (unsigned)(4 * (j - 4)) * 4 * PD_BP * 16);
-        }, 0, t > 0 ? 8 : 4, p.status);
-        pd_mma<8>(acc, acc2, wA, bA, 0, t > 0 ? 8 : 4);
-      }
-      {
-        const float4 wB[8] = {w1[4], w1[5], w1[6], w1[7], w1[8], w1[9], w1[10], w1[11]};
-        float4 bB[8];
-        const unsigned oc = (unsigned)((((int64_t)t * B + nc) * E + 16 * wave + 4 * q) * 4);
-        pd_fetch<SEN, 8>(bB, [=](int j) { return pd_ld_raw(rc, oc + (unsigned)(64 * j) * 4); }, 0, 8, p.status);   // kb 16..47
-        pd_mma<8>(acc, acc2, wB, bB, 0, 8);
-      }
-      SSASR_DTRACE(t, 5);
-      cell_finish(acc, acc2, bias1, cst1, t, p.gates1, p.c1, p.h1, rh1, PC_H1);
-      SSASR_DTRACE(t, 6);
-    }
-  }
+  pd_compute_role<SEN>(p, c, tid, smem, c < B);
 }
 
 inline size_t decoder_persistent_lds(int T) { return sizeof(float) * ((size_t)T * 256 + 2176 + 256); }

@@ -1,7 +1,7 @@
 """Model-level parity on the GPU against the golden vectors captured from the
 real reference (tests/golden, made by oracle/make_golden.py), and against the
 CPU oracle at sizes the goldens do not cover.  Tolerances: activations 2e-5
-abs, loss 1e-4 abs (north star: 1e-3), per-parameter gradient norms 1e-3 rel.
+abs, loss 1e-4 abs (north star: 1e-3), per-parameter gradient norms 2e-5 rel.
 """
 import random
 
@@ -21,7 +21,7 @@ BENCH_SHAPES = ['bench_b32_t800', 'bench_b32_median']
 # utterances of 1500-3000 frames, T' = 375 (split-T attention inside the per-step decode loop, ~300
 # decode steps), 3000 / 1500 / 750 persistent recurrence steps with the exchange ring wrapping ~370 times
 LONG_SHAPES = ['long_b32_t3000']
-GRAD_NORM_RTOL = 2e-4
+GRAD_NORM_RTOL = 2e-5      # measured on MI355X (round 3): <= 3.3e-6 on every fixture
 
 
 def build(fx):
