@@ -259,7 +259,8 @@ typedef struct ssasr_decoder {
   float* gates1; float* c1; float* h1;   /* [U][B][4D], [U][B][D], [U][B][D]     */
   float* gates2; float* c2; float* h2;
   /* optional workspaces of the single-launch persistent loop (taken for
-   * A = 128, E = 512, D = 256, B <= 32, T <= 128, V <= 64; all five non-NULL) */
+   * A = 128, E = 512, D = 256, B <= 32, T <= 128, V <= 64; all five non-NULL;
+   * longer encoder outputs: see ws_part below) */
   float* ws_hx1; float* ws_hx2;          /* [U][D/4][32][4] each                 */
   float* ws_qx;                          /* [U][A/16][32][16]                    */
   int32_t* ws_modes;                     /* device int32[U]                      */
@@ -273,7 +274,17 @@ typedef struct ssasr_decoder {
                                           * needs ws_sync (time-outs are reported in ws_sync[5])                */
   int32_t ws_attn_phase;                 /* phase of step 0 (step t uses ws_attn_phase + t): the buffer the
                                           * previous call on this workspace did NOT use last                */
+  float* ws_part;                        /* optional: ssasr_decoder_fwd_part_floats(...) floats, every word the fill
+                                          * pattern 0x7FC0DEAD on entry (covered by ws_armed like the images): with
+                                          * ws_hx1, ws_hx2, ws_modes and ws_sync it enables the single-launch
+                                          * persistent loop for LONG encoder outputs (128 < T <= 768, B * ceil(T / 64)
+                                          * <= 192; ws_qx and ws_attn are not used by it)                      */
 } ssasr_decoder;
+
+/* Floats of the record ring of the long-encoder persistent decode loop for a shape; 0 when the
+ * shape, the options or the device (all B * ceil(T / 64) + 64 workgroups of 512 threads resident at
+ * once) do not take that form -- ssasr_decoder_fwd then runs one launch per stage and step. */
+int64_t ssasr_decoder_fwd_part_floats(int64_t B, int64_t T, int64_t A, int64_t E, int64_t D, int64_t V);
 
 int ssasr_decoder_fwd(const ssasr_decoder* d, void* stream);
 

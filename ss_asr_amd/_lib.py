@@ -30,7 +30,8 @@ class Decoder(C.Structure):
          ('w_phi_t', P), ('q', P), ('ctx', P), ('emb_in', P), ('chars', P),
          ('gates1', P), ('c1', P), ('h1', P), ('gates2', P), ('c2', P), ('h2', P),
          ('ws_hx1', P), ('ws_hx2', P), ('ws_qx', P), ('ws_modes', P), ('ws_sync', P),
-         ('modes_ready', C.c_int32), ('ws_armed', C.c_int32), ('ws_attn', P), ('ws_attn_phase', C.c_int32)])
+         ('modes_ready', C.c_int32), ('ws_armed', C.c_int32), ('ws_attn', P), ('ws_attn_phase', C.c_int32),
+         ('ws_part', P)])
 
 
 class DecoderGrads(C.Structure):
@@ -67,6 +68,7 @@ SIGNATURES = {
     'ssasr_attn_step_ws_floats': (I64, [I64, I64, I64, I64]),
     'ssasr_attn_step_fwd': (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, I32, P, P]),
     'ssasr_attn_step_bwd': (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P, P, P]),
+    'ssasr_decoder_fwd_part_floats': (I64, [I64] * 6),
     'ssasr_decoder_fwd': (I32, [C.POINTER(Decoder), P]),
     'ssasr_decoder_bwd': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), P]),
     'ssasr_decoder_wgrad': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), I32, I32, P]),

@@ -5,13 +5,14 @@
 #include "attn_kernels.h"
 #include "rnn_kernels.h"
 #ifdef SSASR_TRACE_BUILD      // diagnostic library (tools/dectrace.py): per-phase timestamps of the persistent decode loop
-constexpr int DTR_STEPS = 64, DTR_SLOTS = 8, DTR_WG = 192;
+constexpr int DTR_STEPS = 64, DTR_SLOTS = 8, DTR_WG = 256;
 __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #define SSASR_DTRACE(step, slot) do { if (threadIdx.x == 0 && (step) < DTR_STEPS) { \
   unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
   g_dtrace[(blockIdx.x * DTR_STEPS + (step)) * DTR_SLOTS + (slot)] = t_; } } while (0)
 #endif
 #include "decoder_persistent.h"
+#include "decoder_long.h"
 #include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
@@ -24,10 +25,28 @@ extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
 #endif
 
 extern "C" int64_t ssasr_decoder_bwd_chain_floats(int64_t U, int64_t B, int64_t T, int64_t A, int64_t E, int64_t D) {
-  if (A != PD_A || E != PD_E || D != PD_D || B <= 0 || B > 32 || T <= 0 || T > 128 || U <= 0) return 0;
+  if (A != PD_A || E != PD_E || D != PD_D || B <= 0 || B > 32 || T <= 0 || U <= 0) return 0;
+  if (chain_slices(T) == 0 || chain_slices(T) * B > CB_MAXATT) return 0;   // frame slices x utterances: one workgroup per CU
   if (chain_xc_floats(U) * sizeof(float) >= (1ull << 31)) return 0;        // 32-bit buffer offsets
   return (int64_t)(U * B * A + ((U * B + 63) & ~(int64_t)63) + chain_xa_floats(U) + chain_xc_floats(U) +
-                   chain_xu_floats(U, B) + U * B * 4 * D);
+                   chain_xu_floats(U, T) + U * B * 4 * D);
+}
+
+namespace {
+bool dec_grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t workgroups);
+// the long-encoder persistent decode loop (decoder_long.h): shape, options, residency
+bool dec_long_taken(int64_t B, int64_t T, int64_t A, int64_t E, int64_t D, int64_t V) {
+  const SsasrOptions& opt = ssasr_options();
+  if (A != PD_A || E != PD_E || D != PD_D || V <= 0 || V > 64 || !pl_shape_ok(B, T)) return false;
+  if (opt.no_persistent || opt.no_persistent_decoder || opt.persistent_counter) return false;
+  const void* fn = reinterpret_cast<const void*>(decoder_fwd_long_kernel);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)decoder_long_lds()) != hipSuccess) return false;
+  return dec_grid_fits(fn, 512, decoder_long_lds(), (int64_t)pl_ns(T) * B + PL_NCMP);
+}
+}  // namespace
+
+extern "C" int64_t ssasr_decoder_fwd_part_floats(int64_t B, int64_t T, int64_t A, int64_t E, int64_t D, int64_t V) {
+  return dec_long_taken(B, T, A, E, D, V) ? pl_part_floats(B, T) : 0;
 }
 
 // ------------------------------ attention ---------------------------------
@@ -261,8 +280,12 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     SSASR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     persistent = dec_grid_fits(fn, 256, lds, PD_NATTWG + 128);
   }
-  const bool sentinel = persistent && !opt.persistent_counter;
-  if (persistent && !d.modes_ready)
+  // ... and for long encoder outputs (128 < T <= 64 * 12, decoder_long.h) when the caller provides the
+  // record ring: the same exchange images (ws_qx is not used) plus ws_part
+  const bool longform = !persistent && d.ws_hx1 && d.ws_hx2 && d.ws_modes && d.ws_sync && d.ws_part &&
+                        dec_long_taken(B, T, A, E, D, V);
+  const bool sentinel = (persistent && !opt.persistent_counter) || longform;
+  if ((persistent || longform) && !d.modes_ready)
     SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
   // (self-verifying loop: rows the loop itself produces start as the fill pattern)
   hipLaunchKernelGGL(embed_chars_kernel, dim3((unsigned)((U + 1) * B)), dim3(64), 0, st, d.embed, d.teacher,
@@ -307,11 +330,35 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     }
     SSASR_LAUNCH_CHECK();
   }
+  if (longform) {
+    DecLong lp{};
+    DecPersist& p = lp.d;
+    p.feat = d.feat; p.comp = d.comp; p.enc_len = d.enc_len; p.w_phi = d.w_phi;
+    p.w_ih1 = d.w_ih1; p.w_hh1 = d.w_hh1; p.b_ih1 = d.b_ih1; p.b_hh1 = d.b_hh1;
+    p.w_ih2 = d.w_ih2; p.w_hh2 = d.w_hh2; p.b_ih2 = d.b_ih2; p.b_hh2 = d.b_hh2;
+    p.embed = d.embed; p.w_ct = d.w_ct; p.b_ct = d.b_ct; p.uniforms = d.uniforms; p.modes = d.ws_modes;
+    p.att = d.att; p.q = d.q; p.ctx = d.ctx; p.emb_in = d.emb_in; p.chars = d.chars;
+    p.gates1 = d.gates1; p.c1 = d.c1; p.h1 = d.h1; p.gates2 = d.gates2; p.c2 = d.c2; p.h2 = d.h2;
+    p.hx1 = d.ws_hx1; p.hx2 = d.ws_hx2; p.qx = nullptr;
+    p.cnt = reinterpret_cast<unsigned*>(d.ws_sync); p.status = d.ws_sync + 5;
+    p.B = (int)B; p.T = (int)T; p.U = (int)U; p.V = (int)V;
+    lp.part = d.ws_part; lp.NS = pl_ns(T);
+    if (!armed) {      // every exchanged buffer starts as the fill pattern
+      const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4;
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, img_h * U, st));
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx2, (int)PERSIST_SENTINEL, img_h * U, st));
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ctx, (int)PERSIST_SENTINEL, (size_t)(U * B * E), st));
+      SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_part, (int)PERSIST_SENTINEL, (size_t)pl_part_floats(B, T), st));
+    }
+    hipLaunchKernelGGL(decoder_fwd_long_kernel, dim3((unsigned)(lp.NS * B + PL_NCMP)), dim3(512), decoder_long_lds(), st, lp);
+    SSASR_LAUNCH_CHECK();
+  }
+  const bool looped = !persistent && !longform;       // one launch per stage and step
   const int nch = attn_pick_nch((int)E);
   dim3 cgrid = cell_fwd_grid(D, 1, B), cblock(256);
-  // q_0 = 0 (the persistent loop writes every q_t itself)
-  if (!persistent) SSASR_HIP(hipMemsetAsync(d.q, 0, sizeof(float) * B * A, st));
-  for (int64_t t = 0; t < U && !persistent; ++t) {
+  // q_0 = 0 (the persistent loops write every q_t themselves)
+  if (looped) SSASR_HIP(hipMemsetAsync(d.q, 0, sizeof(float) * B * A, st));
+  for (int64_t t = 0; t < U && looped; ++t) {
     // q_t = tanh(phi(h1_{t-1})); the state is zero at t = 0 and phi has no bias
     if (t) launch_phi(d.h1 + (t - 1) * B * D, d.w_phi, d.q + t * B * A, B, A, D, st);
     AttnFwd p{};
@@ -433,11 +480,14 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
   const bool cell2_direct = cell2_first && ssasr_bptt_ksplit_ok(U, B, D, 1);
   bool chain = cell2_first && g.ws_chain && ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D) > 0 &&
                !opt.no_persistent_decoder_bwd;
+  const int nsl = chain_slices(T);
+  const void* chain_fn = nsl == 6 ? reinterpret_cast<const void*>(decoder_bwd_chain_kernel<6>)
+                       : nsl == 4 ? reinterpret_cast<const void*>(decoder_bwd_chain_kernel<4>)
+                                  : reinterpret_cast<const void*>(decoder_bwd_chain_kernel<2>);
   if (chain) {
     const size_t lds = chain_lds_bytes((int)T);
-    SSASR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_chain_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    chain = dec_grid_fits(reinterpret_cast<const void*>(decoder_bwd_chain_kernel), 320, lds, CB_NATTWG + 64);
+    SSASR_HIP(hipFuncSetAttribute(chain_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    chain = dec_grid_fits(chain_fn, 320, lds, nsl * B + 64);
   }
   if (!chain) {
     if ((rc = ssasr_launch_transpose(d.w_phi, d.w_phi_t, (int)A, (int)D, st))) return rc;
@@ -480,7 +530,7 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     float* xa = wsS + ((U * B + 63) & ~(int64_t)63);
     float* xc = xa + chain_xa_floats(U);
     float* xu = xc + chain_xc_floats(U);
-    float* dg1 = xu + chain_xu_floats(U, B);
+    float* dg1 = xu + chain_xu_floats(U, T);
     {   // V[t][b][:] = att[b][t][:] . comp[b]      (all steps, one batched product)
       GemmDesc m{};
       m.A = d.att; m.ma = rm_dense(T); m.sa = U * T;
@@ -492,7 +542,7 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     }
     if (!armed)
       SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)xa, (int)PERSIST_SENTINEL,
-                                  chain_xa_floats(U) + chain_xc_floats(U) + chain_xu_floats(U, B), st));
+                                  chain_xa_floats(U) + chain_xc_floats(U) + chain_xu_floats(U, T), st));
     DecBwdChain c{};
     c.gates1 = d.gates1; c.dg1 = dg1; c.c1 = d.c1; c.add1 = g.ws_dh2; c.att = d.att; c.q = d.q; c.feat = d.feat;
     c.comp = d.comp; c.enc_len = d.enc_len; c.V = wsV; c.w_hh1 = d.w_hh1; c.w_ih1 = d.w_ih1;
@@ -500,7 +550,10 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     c.xa = xa; c.xc = xc; c.xu = xu; c.status = g.ws_sync + 5;
     c.B = (int)B; c.T = (int)T; c.U = (int)U;
     const size_t lds = chain_lds_bytes((int)T);
-    hipLaunchKernelGGL(decoder_bwd_chain_kernel, dim3(CB_NATTWG + 64), dim3(320), lds, st, c);
+    const dim3 cgrid_chain((unsigned)(nsl * B + 64));
+    if (nsl == 6) hipLaunchKernelGGL(decoder_bwd_chain_kernel<6>, cgrid_chain, dim3(320), lds, st, c);
+    else if (nsl == 4) hipLaunchKernelGGL(decoder_bwd_chain_kernel<4>, cgrid_chain, dim3(320), lds, st, c);
+    else hipLaunchKernelGGL(decoder_bwd_chain_kernel<2>, cgrid_chain, dim3(320), lds, st, c);
     hipLaunchKernelGGL(chain_de_fixup_kernel, dim3(256), dim3(256), 0, st, g.ws_de, d.att, wsS, (int)B, (int)U, (int)T,
                        reinterpret_cast<float4*>(d.gates1), reinterpret_cast<const float4*>(dg1), U * B * D,
                        g.ws_dqpre, (int)(B * A));

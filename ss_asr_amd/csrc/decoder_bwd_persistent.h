@@ -1,7 +1,7 @@
 // Persistent backward of the decode loop's serial chain: first speller cell
 // <-> attention (the second cell's BPTT has no part in it and runs before, see
 // decoder.hip), all U steps in ONE launch, for A = 128, E = 512, D = 256,
-// B <= 32, T <= 128.
+// B <= 32, T <= 384 (NSL * B <= 192 attention workgroups: see chain_slices).
 //
 // Per step t (U-1 .. 0) the chain is
 //   dh1_t   = dG2_t W_ih2 (given, all steps)  +  dG1_{t+1} W_hh1  +  dqpre_{t+1} W_phi
@@ -16,13 +16,15 @@
 //    gate-derivative rows into partial tiles of dh1_{t-1} (half h: 8 of 16 unit
 //    tiles) and of dctx_t (half h: 16 of 32 column tiles), weights resident in
 //    registers.  A helper wave pre-folds the saved activations into coefficients.
-//  * 2 "attention" workgroups per utterance, split over the encoder frames: each
-//    keeps its half of feat[b] in LDS for the whole loop, sums the 16 partial dctx
-//    tiles, and publishes U_h = sum_frames alpha dalpha comp  (128 values) and
-//    s_h = sum_frames alpha dalpha.  Because de is linear in the global scalar
-//    s = s_0 + s_1, the consumer forms dq = U_0 + U_1 - s V_t with
-//    V_t = alpha_t^T comp precomputed for all steps by one GEMM: the two halves
-//    never have to meet, and the step has two hand-offs instead of three.
+//  * NSL = 2, 4 or 6 "attention" workgroups per utterance, split over the encoder
+//    frames (slices of <= 64): each keeps its slice of feat[b] in LDS for the whole
+//    loop, sums the 16 partial dctx tiles, and publishes U_h = sum_frames alpha dalpha
+//    comp (128 values) and s_h = sum_frames alpha dalpha.  Because de is linear in
+//    the global scalar s = sum_h s_h, the consumer forms dq = sum_h U_h - s V_t with
+//    V_t = alpha_t^T comp precomputed for all steps by one GEMM: the slices never
+//    have to meet, and the step has two hand-offs instead of three -- for any number
+//    of slices, which is what lets long encoder outputs (T' = 375: six slices) keep
+//    the two-hand-off chain.
 // Hand-offs are the self-verifying write-through exchanges of rnn_kernels.h
 // (fresh, pattern-filled buffers for every step).  de is stored as alpha dalpha;
 // the "- alpha s" term is applied after the loop by chain_de_fixup_kernel.
@@ -31,12 +33,16 @@
 
 namespace {
 
-constexpr int CB_NATTWG = 64;                 // attention workgroups: utterance b = x >> 1, frame half = x & 1
-// Attention results per step: [chunk 2][frame half 2][slot 34][utterance 16][4] floats; slots 0..31
+// Attention workgroups: utterance b = x / NSL, frame slice = x % NSL (NSL * B of them).
+// Attention results per step: [chunk 2][frame slice NSL][slot 34][utterance 16][4] floats; slots 0..31
 // hold U (slot = column quad), slot 32 holds s in .x.  Utterance-minor, so that the 16 lanes of
 // a cell workgroup that want the same slot for their 16 utterances read 256 contiguous bytes.
 constexpr int CB_XU_SLOTS = 34;
-constexpr int CB_XU_STEP = 2 * 2 * CB_XU_SLOTS * 16 * 4;      // floats per step
+constexpr int CB_MAXATT = 192;                // NSL * B attention + 64 cell workgroups: at most one per CU
+__host__ __device__ inline int cb_xu_step(int nsl) { return 2 * nsl * CB_XU_SLOTS * 16 * 4; }      // floats per step
+// frame slices per utterance: 2 up to 128 frames (the training shapes), then 4 / 6 slices of <= 64 frames;
+// 0: no persistent chain for this length
+__host__ __device__ inline int chain_slices(int64_t T) { return T <= 128 ? 2 : T <= 256 ? 4 : T <= 384 ? 6 : 0; }
 
 struct DecBwdChain {
   const float* gates1;    // [U][B][4D] activated gates (read by BOTH halves of a tile: never written here)
@@ -58,16 +64,17 @@ struct DecBwdChain {
   float* ssum;            // [U][B]
   float* xa;              // [U][2][16 dest][16 src][64][4]   partial dh1 tiles
   float* xc;              // [U][2][16 utterances][16 src][512] partial dctx rows (contiguous per utterance)
-  float* xu;              // [U][CB_XU_STEP]
+  float* xu;              // [U][cb_xu_step(NSL)]
   int* status;
   int B, T, U;
 };
 
 __host__ __device__ inline size_t chain_xa_floats(int64_t U) { return (size_t)U * 2 * 16 * 16 * 256; }
 __host__ __device__ inline size_t chain_xc_floats(int64_t U) { return (size_t)U * 2 * 16 * 32 * 256; }
-__host__ __device__ inline size_t chain_xu_floats(int64_t U, int64_t) { return (size_t)U * CB_XU_STEP; }
+__host__ __device__ inline size_t chain_xu_floats(int64_t U, int64_t T) { return (size_t)U * cb_xu_step(chain_slices(T)); }
 inline size_t chain_lds_bytes(int T) {
-  const size_t att = ((size_t)((T + 1) / 2) * PD_E + PD_E + 8 * PD_A + 16) * sizeof(float);
+  const int nsl = chain_slices(T);
+  const size_t att = ((size_t)((T + nsl - 1) / nsl) * PD_E + PD_E + 8 * PD_A + 16) * sizeof(float);
   const size_t cell = (4 * 64 * 4 + 2 * 7 * 64 * 4 + 4 * 64 * 4 + 8 * 4 * 16 * 4) * sizeof(float);
   return att > cell ? att : cell;
 }
@@ -142,8 +149,9 @@ __device__ __forceinline__ bool cb_fetch(u32x4 (&raw)[NV], F ld, int* status) {
   return missed;
 }
 
-// grid: CB_NATTWG attention workgroups, then 16 tiles x 2 chunks x 2 halves = 64 cell workgroups; 320 threads
+// grid: NSL * B attention workgroups, then 16 tiles x 2 chunks x 2 halves = 64 cell workgroups; 320 threads
 // dynamic LDS: chain_lds_bytes(T)
+template <int NSL>
 __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -151,15 +159,17 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
   constexpr int D = PD_D, E = PD_E, A = PD_A;
   const __amdgpu_buffer_rsrc_t rxa = pd_rsrc(p.xa, chain_xa_floats(U) * sizeof(float));
   const __amdgpu_buffer_rsrc_t rxc = pd_rsrc(p.xc, chain_xc_floats(U) * sizeof(float));
-  const __amdgpu_buffer_rsrc_t rxu = pd_rsrc(p.xu, chain_xu_floats(U, B) * sizeof(float));
+  const __amdgpu_buffer_rsrc_t rxu = pd_rsrc(p.xu, chain_xu_floats(U, T) * sizeof(float));
   constexpr unsigned TILE_B = 64 * 16;                       // bytes of one 16 x 16 tile in lane order
   constexpr unsigned XA_STEP = 2u * 16 * 16 * TILE_B, XC_STEP = 2u * 16 * 32 * TILE_B;
+  constexpr int CB_XU_STEP = 2 * NSL * CB_XU_SLOTS * 16 * 4;      // = cb_xu_step(NSL)
+  const int natt = NSL * B;
 
-  if (blockIdx.x < CB_NATTWG) {
+  if ((int)blockIdx.x < natt) {
     // ------------------------------ attention role ------------------------------
-    const int b = blockIdx.x >> 1, th = blockIdx.x & 1;
-    if (b >= B || wave == 4) return;
-    const int Th = (T + 1) / 2;
+    const int b = (int)blockIdx.x / NSL, th = (int)blockIdx.x - b * NSL;
+    if (wave == 4) return;
+    const int Th = (T + NSL - 1) / NSL;                      // <= 64 frames per slice
     const int tau0 = th * Th;
     int len = p.enc_len ? p.enc_len[b] : T;
     len = len < T ? len : T;
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
 #pragma unroll
           for (int g = 0; g < 8; ++g) v.x += sS[g];
         }
-        pd_st_sc1(rxu, (unsigned)(t * CB_XU_STEP + ((((c * 2 + th) * CB_XU_SLOTS + lane) * 16 + bl) * 4)) * 4u, v);
+        pd_st_sc1(rxu, (unsigned)(t * CB_XU_STEP + ((((c * NSL + th) * CB_XU_SLOTS + lane) * 16 + bl) * 4)) * 4u, v);
       }
       SSASR_DTRACE(U - 1 - t, 3);
       __syncthreads();            // sD / sRed / sS are rewritten next step
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
   }
 
   // ---------------------------------- cell role ----------------------------------
-  const int cidx = blockIdx.x - CB_NATTWG;
+  const int cidx = (int)blockIdx.x - natt;
   const int tile = cidx >> 2, chunk = (cidx >> 1) & 1, half = cidx & 1;
   const int r = lane & 15, q = lane >> 4;
   const int n0 = 16 * chunk;
@@ -382,28 +392,33 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       const float* qq = p.q + ((int64_t)(t + 1) * B + nb) * A + 8 * ablk;
       const float4 vv0 = aload4(vq), vv1 = aload4(vq + 4), qv0 = aload4(qq), qv1 = aload4(qq + 4);
       // results of step t + 1: partial dh1 tiles and the attention's U_h, s_h
-      u32x4 raw[10];
+      u32x4 raw[4 + 3 * NSL];
       const unsigned xab = (unsigned)(t + 1) * XA_STEP + (unsigned)chunk * (16 * 16 * TILE_B) +
                            (unsigned)tile * (16 * TILE_B) + (unsigned)lane * 16;
-      // slot s of frame half h for utterance nb: (((nb / 16) * 2 + h) * SLOTS + s) * 16 + nb % 16, in float4 units
-      const unsigned xub = (unsigned)((t + 1) * CB_XU_STEP) * 4u + (unsigned)(((nb >> 4) * 2 * CB_XU_SLOTS) * 16 + (nb & 15)) * 16u;
+      // slot s of frame slice h for utterance nb: (((nb / 16) * NSL + h) * SLOTS + s) * 16 + nb % 16, in float4 units
+      const unsigned xub = (unsigned)((t + 1) * CB_XU_STEP) * 4u + (unsigned)(((nb >> 4) * NSL * CB_XU_SLOTS) * 16 + (nb & 15)) * 16u;
       constexpr unsigned XU_SLOT = 16 * 16, XU_HALF = CB_XU_SLOTS * 16 * 16;      // bytes
       pacer.sleep();
-      const bool missed = cb_fetch<10>(raw, [=](int j) {
+      const bool missed = cb_fetch<4 + 3 * NSL>(raw, [=](int j) {
+        // 0..3: partial dh1 tiles; then per frame slice h: its two quads of U_h (4 + 2 h, 5 + 2 h); then s_h
         return j < 4 ? pd_ld_raw(rxa, xab + (unsigned)(wave + 4 * j) * TILE_B)
-             : j < 6 ? pd_ld_raw(rxu, xub + (unsigned)(2 * ablk + (j - 4)) * XU_SLOT)              // U_0
-             : j < 8 ? pd_ld_raw(rxu, xub + XU_HALF + (unsigned)(2 * ablk + (j - 6)) * XU_SLOT)    // U_1
-             : pd_ld_raw(rxu, xub + (unsigned)(j - 8) * XU_HALF + 32u * XU_SLOT);                  // s_h
+             : j < 4 + 2 * NSL ? pd_ld_raw(rxu, xub + (unsigned)((j - 4) >> 1) * XU_HALF + (unsigned)(2 * ablk + ((j - 4) & 1)) * XU_SLOT)
+             : pd_ld_raw(rxu, xub + (unsigned)(j - 4 - 2 * NSL) * XU_HALF + 32u * XU_SLOT);
       }, p.status);
       pacer.update(missed);
       SSASR_DTRACE(i, 1);
       part = (__builtin_bit_cast(f32x4, raw[0]) + __builtin_bit_cast(f32x4, raw[1])) +
              (__builtin_bit_cast(f32x4, raw[2]) + __builtin_bit_cast(f32x4, raw[3]));
-      const float s = __builtin_bit_cast(f32x4, raw[8])[0] + __builtin_bit_cast(f32x4, raw[9])[0];
+      float s = __builtin_bit_cast(f32x4, raw[4 + 2 * NSL])[0];
+#pragma unroll
+      for (int h = 1; h < NSL; ++h) s += __builtin_bit_cast(f32x4, raw[4 + 2 * NSL + h])[0];       // fixed order
       float4 dq[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const f32x4 ua = __builtin_bit_cast(f32x4, raw[4 + k]), ub = __builtin_bit_cast(f32x4, raw[6 + k]);
+        f32x4 ua = __builtin_bit_cast(f32x4, raw[4 + k]);
+#pragma unroll
+        for (int h = 1; h < NSL; ++h) ua += __builtin_bit_cast(f32x4, raw[4 + 2 * h + k]);
+        const f32x4 ub = f32x4{0.f, 0.f, 0.f, 0.f};
         const float4 vv = k ? vv1 : vv0, qv = k ? qv1 : qv0;
         dq[k].x = col_ok ? (ua[0] + ub[0] - s * vv.x) * (1.f - qv.x * qv.x) : 0.f;
         dq[k].y = col_ok ? (ua[1] + ub[1] - s * vv.y) * (1.f - qv.y * qv.y) : 0.f;

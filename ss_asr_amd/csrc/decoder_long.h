@@ -26,7 +26,7 @@
 // (pd_compute_role: cell 2 of step t - 1, the next character, cell 1 of step t), unchanged.
 // A step has three hand-offs (h1 -> records -> ctx -> h1) instead of the short form's two.
 // NS * B <= 192 attention + 64 compute workgroups = at most one per CU; every wait is bounded
-// (status word, kernel id PK_DEC_LONG) and the launch drains through the latch.
+// (status word, kernel id PK_DEC_FWD) and the launch drains through the latch.
 #pragma once
 #include "decoder_persistent.h"
 

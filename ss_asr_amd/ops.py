@@ -17,8 +17,7 @@ from ._lib import check
 _persist_status = []     # int32[8] workspaces of persistent launches not yet checked
 TIMEOUT_MESSAGE = 'ss_asr_amd: a persistent recurrence / decode loop timed out'
 _KERNELS = {1: 'encoder forward recurrence', 2: 'encoder BPTT (K-split)', 3: 'encoder BPTT (gather)',
-            4: 'decode loop forward', 5: 'decoder backward chain', 6: 'split-T attention step',
-            7: 'decode loop forward (long encoder output)'}
+            4: 'decode loop forward', 5: 'decoder backward chain', 6: 'split-T attention step'}
 
 
 def describe_status(words):
@@ -626,24 +625,28 @@ class _DecoderLoop(torch.autograd.Function):
                     chars=torch.empty(U + 1, B, device=dev, dtype=torch.int32),
                     gates1=f(U, B, 4 * D), c1=f(U, B, D), h1=f(U, B, D),
                     gates2=f(U, B, 4 * D), c2=f(U, B, D), h2=f(U, B, D))
-        if A == 128 and E == 512 and D == 256 and B <= 32 and T <= 128 and V <= 64:
-            # workspaces of the persistent decode loop
-            # (the three exchange images back to back: one fill instead of three)
-            # (... and the context rows behind them: all four start as the fill pattern)
-            nimg = U * (2 * (D // 4) * 32 * 4 + (A // 16) * 32 * 16)
+        geom = _decoder_fwd_ws(B, T, U, A, E, D, V)
+        if geom is not None:
+            # workspaces of the persistent decode loop: the exchange images back to back, the context
+            # rows behind them, then (long encoder outputs) the record ring -- all start as the fill
+            # pattern, one fill instead of four
+            nh, nq, npart = geom
+            nimg, nctx = 2 * nh + nq, U * B * E
             if slots is not None and slots.get('fwd') is not None:
-                img = slots['fwd_arena'].take(slots['fwd'])[:nimg + U * B * E]     # armed by the arena
-                assert img.numel() == nimg + U * B * E
+                img = slots['fwd_arena'].take(slots['fwd'])[:nimg + nctx + npart]     # armed by the arena
+                assert img.numel() == nimg + nctx + npart
                 ctx_armed = True
             else:
-                img = f(nimg + U * B * E)
+                img = f(nimg + nctx + npart)
                 ctx_armed = False
-            nh = U * (D // 4) * 32 * 4
-            bufs.update(ws_hx1=img[:nh], ws_hx2=img[nh:2 * nh], ws_qx=img[2 * nh:nimg],
-                        ctx=img[nimg:].view(U, B, E),
+            bufs.update(ws_hx1=img[:nh], ws_hx2=img[nh:2 * nh], ctx=img[nimg:nimg + nctx].view(U, B, E),
                         ws_modes=modes_dev if modes_dev is not None else
                         torch.empty(U, device=dev, dtype=torch.int32),
                         ws_sync=_status_words(dev))
+            if nq:
+                bufs['ws_qx'] = img[2 * nh:nimg]
+            if npart:
+                bufs['ws_part'] = img[nimg + nctx:]
             _track_status(bufs['ws_sync'], 5)
         if 'ctx' not in bufs:
             bufs['ctx'] = f(U, B, E)
@@ -791,15 +794,30 @@ def decoder_loop(feat, comp, enc_len, teacher, step_mode, uniforms, params, mode
                               modes_dev, slots, *plist)
 
 
+def _decoder_fwd_ws(B, T, U, A, E, D, V):
+    """(floats of one h image over all steps, of the q image, of the record ring) for the decode
+    loop's persistent forward forms, or None when the shape takes one launch per stage and step:
+    T <= 128 -> the short form (csrc/decoder_persistent.h); longer encoder outputs -> the form of
+    csrc/decoder_long.h when the library says it is taken (ssasr_decoder_fwd_part_floats)."""
+    if not (A == 128 and E == 512 and D == 256 and B <= 32 and V <= 64 and U > 0):
+        return None
+    nh = U * (D // 4) * 32 * 4
+    if T <= 128:
+        return nh, U * (A // 16) * 32 * 16, 0
+    npart = int(_lib.load().ssasr_decoder_fwd_part_floats(B, T, A, E, D, V))
+    return (nh, 0, npart) if npart else None
+
+
 def decoder_reserve(fwd_arena, bwd_arena, B, T, U, A=128, E=512, D=256, V=64):
     """Reserves the decode loop's exchange workspaces in the two arenas of a pass (forward
-    images + context rows; cell-2 ring + chain workspace).  Returns the `slots` argument of
-    decoder_loop, or None when the sizes have no persistent form."""
+    images + context rows (+ record ring); cell-2 ring + chain workspace).  Returns the `slots`
+    argument of decoder_loop, or None when the sizes have no persistent form."""
     lib = _lib.load()
-    if not (A == 128 and E == 512 and D == 256 and B <= 32 and T <= 128 and V <= 64 and U > 0):
+    geom = _decoder_fwd_ws(B, T, U, A, E, D, V)
+    if geom is None:
         return None
     slots = dict(fwd_arena=fwd_arena, bwd_arena=bwd_arena, fwd=None, ring=None, chain=None)
-    slots['fwd'] = fwd_arena.reserve(U * (2 * (D // 4) * 32 * 4 + (A // 16) * 32 * 16) + U * B * E)
+    slots['fwd'] = fwd_arena.reserve(2 * geom[0] + geom[1] + U * B * E + geom[2])
     ring = int(lib.ssasr_bilstm_bwd_ring_floats(U, B, D, 1))
     chain = int(lib.ssasr_decoder_bwd_chain_floats(U, B, T, A, E, D))
     if ring and chain:

@@ -152,3 +152,58 @@ def test_joint_ctc_attention_step_matches_the_oracle(frames, chars, weight):
     worst = max(worst, float((sd['ctc_head.weight'].cpu() - head.weight).abs().max()),
                 float((sd['ctc_head.bias'].cpu() - head.bias).abs().max()))
     assert worst < 5e-4, worst
+
+
+def test_joint_step_at_config4_full_size_matches_the_oracle_fixture(golden):
+    """BASELINE.json configs[3] at its own size -- 32 utterances of 1500-3000 frames, 150-300
+    characters, ctc_weight 0.3: ONE joint train step (Listener at 3000 / 1500 / 750 persistent steps,
+    the long-encoder persistent decode loop, the CTC lattice at T' = 375 with 601 states, clip,
+    Adadelta) against tests/golden/joint_long_b32_t3000.npz, which oracle/make_joint_golden.py made
+    with the CPU oracle's joint_train_step (build-defined branch: the reference has no CTC; the
+    attention half of the oracle is pinned to the reference at this shape by long_b32_t3000)."""
+    from conftest import fixture_xy
+    from ss_asr_amd import ops
+    from ss_asr_amd.ctc import JointCTCASR, JointCTCTrainStep
+    fx = golden('joint_long_b32_t3000')
+    x, y = fixture_xy(fx)
+    lens = [int(v) for v in fx['lens']]
+    dims = [int(v) for v in fx['dims']]
+    model = JointCTCASR(*dims, 1.0, ctc_weight=float(fx['ctc_weight']))
+    lo.seeded_weights(model, int(fx['weights_seed']))          # same names, same draws; the head is set below
+    g = torch.Generator().manual_seed(int(fx['head_seed']))
+    model.ctc_head.weight.data = torch.randn(dims[0], 512, generator=g) / 512 ** 0.5
+    model.ctc_head.bias.data = torch.randn(dims[0], generator=g) / 10
+    model = model.to('cuda:0')
+    names = [str(n) for n in fx['param_names']]
+    step = JointCTCTrainStep(model)
+    # gradients are zeroed by the fused update: capture them through the optimizer's view before it runs
+    grads = {}
+    real = step.optim.clip_and_step
+
+    def capture(*a, **k):
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            grads[n] = p.grad.detach().clone()
+        return real(*a, **k)
+    step.optim.clip_and_step = capture
+    random.seed(0)
+    loss = float(step(x.cuda(), y.cuda(), lens, int(fx['ans_len'])))
+    norm, skipped = step.finish()
+    ops.check_persistent_status()
+    assert not skipped
+    assert abs(float(step.last_att_loss) - float(fx['att_loss'])) < 1e-4
+    assert abs(float(step.last_ctc_loss) - float(fx['ctc_loss'])) < 2e-5 * max(1.0, float(fx['ctc_loss']))
+    assert abs(loss - float(fx['loss'])) < 1e-4 * max(1.0, float(fx['loss']))
+    assert abs(norm - float(fx['grad_norm'])) < 2e-4 * max(1.0, float(fx['grad_norm']))
+    got = np.array([grads[n].double().norm().item() for n in names])
+    np.testing.assert_allclose(got, fx['grad_norms'], rtol=2e-4, atol=1e-6)
+    logits = step.last_logits.detach().reshape(-1)[::997][:2048].cpu().numpy()
+    np.testing.assert_allclose(logits, fx['logits_sample'], atol=5e-5, rtol=0)
+    params = dict(model.named_parameters())
+    for k in fx.files:
+        if k.startswith('g_head/'):
+            np.testing.assert_allclose(grads[k[7:]].reshape(-1)[:256].cpu().numpy(), fx[k], atol=2e-5, rtol=0, err_msg=k)
+        if k.startswith('w1_head/'):
+            np.testing.assert_allclose(params[k[8:]].detach().reshape(-1)[:256].cpu().numpy(), fx[k], atol=1e-4,
+                                       rtol=0, err_msg=k)

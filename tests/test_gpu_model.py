@@ -337,6 +337,63 @@ def test_persistent_decode_loop_equals_multi_launch_loop():
         np.testing.assert_allclose(x.numpy(), y.numpy(), atol=5e-5 * max(1.0, float(y.abs().max())), rtol=0)
 
 
+@pytest.mark.parametrize('B,Tp,U,lens', [
+    (32, 375, 24, [375 - 7 * k for k in range(32)]),          # BASELINE.json configs[3]: six slices of 64 frames
+    (5, 129, 9, [129, 128, 65, 64, 1]),                       # three slices, lengths on slice edges, a one-frame utterance
+    (16, 250, 12, [250 - 13 * k for k in range(16)]),         # four slices; utterances that end before the last slice starts
+    (7, 384, 8, [384, 383, 321, 320, 192, 64, 3]),            # the longest encoder output the backward chain takes
+])
+def test_long_encoder_persistent_decode_loop_equals_multi_launch_loop(B, Tp, U, lens):
+    """Encoder outputs longer than 128 frames take the register-resident persistent decode loop
+    (csrc/decoder_long.h: frame slices of 64 per workgroup, partial softmaxes combined in-launch)
+    and the frame-sliced persistent backward chain.  With the same coin flips and uniforms they
+    must feed the same characters and give the same logits / attention / gradients as the
+    one-launch-per-stage loops (split-T attention kernel per step), teacher-forced, sampled and
+    greedy steps alike."""
+    from ss_asr_amd import _lib, ops
+    from ss_asr_amd.asr import ASR
+    assert int(_lib.load().ssasr_decoder_fwd_part_floats(B, Tp, 128, 512, 256, 50)) > 0, 'long form not taken'
+    torch.manual_seed(5)
+    model = ASR(50, 256, 256, 128, 80, 0.5).to('cuda:0')
+    feat = torch.randn(B, Tp, 512, device='cuda')
+    enc_len = torch.tensor(lens, dtype=torch.int32, device='cuda')
+    for b, l in enumerate(lens):
+        feat[b, l:] = 0
+    teacher = torch.randint(3, 50, (B, U + 2), device='cuda').to(torch.int32)
+    modes = ([0, 1, 0, 0, 2, 1, 1, 0, 0, 0, 1, 0, 2, 0] * 2)[:U]
+    uniforms = torch.rand(U, B, device='cuda')
+    results = []
+    try:
+        for per_step in (0, 1):
+            _lib.set_option('SSASR_NO_PERSISTENT_DECODER', per_step)
+            _lib.set_option('SSASR_NO_PERSISTENT_DECODER_BWD', per_step)
+            f = feat.clone().requires_grad_(True)
+            comp = ops.attn_precompute(f, model.attention.psi.weight, model.attention.psi.bias)
+            logits, att, chars = ops.decoder_loop(f, comp, enc_len, teacher, modes, uniforms,
+                                                  model._decoder_params())
+            model.zero_grad()
+            (logits * torch.linspace(0.5, 1.5, 50, device='cuda')).sum().backward()
+            torch.cuda.synchronize()
+            ops.check_persistent_status()
+            results.append((logits.detach().cpu(), att.cpu(), chars.cpu(), f.grad.cpu(),
+                            model.decoder.layer_1.weight_ih.grad.cpu().clone(),
+                            model.decoder.layer_2.weight_hh.grad.cpu().clone(),
+                            model.attention.phi.weight.grad.cpu().clone(),
+                            model.attention.psi.weight.grad.cpu().clone(),
+                            model.embed.weight.grad.cpu().clone()))
+    finally:
+        _lib.set_option('SSASR_NO_PERSISTENT_DECODER', 0)
+        _lib.set_option('SSASR_NO_PERSISTENT_DECODER_BWD', 0)
+    a, b = results
+    assert torch.equal(a[2], b[2])                                  # same characters fed
+    np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), atol=2e-6, rtol=0)
+    for b_idx, l in enumerate(lens):                                # nothing attends past an utterance's end
+        assert float(a[1][b_idx, :, l:].abs().sum()) == 0.0
+    for x, y in zip(a[3:], b[3:]):
+        np.testing.assert_allclose(x.numpy(), y.numpy(), atol=5e-5 * max(1.0, float(y.abs().max())), rtol=0)
+
+
 @pytest.mark.slow
 def test_long_utterances_config4_shape_against_the_oracle():
     """BASELINE.json configs[3] in miniature: 1,500+ frame utterances (T' = 192 > 128, so the
