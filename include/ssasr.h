@@ -48,7 +48,7 @@ int ssasr_abi_version(void);
  * SSASR_FWD_NB, SSASR_BPTT_GATHER, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
  * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
  * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_GEMM_X6, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
- * SSASR_TEST_DROP_TILE (fault injection for the timeout test, -1 = off), SSASR_BPTT_LOCAL,
+ * SSASR_TEST_DROP_TILE (fault injection for the timeout test, -1 = off), SSASR_BPTT_LOCAL, SSASR_FWD_LOCAL,
  * SSASR_XCD_ROUND_ROBIN (the probe's verdict, settable for tests).  Unknown name: -1. */
 int ssasr_set_option(const char* name, int value);
 int ssasr_get_option(const char* name, int* value);
@@ -58,13 +58,16 @@ int ssasr_get_option(const char* name, int* value);
 int ssasr_events_create(void** handle);
 int ssasr_events_destroy(void* handle);
 
-/* Placement probe.  The K-split BPTT can keep each of its exchange groups on ONE XCD and hand data
- * over through that XCD's L2 instead of the fabric (and `beside` GEMMs then keep to the other XCDs).
- * That rests on an observed property of the dispatcher -- in a 1-D launch blocks b and b + 8 share
- * an XCD, the classes b & 7 sit on eight different XCDs -- which this call verifies on the current
- * device, once (synchronous; the one place where the library allocates: 8 KB of scratch, freed
- * before it returns).  1 = holds (XCD-local placement is used unless SSASR_BPTT_LOCAL=0), 0 = does
- * not (spread placement), negative = HIP error.  Until it has been called the spread placement is used. */
+/* Placement probe.  The persistent recurrences can keep each of their exchange groups on ONE XCD and
+ * hand data over through that XCD's L2 instead of the fabric, on request: the forward recurrence of
+ * H = 256, N <= 32 layers (SSASR_FWD_LOCAL, csrc/rnn_local.h) and the K-split BPTT (SSASR_BPTT_LOCAL;
+ * `beside` GEMMs then keep to the other XCDs).  Both measured no faster than the spread placement
+ * inside a train step and are off by default.  That rests on an observed property
+ * of the dispatcher -- in a 1-D launch blocks b and b + 8 share an XCD, the classes b & 7 sit on
+ * eight different XCDs -- which this call verifies on the current device, once (synchronous; the one
+ * place where the library allocates: 8 KB of scratch, freed before it returns).  1 = holds, 0 = does
+ * not (spread placement everywhere), negative = HIP error.  Until it has been called the spread
+ * placement is used. */
 int ssasr_probe_placement(void* stream);
 
 /* C[b] = act(alpha * op(A[b]) . op(B[b]) + bias) + beta * C[b]; fp32 operands, fp32 accumulation on
@@ -92,9 +95,11 @@ int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
  * y element (s, n, d * H + u) at y[s * ys_s + n * ys_n + d * H + u].
  * Saved for backward: gates [2][S*N][4H], cs [2][S*N][H], hs [2][S*N][H].
  * Optional workspaces that enable the single-launch persistent recurrence
- * (taken when H % 64 == 0 and N <= 128): hx [2][S][H/4][roundup(N,8)][4] floats
- * and sync_ws int32[8], ZERO ON ENTRY (sync_ws[4] != 0 afterwards reports an exchange
- * timeout); pass NULL for one launch per step.
+ * (taken when H % 64 == 0 and N <= 128): hx, ssasr_bilstm_fwd_hx_floats(S, N, H) floats of
+ * exchange image (layout internal: [2][S][H/4][roundup(N,8)][4] floats for the form whose exchange
+ * groups spread over all XCDs, three bf16 planes for the XCD-local form of H = 256, N <= 32,
+ * which ssasr_probe_placement enables), and sync_ws int32[8], ZERO ON ENTRY (sync_ws[4] != 0
+ * afterwards reports an exchange timeout); pass NULL for one launch per step.
  * armed != 0: hx already holds the fill pattern 0x7FC0DEAD in every word, written on the same
  * stream (a caller that arms the exchange workspaces of a whole pass with ONE fill: a dependent
  * launch costs ~6 us however small); 0: the call fills it itself.
@@ -105,6 +110,7 @@ int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
  * cs is not touched and may be NULL.  The same pointer must be passed to the backward call.
  * Replaces: pBLSTM.forward / nn.LSTM, src/asr.py:406-427, :262. */
 int64_t ssasr_bilstm_tsave_floats(int64_t S, int64_t N, int64_t H);
+int64_t ssasr_bilstm_fwd_hx_floats(int64_t S, int64_t N, int64_t H);      /* 0: no persistent form for the shape */
 int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
                      int64_t H, const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
                      const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,

@@ -55,6 +55,7 @@ SIGNATURES = {
     'ssasr_bilstm_fwd': (I32, [P, I64, I64, I64, I64, I64, I64, P] + [P] * 8 +
                          [P, I64, I64, P, P, P, P, P, I32, P, P]),
     'ssasr_bilstm_tsave_floats': (I64, [I64, I64, I64]),
+    'ssasr_bilstm_fwd_hx_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_bwd': (I32, [P, I64, I64, P, I64, I64, I64, I64, I64, I64, P] + [P] * 4 +
                          [P, P, P, P, I64, I64] + [P] * 6 + [P, P, P, P, I32, P, P]),
     'ssasr_bilstm_wgrad': (I32, [P, P, I64, I64, P, I64, I64, I64, I64] + [P] * 8 + [I32, I32, P]),

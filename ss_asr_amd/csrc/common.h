@@ -188,6 +188,7 @@ struct SsasrOptions {
   int attn_rph;                   // SSASR_ATTN_RPH: 0 model, 2 | 3 | 4 | 6 rows per half-wave of the split-T attention kernel
   int no_tsave;                   // SSASR_NO_TSAVE: saved gates / cell states row-major (in place) instead of tile-major
   int bptt_local;                 // SSASR_BPTT_LOCAL (0): XCD-local placement of the K-split BPTT when the probe allows it
+  int fwd_local;                  // SSASR_FWD_LOCAL (0): XCD-local forward recurrence (rnn_local.h) when the probe allows it
   int xcd_round_robin;            // verdict of ssasr_probe_placement(): -1 not probed, 0 no, 1 yes (not an environment switch)
 };
 // true when persistent recurrences may be placed XCD-locally (option on and the probe said yes)

@@ -39,6 +39,7 @@ void init_options() {
   if (g_opt.attn_rph != 2 && g_opt.attn_rph != 3 && g_opt.attn_rph != 4 && g_opt.attn_rph != 6) g_opt.attn_rph = 0;
   g_opt.no_tsave = env_flag("SSASR_NO_TSAVE");
   g_opt.bptt_local = env_int("SSASR_BPTT_LOCAL", 0);     // measured slower inside the train step: rnn.hip
+  g_opt.fwd_local = env_int("SSASR_FWD_LOCAL", 0);      // measured equal to the spread form: off
   g_opt.xcd_round_robin = -1;
 }
 
@@ -62,6 +63,7 @@ const Named kNames[] = {
     {"SSASR_ATTN_RPH", &SsasrOptions::attn_rph},
     {"SSASR_NO_TSAVE", &SsasrOptions::no_tsave},
     {"SSASR_BPTT_LOCAL", &SsasrOptions::bptt_local},
+    {"SSASR_FWD_LOCAL", &SsasrOptions::fwd_local},
     {"SSASR_XCD_ROUND_ROBIN", &SsasrOptions::xcd_round_robin},
 };
 

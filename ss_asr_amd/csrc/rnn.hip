@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "../../include/ssasr.h"
 #include "rnn_kernels.h"
+#include "rnn_local.h"
 
 constexpr int SSASR_MAX_SEGMENTS = 8;
 
@@ -42,6 +43,20 @@ static bool grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t w
   if (ssasr_options().no_residency_check) return true;
   const int64_t cap = ssasr_resident_capacity(kernel, threads, dyn_lds);
   return cap <= 0 || workgroups <= cap;
+}
+
+// The XCD-local forward recurrence (rnn_local.h) is taken for its shape when the option is on, the
+// sentinel exchange is selected and the placement probe has confirmed the dispatcher property.
+static bool ssasr_fwd_local_ok(int64_t S, int64_t N, int64_t H) {
+  const SsasrOptions& o = ssasr_options();
+  return o.fwd_local != 0 && o.xcd_round_robin == 1 && !o.no_persistent && !o.persistent_counter && fl_shape_ok(S, N, H);
+}
+
+extern "C" int64_t ssasr_bilstm_fwd_hx_floats(int64_t S, int64_t N, int64_t H) {
+  if (S <= 0 || N <= 0 || H <= 0 || N > 128 || H % 64 != 0) return 0;
+  const int64_t Np = (N + 7) & ~(int64_t)7;
+  const int64_t spread = 2 * S * (H / 4) * Np * 4;
+  return fl_shape_ok(S, N, H) && fl_hx_floats(S, N) > spread ? fl_hx_floats(S, N) : spread;
 }
 
 // ---------------------------------------------------------------------------
@@ -93,6 +108,37 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   // (2) the recurrence, one launch per step, both directions per launch
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31) || rows * 4 * H >= (1ll << 40)) return SSASR_EARG;
   if (!aligned16(w_hh_f) || !aligned16(w_hh_r) || !aligned16(hs)) return SSASR_EARG;   // 16-byte loads
+  // XCD-local form (rnn_local.h): one exchange group per XCD, one workgroup per CU, h exchanged as
+  // bf16 planes through that XCD's L2 -- when the placement probe has said yes (ssasr_probe_placement)
+  if (ssasr_fwd_local_ok(S, N, H) && hx && sync_ws && aligned16(hx) && aligned16(gates) && (tsave || aligned16(cs)) &&
+      aligned16(y) && ys_s % 4 == 0 && ys_n % 4 == 0) {
+    const bool fuse_in = I == 80 && bih[0] && bhh[0] && bih[1] && bhh[1] && aligned16(x) && aligned16(w_ih_f) &&
+                         aligned16(w_ih_r) && xs_s % 4 == 0 && xs_n % 4 == 0 && !opt.no_fused_input;
+    const void* kfn = fuse_in ? reinterpret_cast<const void*>(lstm_enc_fwd_local_kernel<5>)
+                              : reinterpret_cast<const void*>(lstm_enc_fwd_local_kernel<0>);
+    if (grid_fits(kfn, FWD_THREADS, 0, 8 * FL_TILES)) {
+      if (!fuse_in) {
+        const int rc = input_projection();
+        if (rc) return rc;
+      }
+      EncPersist p{};
+      p.tsave = tsave;
+      p.drop_tile = opt.test_drop_tile;
+      p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
+      p.x = x; p.xs_s = xs_s; p.xs_n = xs_n;
+      for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }
+      p.gates = gates; p.cs = cs; p.hs = hs; p.hx = hx; p.y = y; p.lens = lens;
+      p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
+      p.delay = persist_delay(opt.delay_fwd, 8);
+      p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
+      p.local = 2; p.nchunk = (int)((N + FL_COLS - 1) / FL_COLS);
+      if (!armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)fl_hx_floats(S, N), st));
+      if (fuse_in) hipLaunchKernelGGL(lstm_enc_fwd_local_kernel<5>, dim3(8 * FL_TILES), dim3(FWD_THREADS), 0, st, p);
+      else hipLaunchKernelGGL(lstm_enc_fwd_local_kernel<0>, dim3(8 * FL_TILES), dim3(FWD_THREADS), 0, st, p);
+      SSASR_LAUNCH_CHECK();
+      return SSASR_OK;
+    }
+  }
   // One persistent launch when the whole grid is certain to be resident
   // (rnn_kernels.h, "persistent forward recurrence"); else one launch per step.
   {

@@ -147,6 +147,22 @@ def probe_placement():
     return _probed
 
 
+def placement_probed():
+    """Runs the placement probe on first use when a form that needs it is switched on
+    (SSASR_FWD_LOCAL / SSASR_BPTT_LOCAL, both off by default)."""
+    if _probed is None:
+        lib = _lib.load()
+        for name in (b'SSASR_FWD_LOCAL', b'SSASR_BPTT_LOCAL'):
+            v = C.c_int(0)
+            lib.ssasr_get_option(name, C.byref(v))
+            if v.value:
+                probe_placement()
+                break
+        else:
+            return False
+    return bool(_probed)
+
+
 def side_stream():
     global _side
     if _side is None:
@@ -200,8 +216,7 @@ def bilstm_exchange_floats(S, N, H):
     """(forward image floats, BPTT ring floats) of a BiLSTM layer; 0 where the layer has no
     persistent form that an ExchangeArena can serve."""
     lib = _lib.load()
-    hx = 2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4 if N <= 128 and H % 64 == 0 else 0
-    return hx, int(lib.ssasr_bilstm_bwd_ring_floats(S, N, H, 2))
+    return int(lib.ssasr_bilstm_fwd_hx_floats(S, N, H)), int(lib.ssasr_bilstm_bwd_ring_floats(S, N, H, 2))
 
 
 def upload_i32(device, *seqs):
@@ -329,7 +344,8 @@ class _BiLSTM(torch.autograd.Function):
         tsave = torch.empty(ts_floats, device=x.device, dtype=torch.float32) if ts_floats else None
         cs = None if ts_floats else torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         # workspaces of the persistent recurrence (exchange image + counters)
-        hx_floats = 2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4 if N <= 128 and H % 64 == 0 else 0
+        placement_probed()
+        hx_floats = int(lib.ssasr_bilstm_fwd_hx_floats(S, N, H))
         armed = 0
         if slots is not None and slots[1] is not None and hx_floats:
             hx = slots[0].take(slots[1])              # armed with the arena's one fill

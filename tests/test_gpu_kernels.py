@@ -122,6 +122,12 @@ def lstm_weights(I, H, seed):
     # what timed out under an exchange ring: DESIGN.md 4.2); the BPTT runs 3 / 4 chunks without halves
     (48, 40, 64, 256, [40] * 10 + [33] * 20 + [9] * 18),
     (64, 24, 64, 256, [24] * 30 + [11] * 34),
+    # H = 256, N <= 32: the XCD-local forward recurrence (csrc/rnn_local.h: 8-column exchange groups, h
+    # exchanged as bf16 planes) -- four full groups per direction with ragged lengths; a last group of
+    # 5 live columns; the fused 80-bin input projection (I = 80) with 13 columns
+    (32, 37, 64, 256, [37 - k for k in range(32)]),
+    (29, 21, 48, 256, [21] * 9 + [14] * 12 + [2] * 8),
+    (13, 26, 80, 256, [26, 26, 25, 20, 19, 19, 12, 9, 9, 5, 3, 2, 1]),
 ])
 def test_bilstm_packed_forward_backward(N, T, I, H, lens):
     from ss_asr_amd import ops
@@ -146,6 +152,43 @@ def test_bilstm_packed_forward_backward(N, T, I, H, lens):
     close(xd.grad, xr.grad, 5e-5, 'dx')
     for name, a, b in zip(['w_ih', 'w_hh', 'b_ih', 'b_hh'] * 2, wd, wr):
         close(a.grad, b.grad, 2e-4, 'd' + name)
+
+
+@pytest.mark.parametrize('I', [80, 1024])
+def test_xcd_local_forward_recurrence_equals_the_spread_form(I):
+    """The same layer through both placements of the persistent forward recurrence (SSASR_FWD_LOCAL
+    1 / 0) at a bench-like shape, 32 ragged columns x 300 steps: the XCD-local form (exchange through
+    one XCD's L2, product on the bf16 pipeline in the exact three-way split) and the spread form
+    (fabric hand-off, fp32 MFMA instruction) agree to fp32 rounding on y and on what the BPTT reads
+    back -- checked through the gradients of a backward pass -- and the local form is the one that
+    ran when the placement probe allows it."""
+    from ss_asr_amd import _lib, ops
+    N, S, H = 32, 300, 256
+    lens = [300 - 7 * k for k in range(N)]
+    x = rnd(N, S, I, seed=91, scale=0.5).float()
+    for i, l in enumerate(lens):
+        x[i, l:] = 0
+    w = [t.float().to(dev()) for t in lstm_weights(I, H, 92)]
+    ld = torch.tensor(lens, dtype=torch.int32, device=dev())
+    gy = rnd(N, S, 2 * H, seed=93).float().to(dev())
+    probed = ops.probe_placement()
+    outs = []
+    for local in (1, 0):
+        old = _lib.set_option('SSASR_FWD_LOCAL', local)
+        try:
+            xd = x.to(dev()).requires_grad_(True)
+            wd = [t.clone().requires_grad_(True) for t in w]
+            y = ops.bilstm(xd, ld, S, True, wd)
+            (y * gy).sum().backward()
+            torch.cuda.synchronize()
+            ops.check_persistent_status()
+            outs.append((y.detach(), xd.grad, wd[1].grad, wd[5].grad))
+        finally:
+            _lib.set_option('SSASR_FWD_LOCAL', old)
+    if not probed:
+        pytest.skip('placement probe says no: both runs took the spread form')
+    for a, b, tol, what in zip(outs[0], outs[1], (2e-6, 2e-5, 2e-4, 2e-4), ('y', 'dx', 'dw_hh', 'dw_hh_r')):
+        close(a, b, tol, what)
 
 
 @pytest.mark.parametrize('N,S,I,H,segments', [(20, 150, 24, 64, 4), (9, 130, 16, 128, 3), (20, 150, 24, 64, 1)])

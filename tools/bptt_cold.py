@@ -18,7 +18,7 @@ y = torch.empty(S, N, 2 * H, device=dev)
 dy = (torch.randn(S, N, 2 * H, generator=g) / 8).to(dev)
 gates = torch.empty(2, S * N, 4 * H, device=dev)
 hs = torch.empty(2, S * N, H, device=dev)
-hx = torch.empty(2 * S * (H // 4) * ((N + 7) // 8 * 8) * 4, device=dev)
+hx = torch.empty(int(lib.ssasr_bilstm_fwd_hx_floats(S, N, H)), device=dev)
 gx = torch.empty(int(lib.ssasr_bilstm_bwd_gx_floats(S, N, H)), device=dev)
 ws_t = torch.empty(2, H, 4 * H, device=dev); ws_dc = torch.empty(2, 2, N, H, device=dev)
 tsave = torch.empty(int(lib.ssasr_bilstm_tsave_floats(S, N, H)), device=dev)

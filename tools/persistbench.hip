@@ -25,6 +25,7 @@ __device__ unsigned g_retry[TR_WG * 4 * 4];   // per (workgroup, wave): steps ne
   unsigned long long t_; asm volatile(SSASR_CLK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
   g_trace[((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * TR_N + ((step) - TR_LO)) * TR_SLOTS + (slot)] = t_; } } while (0)
 #include "rnn_kernels.h"
+#include "rnn_local.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at %s:%d\n", e_, __FILE__, __LINE__); return 1; } } while (0)
 
@@ -135,6 +136,22 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
     printf("fwd persistent: %.3f us / step (status %d)\n", ms * 1e3 / S, status);
+  }
+  if (getenv("LOCALF")) {        // the XCD-local forward recurrence (rnn_local.h), phases per workgroup
+    float* hxl; CK(hipMalloc(&hxl, sizeof(float) * fl_hx_floats(S, N)));
+    pf.hx = hxl; pf.local = 2; pf.nchunk = (int)((N + FL_COLS - 1) / FL_COLS);
+    pf.delay = getenv("DELAY_F") ? atoi(getenv("DELAY_F")) : 8;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemsetAsync(sync, 0, 32, st));
+      CK(hipMemsetD32Async((hipDeviceptr_t)hxl, (int)PERSIST_SENTINEL, (size_t)fl_hx_floats(S, N), st));
+      CK(hipEventRecord(e0, st));
+      hipLaunchKernelGGL(lstm_enc_fwd_local_kernel<0>, dim3(8 * FL_TILES), dim3(FWD_THREADS), 0, st, pf);
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
+      printf("fwd local: %.3f us / step (status %d)\n", ms * 1e3 / S, status);
+    }
+    return report("fwd local", 8 * FL_TILES, 0.01, 8 * FL_TILES);
   }
   // tick calibration: stamps span of the traced window vs the event-timed period is
   // not exact, so calibrate s_memtime against the wall clock with a sleep kernel instead
