@@ -198,6 +198,12 @@ const SsasrOptions& ssasr_options();
 // device: occupancy per CU x CU count, cached per (kernel, LDS).  A persistent grid larger than this
 // could spin on a workgroup that is not resident; the launchers fall back to one launch per step.
 int64_t ssasr_resident_capacity(const void* kernel, int threads, size_t dyn_lds);
+// The least LDS a GEMM workgroup of this library occupies (64 x 64 tiles of the selected kernel): what the
+// BPTT's LDS reservation must leave NO room for on its CU (rnn.hip, "Placement")
+size_t ssasr_gemm_min_lds_bytes();
+// Dynamic LDS that a persistent workgroup of `kernel` must reserve so that no GEMM workgroup fits beside it
+// on a 160 KB CU; 0 when the kernel's own static LDS already excludes one (or on error)
+size_t ssasr_lds_reservation_against_gemm(const void* kernel);
 // true when the shape takes the K-split persistent form (which supports iteration ranges)
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs);
 extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);

@@ -52,7 +52,7 @@ inline bool pl_shape_ok(int64_t B, int64_t T) {
 inline int64_t pl_part_floats(int64_t B, int64_t T) { return (int64_t)PL_RING * B * pl_ns(T) * PL_PART; }
 inline size_t decoder_long_lds() {
   const size_t att = 256 + 2048 + 64 + 64 + 16 + 16 + 4 + 12;
-  const size_t cmp = 2 * (size_t)PD_GROUP_LDS_FLOATS;
+  const size_t cmp = 2 * (size_t)PD_GROUP_LDS_FLOATS + PD_WCT_FLOATS;
   return sizeof(float) * (att > cmp ? att : cmp);
 }
 
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(512) void decoder_fwd_long_kernel(DecLong pp) {
   const int natt = NS * B;
   if ((int)blockIdx.x >= natt) {
     const int cw = (int)blockIdx.x - natt, grp = tid >> 8;
-    pd_compute_role<true>(p, 2 * cw + grp, tid & 255, smem + grp * PD_GROUP_LDS_FLOATS, 2 * cw < B);
+    pd_compute_role<true>(p, 2 * cw + grp, tid & 255, smem + grp * PD_GROUP_LDS_FLOATS, 2 * cw < B,
+                          smem + 2 * PD_GROUP_LDS_FLOATS, grp == 0);
     return;
   }
 

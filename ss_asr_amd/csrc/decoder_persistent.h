@@ -144,10 +144,28 @@ __device__ __forceinline__ void pd_mma(f32x4& acc, f32x4& acc2, const float4 (&w
 // may hold several groups (decoder_long.h: two), which all run the same barrier sequence:
 // `any_chr` says whether ANY group of the workgroup has the character role (barriers are uniform).
 constexpr int PD_GROUP_LDS_FLOATS = 4 * 64 * 4 + 256 + 64 + 64;
+// char_trans' weight and bias in LDS for the workgroups that draw characters: [64 rows][PD_WCT_LD] + [64]
+// (rows padded by a float4 so that the 16 rows a wave reads at one k fall on different banks).  A
+// sampled / greedy step has the whole loop waiting on h2 -> logits -> character -> embedding, so
+// that chain reads nothing but LDS and the one embedding row.
+constexpr int PD_WCT_LD = PD_D + 4;
+constexpr int PD_WCT_FLOATS = 64 * PD_WCT_LD + 64;
+// `swct`: the table above (one per workgroup, shared by its groups) or unused when !any_chr;
+// `stage`: this group fills it (exactly one group of a workgroup with any_chr does).
 template <bool SEN>
 __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c, const int tid, float* smem,
-                                                const bool any_chr) {
+                                                const bool any_chr, float* swct, const bool stage) {
   const int wave = tid >> 6, lane = tid & 63;
+  if (any_chr) {
+    if (stage) {
+      for (int i = tid; i < p.V * (PD_D / 4); i += 256) {
+        const int row = i / (PD_D / 4), c4 = i - row * (PD_D / 4);
+        *reinterpret_cast<float4*>(swct + row * PD_WCT_LD + 4 * c4) = aload4(p.w_ct + (int64_t)row * PD_D + 4 * c4);
+      }
+      if (tid < 64) swct[64 * PD_WCT_LD + tid] = tid < p.V ? p.b_ct[tid] : 0.f;
+    }
+    __syncthreads();
+  }
   const int B = p.B, U = p.U;
   PdWaiter wt{false, p.status};
   const unsigned n_att = (unsigned)(B * PD_NATT);     // ctx publishers per step (counter form only)
@@ -275,34 +293,45 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
             *reinterpret_cast<float4*>(sV + 4 * tid) = hv[0];
           }
           __syncthreads();
-          for (int v = wave; is_chr && v < p.V; v += 4) {
-            const float* wr = p.w_ct + (int64_t)v * D;
+          if (is_chr) {
+            // logits = W_ct h2 + b_ct out of LDS: thread (row = tid >> 2, quarter of k = tid & 3), 64 FMAs, a
+            // quad sum on the DPP network
+            const int row = tid >> 2, part = tid & 3;
+            const float* wr = swct + row * PD_WCT_LD + 64 * part;
+            const float* hv = sV + 64 * part;
             float a = 0.f;
-            for (int k = lane; k < D; k += 64) a = fmaf(wr[k], sV[k], a);
-            a = wave_sum(a);
-            if (lane == 0) sL[v] = a + p.b_ct[v];
+            if (row < p.V) {
+#pragma unroll
+              for (int j = 0; j < 16; ++j) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wr + 4 * j);
+                const float4 h4 = *reinterpret_cast<const float4*>(hv + 4 * j);
+                a = fmaf(w4.x, h4.x, fmaf(w4.y, h4.y, fmaf(w4.z, h4.z, fmaf(w4.w, h4.w, a))));
+              }
+            }
+            a += dpp_move<0xB1>(a);       // quad_perm [1,0,3,2]
+            a += dpp_move<0x4E>(a);       // quad_perm [2,3,0,1]
+            if (part == 0 && row < p.V) sL[row] = a + swct[64 * PD_WCT_LD + row];
           }
           __syncthreads();
           if (is_chr && wave == 0) {
-            int best = 0;
-            if (lane == 0) {
-              float mx = sL[0];
-              for (int v = 1; v < p.V; ++v)
-                if (sL[v] > mx) { mx = sL[v]; best = v; }
-              if (mode == 1) {
-                float tot = 0.f;
-                for (int v = 0; v < p.V; ++v) tot += expf(sL[v] - mx);
-                const float target = p.uniforms[(int64_t)s * B + b] * tot;
-                float run = 0.f;
-                best = p.V - 1;
-                for (int v = 0; v < p.V; ++v) {
-                  run += expf(sL[v] - mx);
-                  if (run > target) { best = v; break; }
-                }
+            // one lane per class: first maximum (argmax), or the inverse-CDF draw from a parallel prefix sum
+            // (same law as the sequential sums of char_select_kernel; the running sums differ in rounding only)
+            const float l = lane < p.V ? sL[lane] : -INFINITY;
+            const float mx = wave_max(l);
+            int best = __builtin_ctzll(__ballot(l == mx));
+            if (mode == 1) {
+              float run = lane < p.V ? expf(l - mx) : 0.f;
+#pragma unroll
+              for (int off = 1; off < 64; off <<= 1) {
+                const float up = __shfl_up(run, off, 64);
+                if (lane >= off) run += up;
               }
-              p.chars[(int64_t)(s + 1) * B + b] = best;
+              const float tot = __shfl(run, 63, 64);
+              const float target = p.uniforms[(int64_t)s * B + b] * tot;
+              const unsigned long long over = __ballot(lane < p.V && run > target);
+              best = over ? __builtin_ctzll(over) : p.V - 1;
             }
-            best = __shfl(best, 0, 64);
+            if (lane == 0) p.chars[(int64_t)(s + 1) * B + b] = best;
             pd_st_sc1(re, (unsigned)((((int64_t)(s + 1) * B + b) * D + 4 * lane) * 4),
                       aload4(p.embed + (int64_t)best * D + 4 * lane));
             if (!SEN) {
@@ -543,9 +572,12 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
 
   // -------------------------------- compute role --------------------------------
   const int c = blockIdx.x - PD_NATTWG;
-  pd_compute_role<SEN>(p, c, tid, smem, c < B);
+  pd_compute_role<SEN>(p, c, tid, smem, c < B, smem + PD_GROUP_LDS_FLOATS, true);
 }
 
-inline size_t decoder_persistent_lds(int T) { return sizeof(float) * ((size_t)T * 256 + 2176 + 256); }
+inline size_t decoder_persistent_lds(int T) {
+  const size_t att = (size_t)T * 256 + 2176 + 256, cmp = (size_t)PD_GROUP_LDS_FLOATS + PD_WCT_FLOATS;
+  return sizeof(float) * (att > cmp ? att : cmp);
+}
 
 }  // namespace

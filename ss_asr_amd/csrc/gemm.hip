@@ -675,6 +675,12 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
 
 }  // namespace
 
+size_t ssasr_gemm_min_lds_bytes() {
+  // 64 x 64 tiles: the split-bf16 kernel's dynamic image of both operands, or the fp32 kernel's two static stages
+  if (ssasr_options().gemm_x6) return XGeom<64>::BYTES + XGeom<64>::BYTES;
+  return sizeof(float) * 2 * (TileGeom<64, false>::FLOATS + TileGeom<64, false>::FLOATS);
+}
+
 int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   GemmDesc g = gin;
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return SSASR_OK;

@@ -141,6 +141,16 @@ extern "C" int ssasr_probe_placement(void* stream) {
   return g_opt.xcd_round_robin;
 }
 
+size_t ssasr_lds_reservation_against_gemm(const void* kernel) {
+  constexpr size_t CU_LDS = 160 * 1024;
+  hipFuncAttributes fa{};
+  if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) return 0;
+  const size_t own = fa.sharedSizeBytes, gemm = ssasr_gemm_min_lds_bytes();
+  if (own + gemm > CU_LDS) return 0;
+  // own + reserve + gemm must exceed the CU's LDS; LDS is granted in 1 KB steps on this part: one step of margin
+  return CU_LDS - own - gemm + 1024;
+}
+
 int64_t ssasr_resident_capacity(const void* kernel, int threads, size_t dyn_lds) {
   static std::mutex mu;
   static std::map<std::tuple<const void*, int, size_t, int>, int64_t> cache;

@@ -337,7 +337,15 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
     const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
     p.delay = persist_delay(opt.delay_bwd_ksplit, 40);
-    const int reserve = opt.bptt_reserve_kb * 1024;
+    // LDS reservation that keeps side-stream GEMM workgroups off this kernel's CUs (see "Placement" below).
+    // The option gives its size (SSASR_BPTT_RESERVE_KB, 0 = off); it is RAISED to what the invariant needs
+    // -- own static LDS + reservation + the smallest GEMM workgroup's LDS > 160 KB -- so that a change of
+    // the GEMM's tile or of this kernel's LDS cannot silently break the separation.
+    int reserve = opt.bptt_reserve_kb * 1024;
+    if (reserve) {
+      const size_t need = ssasr_lds_reservation_against_gemm(bptt_rs_fn(kpw, kpw >= 8, 4));
+      if ((size_t)reserve < need) reserve = (int)need;
+    }
     // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
     // (not for launches of fewer than three steps: see the note on in-place rows in rnn_kernels.h)
     // (Eight recurrence waves per workgroup -- two partial tiles loaded and one unit tile multiplied per

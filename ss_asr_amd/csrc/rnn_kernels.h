@@ -636,8 +636,11 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
         }
       }
     };
-    fetch(0); publish(0);
-    if (S > 1) fetch(1);
+    // KI > 0: the recurrence waves form the input projection themselves (below): nothing to stream here
+    if (KI == 0) {
+      fetch(0); publish(0);
+      if (S > 1) fetch(1);
+    }
     for (int i = 0; i < S; ++i) {
       if (i > 0) {
         SSASR_PTRACE_H(i, 8);
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
         __syncthreads();                              // operand loads released
       }
       // addbuf[(i + 1) & 1] was last read in step i - 1
-      if (i + 1 < S) { publish(i + 1); if (i + 2 < S) fetch(i + 2); }
+      if (KI == 0 && i + 1 < S) { publish(i + 1); if (i + 2 < S) fetch(i + 2); }
       if (i > 0) flush(i - 1);                        // stage is rewritten after the next barrier
       __syncthreads();                                // product done
       if (SENTINEL && i > 0) { pacer.update(missed != 0); missed = 0; }
@@ -679,6 +682,36 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
   const int n = n0 + 16 * bt + r;
   const bool epi = bt < NB && n < N;
   float cstate = 0.f;
+  // KI > 0 (narrow input, the 80 mel bins of the first layer): W_ih x_s is part of the SAME K-split
+  // product.  Wave w multiplies the features 16 j + 4 q + w (one MFMA per j) into its accumulators
+  // while its exchange loads are in flight -- the matrix pipe is idle then -- so the pre-activations
+  // never pass through LDS and the helper wave's 4 KI MFMAs per step (which shared a SIMD with wave 1)
+  // are gone.  x is fetched two steps ahead (first touch comes from HBM); the biases join in the epilogue.
+  constexpr int KIN = KI > 0 ? KI : 1;
+  float wiq[KIN], xcur[NB][KIN], xnxt[NB][KIN], xnn[NB][KIN], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load_x = [&](int i, float (&dst)[NB][KIN]) {
+    const int s = d ? S - 1 - i : i;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int nn = n0 + 16 * t + r;
+      const float* xp = e.x + (int64_t)s * e.xs_s + (int64_t)(nn < N ? nn : N - 1) * e.xs_n + 4 * q + wave;
+#pragma unroll
+      for (int j = 0; j < KIN; ++j) dst[t][j] = xp[16 * j];
+    }
+  };
+  if (KI > 0) {
+    const int rowA = (r & 3) * H + 4 * tile + (r >> 2);       // A row r = 4 * unit + gate
+    const float* wp = e.wih[d] + (int64_t)rowA * (16 * KI) + 4 * q + wave;
+#pragma unroll
+    for (int j = 0; j < KIN; ++j) wiq[j] = wp[16 * j];
+    if (epi) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bsum[g] = e.bih[d][g * H + u] + e.bhh[d][g * H + u];
+    }
+    load_x(0, xcur);
+    load_x(S > 1 ? 1 : 0, xnxt);
+    load_x(S > 2 ? 2 : 0, xnn);
+  }
   const int len = (epi && e.lens) ? e.lens[n] : 0x7fffffff;
   // lane part of the h_{s-1} operand address.  Columns past N read this chunk's OWN first column
   // (their products are never stored).  They used to read column 0, which belongs to chunk 0: a
@@ -714,6 +747,15 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
         for (int t = 0; t < NB; ++t)
           raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, 16);
       }
+      if (KI > 0) {              // the input projection's share of the product, behind the loads just issued
+#pragma unroll
+        for (int j = 0; j < KIN; ++j)
+#pragma unroll
+          for (int t = 0; t < NB; ++t) {
+            if (j & 1) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wiq[j], xcur[t][j], acc2[t], 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wiq[j], xcur[t][j], acc[t], 0, 0, 0);
+          }
+      }
       if (SENTINEL) {
         // re-fetch any piece that still holds the fill pattern
         for (unsigned tries = 0;; ++tries) {
@@ -748,6 +790,18 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
         }
       }
       seg_group_mma<NB, KPW>(acc, acc2, wreg, b, KPW);
+    } else if (KI > 0) {         // step 0: h = 0, the input projection alone
+#pragma unroll
+      for (int j = 0; j < KIN; ++j)
+#pragma unroll
+        for (int t = 0; t < NB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wiq[j], xcur[t][j], acc[t], 0, 0, 0);
+    }
+    if (KI > 0) {                // rotate the sets that have arrived (x of steps i + 1, i + 2), then x of step i + 3 on its way
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int j = 0; j < KIN; ++j) { xcur[t][j] = xnxt[t][j]; xnxt[t][j] = xnn[t][j]; }
+      if (i + 3 < S) load_x(i + 3, xnn);
     }
 #pragma unroll
     for (int t = 0; t < NB; ++t) red[(wave * NB + t) * 64 + lane] = acc[t] + acc2[t];
@@ -756,9 +810,17 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
     SSASR_PTRACE(i, 5);
     if (epi) {
       const f32x4 p = red_sum<NB>(red, bt, lane);
-      const float* ab = &addbuf[i & 1][bt][0][lane];
-      float gi = fast_sigmoid(p[0] + ab[0]), gf = fast_sigmoid(p[1] + ab[64]);
-      float gg = fast_tanh(p[2] + ab[128]), go = fast_sigmoid(p[3] + ab[192]);
+      float add[4];
+      if (KI > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) add[g] = bsum[g];
+      } else {
+        const float* ab = &addbuf[i & 1][bt][0][lane];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) add[g] = ab[64 * g];
+      }
+      float gi = fast_sigmoid(p[0] + add[0]), gf = fast_sigmoid(p[1] + add[1]);
+      float gg = fast_tanh(p[2] + add[2]), go = fast_sigmoid(p[3] + add[3]);
       float c = gf * cstate + gi * gg;
       float h = go * fast_tanh(c);
       if (s >= len) { gi = gf = gg = go = 0.f; c = 0.f; h = 0.f; }
