@@ -537,7 +537,9 @@ def main():
         note('input-projection GEMM: %s' % gemm_rl)
         note('BPTT recurrence: %s' % bptt)
         note('forward recurrence: %s' % fwd_rec)
-        traffic = os.path.join(ROOT, 'profiles', 'r02_traffic.json')    # rocprofv3 --pmc passes, see profiles/README.md
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))   # rocprofv3 --pmc passes, see profiles/README.md
+        traffic = found[-1] if found else ''
         if os.path.exists(traffic):
             with open(traffic) as f:
                 t = json.load(f)

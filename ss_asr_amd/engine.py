@@ -40,6 +40,9 @@ class ASRTrainStep:
         persistent launches timed out) is picked up here when its words have reached the host
         -- no synchronisation; a timeout raises."""
         self._note(self.optim.poll())
+        # the weight-gradient listener is process-wide: claim it for THIS step object (several step
+        # objects may alternate in one process -- the ASR and joint steps, the trainers of the Seed loop)
+        ops.set_wgrad_listener(self.reducer.wgrad_enqueued)
         if not self._grads_clean:
             self.optim.zero_grad()
         self._grads_clean = False

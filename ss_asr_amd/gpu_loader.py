@@ -68,6 +68,30 @@ class GpuResidentLoader:
                     batch_size, device, rank, world, time_multiple, pad)
         return self
 
+    @classmethod
+    def from_waveforms(cls, waves, sample_rate, texts, batch_size, device, n_mels=None, chars=TOKENS + ALL_CHARS,
+                       rank=0, world=1, time_multiple=8):
+        """The corpus built from WAVEFORMS on the GPU: every utterance goes through the log-mel frontend
+        (frontend.log_fbank -> ssasr_logmel; src/preprocess.py:187-208 is what it replaces) and its frames
+        stay on the device -- no .npy round trip, no host copy of the features.  `waves`: 1-D float arrays
+        (or tensors) at `sample_rate`; `texts`: the normalised transcripts WITHOUT the '<' '>' tokens.
+        Utterances are ordered by decreasing frame count first (the order the reference's index must
+        have inside a batch, conf/README.md:16), then cut into whole batches as everywhere else.
+        (The frontend's parity with librosa 0.6.3 is unpinned: DESIGN.md 4.6.)"""
+        from .frontend import log_fbank
+        from .preprocess import EOS_TKN, N_DIMS
+        n_mels = n_mels or N_DIMS
+        char2idx = {c: i for i, c in enumerate(chars)}
+        feats = [log_fbank(w, sample_rate, n_mels) for w in waves]
+        order = sorted(range(len(feats)), key=lambda i: -feats[i].shape[0])
+        n = len(plan_batches(len(order), batch_size)) * batch_size
+        order = order[:n]
+        self = cls.__new__(cls)
+        self.rows = None
+        labels = [[char2idx[SOS_TKN]] + [char2idx[c] for c in texts[i]] + [char2idx[EOS_TKN]] for i in order]
+        self._setup([feats[i] for i in order], labels, batch_size, device, rank, world, time_multiple, char2idx[SOS_TKN])
+        return self
+
     def _setup(self, kept, labels, batch_size, device, rank, world, time_multiple, pad):
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -82,7 +106,10 @@ class GpuResidentLoader:
         offs = np.zeros(len(lens) + 1, dtype=np.int64)
         np.cumsum(lens, out=offs[1:])
         # one upload each; batches are views of these
-        self.frames = torch.from_numpy(np.concatenate(kept, axis=0)).to(self.device) if kept else None
+        if kept and torch.is_tensor(kept[0]):       # features that were computed on the device stay there
+            self.frames = torch.cat([a.to(self.device, torch.float32) for a in kept], dim=0)
+        else:
+            self.frames = torch.from_numpy(np.concatenate(kept, axis=0)).to(self.device) if kept else None
         self.offsets = torch.from_numpy(offs[:-1].copy()).to(self.device)
         self.lens_dev = torch.tensor(lens, dtype=torch.int32, device=self.device)
         # labels: padded with <sos> like ASRDataset.get_batched_texts

@@ -197,3 +197,38 @@ def test_asr_trainer_with_the_joint_ctc_attention_loss(tmp_path):
     fresh = JointCTCASR(50, 64, 64, 32, 80, 1.0, ctc_weight=0.3)
     fresh.load_state_dict(plain)                     # the reference's key set: head keeps its initialisation
     assert torch.equal(fresh.encoder.blstm_1.layer.weight_ih_l0, saved['encoder.blstm_1.layer.weight_ih_l0'])
+
+
+def test_corpus_built_from_waveforms_by_the_gpu_frontend_trains_a_step():
+    """SURVEY.md 8 f3 wired to the path: GpuResidentLoader.from_waveforms runs every waveform through
+    ssasr_logmel (the replacement of src/preprocess.py:187-208's log_fbank) and keeps the frames on the
+    device; a batch assembled from that corpus holds exactly the frontend's frames and trains one step
+    of engine.ASRTrainStep with a finite loss.  (The frontend's arithmetic is checked against its own
+    oracle in tests/test_frontend.py; its parity with librosa is unpinned.)"""
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.engine import ASRTrainStep
+    from ss_asr_amd.frontend import log_fbank
+    from ss_asr_amd.gpu_loader import GpuResidentLoader
+    from ss_asr_amd.preprocess import ALL_CHARS, TOKENS
+    sr, n_mels = 16000, 80
+    rng = np.random.default_rng(8)
+    secs = [1.9, 0.7, 1.3, 1.6, 0.9, 1.1, 0.5, 1.4, 1.0]
+    waves = [(0.1 * rng.standard_normal(int(s * sr)) + 0.3 * np.sin(2 * np.pi * (200 + 50 * k) * np.arange(int(s * sr)) / sr)
+              ).astype(np.float32) for k, s in enumerate(secs)]
+    texts = [''.join(rng.choice(list(ALL_CHARS), size=3 + k)) for k in range(len(secs))]
+    dev = torch.device('cuda:0')
+    gl = GpuResidentLoader.from_waveforms(waves, sr, texts, 4, dev, n_mels=n_mels)
+    assert len(gl) == 2 and gl.feature_dim == n_mels            # 9 utterances -> two whole batches of 4
+    x, x_lens, y, y_lens = gl.batch(0)
+    assert x_lens == sorted(x_lens, reverse=True) and x_lens[0] == 1 + int(1.9 * sr) // 160
+    longest = log_fbank(waves[0], sr, n_mels)
+    assert torch.equal(x[0, :x_lens[0]], longest) and float(x[0, x_lens[0]:].abs().sum()) == 0.0
+    chars = TOKENS + ALL_CHARS
+    assert ''.join(chars[int(c)] for c in y[0, 1:y_lens[0] - 1]) == texts[0]
+    torch.manual_seed(0)
+    model = ASR(len(chars), 64, 64, 32, n_mels, 1.0).to(dev)
+    step = ASRTrainStep(model)
+    random.seed(0)
+    loss = float(step(x, y, x_lens, max(y_lens) - 1))
+    norm, skipped = step.finish()
+    assert np.isfinite(loss) and np.isfinite(norm) and not skipped and 1.0 < loss < 10.0
