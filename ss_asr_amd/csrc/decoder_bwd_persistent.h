@@ -149,6 +149,30 @@ __device__ __forceinline__ bool cb_fetch(u32x4 (&raw)[NV], F ld, int* status) {
   return missed;
 }
 
+// The waiting half of cb_fetch for loads that are already in flight: re-fetches pieces of raw[] that
+// still hold the fill pattern until none does (bounded).  Returns whether anything had to be re-fetched.
+template <int NV, typename F>
+__device__ __forceinline__ bool cb_verify(u32x4 (&raw)[NV], F ld, int* status) {
+  bool missed = false;
+  for (unsigned tries = 0;; ++tries) {
+    bool anybad = false;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const bool bad = raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
+                       raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
+      if (__any(bad)) {
+        anybad = true;
+        raw[j] = ld(j);
+      }
+    }
+    if (!anybad) break;
+    missed = true;
+    if (persist_give_up(tries, status, persist_code(PK_DEC_CHAIN, 0xfff))) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return missed;
+}
+
 // grid: NSL * B attention workgroups, then 16 tiles x 2 chunks x 2 halves = 64 cell workgroups; 320 threads
 // dynamic LDS: chain_lds_bytes(T)
 template <int NSL>
@@ -392,32 +416,73 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       const float* qq = p.q + ((int64_t)(t + 1) * B + nb) * A + 8 * ablk;
       const float4 vv0 = aload4(vq), vv1 = aload4(vq + 4), qv0 = aload4(qq), qv1 = aload4(qq + 4);
       // results of step t + 1: partial dh1 tiles and the attention's U_h, s_h
-      u32x4 raw[4 + 3 * NSL];
       const unsigned xab = (unsigned)(t + 1) * XA_STEP + (unsigned)chunk * (16 * 16 * TILE_B) +
                            (unsigned)tile * (16 * TILE_B) + (unsigned)lane * 16;
       // slot s of frame slice h for utterance nb: (((nb / 16) * NSL + h) * SLOTS + s) * 16 + nb % 16, in float4 units
       const unsigned xub = (unsigned)((t + 1) * CB_XU_STEP) * 4u + (unsigned)(((nb >> 4) * NSL * CB_XU_SLOTS) * 16 + (nb & 15)) * 16u;
       constexpr unsigned XU_SLOT = 16 * 16, XU_HALF = CB_XU_SLOTS * 16 * 16;      // bytes
-      pacer.sleep();
-      const bool missed = cb_fetch<4 + 3 * NSL>(raw, [=](int j) {
-        // 0..3: partial dh1 tiles; then per frame slice h: its two quads of U_h (4 + 2 h, 5 + 2 h); then s_h
-        return j < 4 ? pd_ld_raw(rxa, xab + (unsigned)(wave + 4 * j) * TILE_B)
-             : j < 4 + 2 * NSL ? pd_ld_raw(rxu, xub + (unsigned)((j - 4) >> 1) * XU_HALF + (unsigned)(2 * ablk + ((j - 4) & 1)) * XU_SLOT)
-             : pd_ld_raw(rxu, xub + (unsigned)(j - 4 - 2 * NSL) * XU_HALF + 32u * XU_SLOT);
-      }, p.status);
-      pacer.update(missed);
+      f32x4 ua2[2];
+      float s;
+      if constexpr (NSL == 2) {
+        // two frame slices (the training shapes): all ten result quads in flight at once
+        u32x4 raw[4 + 3 * NSL];
+        pacer.sleep();
+        const bool missed = cb_fetch<4 + 3 * NSL>(raw, [=](int j) {
+          // 0..3: partial dh1 tiles; then per frame slice h: its two quads of U_h (4 + 2 h, 5 + 2 h); then s_h
+          return j < 4 ? pd_ld_raw(rxa, xab + (unsigned)(wave + 4 * j) * TILE_B)
+               : j < 4 + 2 * NSL ? pd_ld_raw(rxu, xub + (unsigned)((j - 4) >> 1) * XU_HALF + (unsigned)(2 * ablk + ((j - 4) & 1)) * XU_SLOT)
+               : pd_ld_raw(rxu, xub + (unsigned)(j - 4 - 2 * NSL) * XU_HALF + 32u * XU_SLOT);
+        }, p.status);
+        pacer.update(missed);
+        part = (__builtin_bit_cast(f32x4, raw[0]) + __builtin_bit_cast(f32x4, raw[1])) +
+               (__builtin_bit_cast(f32x4, raw[2]) + __builtin_bit_cast(f32x4, raw[3]));
+        s = __builtin_bit_cast(f32x4, raw[4 + 2 * NSL])[0] + __builtin_bit_cast(f32x4, raw[4 + 2 * NSL + 1])[0];
+        ua2[0] = __builtin_bit_cast(f32x4, raw[4]) + __builtin_bit_cast(f32x4, raw[6]);
+        ua2[1] = __builtin_bit_cast(f32x4, raw[5]) + __builtin_bit_cast(f32x4, raw[7]);
+      } else {
+        // The attention results arrive per frame slice (two quads of U_h and s_h each).  With all
+        // 4 + 3 NSL loads in flight at once the cell role needs 22 x 4 result registers at NSL = 6 on top
+        // of its 144 of resident weight planes: 64 spilled registers, and the product phase, re-reading
+        // weights from scratch, took 2.9 us instead of 1.0 (tools/chaintrace.py 375).  So the slices are
+        // software-pipelined through TWO register sets: slice h + 1 is issued before slice h is verified
+        // and added -- one load latency in all, ten result quads live at any time, as at NSL = 2.
+        auto ld_u = [=](int h, int j) {
+          return j < 2 ? pd_ld_raw(rxu, xub + (unsigned)h * XU_HALF + (unsigned)(2 * ablk + j) * XU_SLOT)
+                       : pd_ld_raw(rxu, xub + (unsigned)h * XU_HALF + 32u * XU_SLOT);
+        };
+        ua2[0] = f32x4{0.f, 0.f, 0.f, 0.f}; ua2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s = 0.f;
+        pacer.sleep();
+        u32x4 rx[4], ru[2][3];
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) rx[j] = pd_ld_raw(rxa, xab + (unsigned)(wave + 4 * j) * TILE_B);
+  #pragma unroll
+        for (int j = 0; j < 3; ++j) ru[0][j] = ld_u(0, j);
+        bool missed = false;
+  #pragma unroll
+        for (int h = 0; h < NSL; ++h) {
+          if (h + 1 < NSL) {
+  #pragma unroll
+            for (int j = 0; j < 3; ++j) ru[(h + 1) & 1][j] = ld_u(h + 1, j);
+          }
+          if (h == 0) {
+            missed |= cb_verify<4>(rx, [=](int j) { return pd_ld_raw(rxa, xab + (unsigned)(wave + 4 * j) * TILE_B); }, p.status);
+            part = (__builtin_bit_cast(f32x4, rx[0]) + __builtin_bit_cast(f32x4, rx[1])) +
+                   (__builtin_bit_cast(f32x4, rx[2]) + __builtin_bit_cast(f32x4, rx[3]));
+          }
+          missed |= cb_verify<3>(ru[h & 1], [=](int j) { return ld_u(h, j); }, p.status);
+          ua2[0] += __builtin_bit_cast(f32x4, ru[h & 1][0]);        // fixed order: slice 0, 1, ...
+          ua2[1] += __builtin_bit_cast(f32x4, ru[h & 1][1]);
+          s += __builtin_bit_cast(f32x4, ru[h & 1][2])[0];
+          asm volatile("" ::: "memory");       // (keeps later slices' loads from being scheduled up here)
+        }
+        pacer.update(missed);
+      }
       SSASR_DTRACE(i, 1);
-      part = (__builtin_bit_cast(f32x4, raw[0]) + __builtin_bit_cast(f32x4, raw[1])) +
-             (__builtin_bit_cast(f32x4, raw[2]) + __builtin_bit_cast(f32x4, raw[3]));
-      float s = __builtin_bit_cast(f32x4, raw[4 + 2 * NSL])[0];
-#pragma unroll
-      for (int h = 1; h < NSL; ++h) s += __builtin_bit_cast(f32x4, raw[4 + 2 * NSL + h])[0];       // fixed order
       float4 dq[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        f32x4 ua = __builtin_bit_cast(f32x4, raw[4 + k]);
-#pragma unroll
-        for (int h = 1; h < NSL; ++h) ua += __builtin_bit_cast(f32x4, raw[4 + 2 * h + k]);
+        const f32x4 ua = ua2[k];
         const f32x4 ub = f32x4{0.f, 0.f, 0.f, 0.f};
         const float4 vv = k ? vv1 : vv0, qv = k ? qv1 : qv0;
         dq[k].x = col_ok ? (ua[0] + ub[0] - s * vv.x) * (1.f - qv.x * qv.x) : 0.f;
@@ -536,10 +601,20 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               ac[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcA[k][0][pa], piece[level][0], ac[k], 0, 0, 0);
-              ac2[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcA[k][1][pa], piece[level][1], ac2[k], 0, 0, 0);
+              if constexpr (NSL == 2)
+                ac2[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcA[k][1][pa], piece[level][1], ac2[k], 0, 0, 0);
+            }
+            if constexpr (NSL > 2) {
+              // (more frame slices: the register file is the limit -- one accumulator per tile, the four
+              // tiles' chains still overlap; measured 11.8 -> 11.3 us per step at NSL = 6)
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                ac[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcA[k][1][pa], piece[level][1], ac[k], 0, 0, 0);
             }
           }
         }
+      }
+      if constexpr (NSL == 2) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) ac[k] += ac2[k];
       }

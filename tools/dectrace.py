@@ -30,7 +30,7 @@ e1.record()
 torch.cuda.synchronize()
 ops.check_persistent_status()
 print('decoder_loop forward: %.1f us total, %.2f us / decode step' % (e0.elapsed_time(e1) * 1e3, e0.elapsed_time(e1) * 1e3 / U))
-STEPS, SLOTS, WG = 64, 8, 192
+STEPS, SLOTS, WG = 64, 8, 256
 buf = np.zeros(WG * STEPS * SLOTS, dtype=np.uint64)
 lib.ssasr_debug_dtrace.restype = C.c_int
 lib.ssasr_debug_dtrace.argtypes = [C.c_void_p, C.c_size_t]
