@@ -342,7 +342,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     p.hx1 = d.ws_hx1; p.hx2 = d.ws_hx2; p.qx = nullptr;
     p.cnt = reinterpret_cast<unsigned*>(d.ws_sync); p.status = d.ws_sync + 5;
     p.B = (int)B; p.T = (int)T; p.U = (int)U; p.V = (int)V;
-    lp.part = d.ws_part; lp.NS = pl_ns(T);
+    lp.part = d.ws_part; lp.NS = pl_ns(T); lp.drop_slice = opt.test_drop_tile;
     if (!armed) {      // every exchanged buffer starts as the fill pattern
       const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4;
       SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, img_h * U, st));

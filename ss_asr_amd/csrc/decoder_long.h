@@ -43,6 +43,8 @@ struct DecLong {
   DecPersist d;                       // (d.qx, d.cnt unused: sentinel hand-offs only, q is formed in place)
   float* part;                        // [PL_RING][B][NS][PL_PART] records, every word the fill pattern on entry
   int NS;
+  int drop_slice;                     // fault injection for tests (SSASR_TEST_DROP_TILE, -1 = off): slice `drop_slice`
+                                      // of utterance 0 stops publishing its record from step 1 on
 };
 
 __host__ __device__ inline int pl_ns(int64_t T) { return (int)((T + PL_R - 1) / PL_R); }
@@ -214,7 +216,9 @@ __global__ __launch_bounds__(512) void decoder_fwd_long_kernel(DecLong pp) {
     // publish this workgroup's record, write-through, whole 128-byte lines per store instruction
     // (the re-arm stores of this step have long been issued; drained before the slot is reused)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid < 128) {
+    if (b == 0 && s == pp.drop_slice && t >= 1) {
+      // fault injection: this record stays unpublished; its peers give up, report and the launch drains
+    } else if (tid < 128) {
       float4 v = *reinterpret_cast<const float4*>(sRed + 4 * tid);
 #pragma unroll
       for (int g = 1; g < 4; ++g) {

@@ -394,6 +394,43 @@ def test_long_encoder_persistent_decode_loop_equals_multi_launch_loop(B, Tp, U, 
         np.testing.assert_allclose(x.numpy(), y.numpy(), atol=5e-5 * max(1.0, float(y.abs().max())), rtol=0)
 
 
+def test_long_encoder_decode_loop_with_a_missing_record_times_out_and_is_reported():
+    """Fault injection (SSASR_TEST_DROP_TILE): slice 1 of utterance 0 stops publishing its partial-softmax
+    record after the first decode step of the long-encoder persistent loop.  Its peers' bounded waits give
+    up, every other wait of the launch drains through the latch (40 steps x 192 + 64 workgroups: seconds,
+    not minutes), the status word names the decode loop, and the next call is healthy."""
+    import time
+    from ss_asr_amd import _lib, ops
+    from ss_asr_amd.asr import ASR
+    torch.manual_seed(5)
+    model = ASR(50, 256, 256, 128, 80, 1.0).to('cuda:0')
+    B, Tp, U = 32, 375, 40
+    feat = torch.randn(B, Tp, 512, device='cuda')
+    enc_len = torch.full((B,), Tp, dtype=torch.int32, device='cuda')
+    teacher = torch.randint(3, 50, (B, U + 2), device='cuda').to(torch.int32)
+    modes = [0] * U
+    with torch.no_grad():
+        comp = ops.attn_precompute(feat, model.attention.psi.weight, model.attention.psi.bias)
+        good, _, _ = ops.decoder_loop(feat, comp, enc_len, teacher, modes, None, model._decoder_params())
+        torch.cuda.synchronize()
+        ops.check_persistent_status()
+        old = _lib.set_option('SSASR_TEST_DROP_TILE', 1)
+        try:
+            t0 = time.perf_counter()
+            ops.decoder_loop(feat, comp, enc_len, teacher, modes, None, model._decoder_params())
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        finally:
+            _lib.set_option('SSASR_TEST_DROP_TILE', old)
+        with pytest.raises(RuntimeError, match='decode loop forward'):
+            ops.check_persistent_status()
+        assert elapsed < 30.0, elapsed
+        again, _, _ = ops.decoder_loop(feat, comp, enc_len, teacher, modes, None, model._decoder_params())
+        torch.cuda.synchronize()
+        ops.check_persistent_status()
+        assert torch.equal(again, good)
+
+
 @pytest.mark.slow
 def test_long_utterances_config4_shape_against_the_oracle():
     """BASELINE.json configs[3] in miniature: 1,500+ frame utterances (T' = 192 > 128, so the
