@@ -1368,8 +1368,26 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
 // NW = recurrence waves (4, or 8 for H = 256: each wave then loads 2 instead of 4 partial tiles and
 // multiplies into 1 instead of 2 unit tiles -- the product is issue bound, 32 cycles per MFMA);
 // the helper wave is wave NW: 64 * (NW + 1) threads.
+// which steps' gate-derivative rows go straight to `gates` (the two-halves in-place form holds the first two of a
+// launch back: see the note on in-place rows above)
+__device__ __forceinline__ bool epi_rows_ok(bool col_ok, int half, int hv, bool inplace, int i, int i0) {
+  return col_ok && half == 0 && (hv == 1 || !inplace || i >= i0 + 2);
+}
+// LANE SPLIT (round 3, NW = 4; SSASR_BPTT_LANE_SPLIT=0 compiles the earlier form for A/B).  The sum of the
+// partial tiles used to be: wave w loads sources 4w .. 4w + 3 whole, adds them, writes its partial to LDS,
+// barrier, wave 0 adds the four partials and runs the whole gate epilogue (4 units per lane) while waves
+// 1-3 wait.  Now wave w owns unit quad w of the tile: one load instruction fetches that quad's 256 bytes
+// of FOUR sources (16-lane group g reads source 4 t + g: 8 whole lines per instruction, as before), the
+// four groups are added on the DPP / permlane network (fixed order, every lane the same bits), and every
+// wave runs the epilogue of its own 64 (unit, column) pairs, one per lane.  No LDS reduction, one barrier
+// less per step, the epilogue's 16-deep dependent chain becomes 4 deep; the helper wave writes the
+// row-major gate derivatives for the GEMMs one barrier later, off the critical path.
+#ifndef SSASR_BPTT_LANE_SPLIT
+#define SSASR_BPTT_LANE_SPLIT 1
+#endif
 template <int TPW, int HV, int NW = 4>   // TPW = (H / 16) / 4; grid.z = chunks * HV
 __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
+  constexpr bool LS = SSASR_BPTT_LANE_SPLIT != 0 && NW == 4;
   if (SSASR_PERSIST_PRIO) __builtin_amdgcn_s_setprio(SSASR_PERSIST_PRIO);
   constexpr int T = 4 * TPW;                    // unit tiles = H / 16
   constexpr int SPW = T / NW;                   // source tiles loaded per wave
@@ -1429,6 +1447,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
     }
     PersistPacer pacer{e.delay, 0};
     const u32x4 fill = {PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL};
+    // LS: the waves read this launch's first coefficients before the first per-step barrier
+    if (LS) __syncthreads();
     for (int i = i0; i < i1; ++i) {
       if (i > 0) {
         if (i > i0) pacer.sleep();
@@ -1441,7 +1461,15 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
         sv.publish(&coef[(i + 2) % 3][0][lane], live(i + 2));
         if (i + 3 < S) sv.fetch(e, gbase, cbase, d, i + 3, n, u0);
       }
-      __syncthreads();      // partial tiles summed per wave (red), loads verified
+      if (!LS) __syncthreads();      // partial tiles summed per wave (red), loads verified
+      else __syncthreads();          // LS: this IS the "gate derivatives in LDS" barrier (the loads are verified before it)
+      if (LS && epi_rows_ok(col_ok, half, HV, inplace, i, i0)) {
+        // row-major copy of this step's gate derivatives for the dX and weight-gradient GEMMs
+        const int sr = d ? i : S - 1 - i;
+        float* g0 = gbase + ((int64_t)sr * N + n) * 4 * H + u0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[i % NG][g][lane]);
+      }
       if (i > i0) {
         pacer.update(missed != 0);
         missed = 0;
@@ -1465,7 +1493,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
           for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[(i0 + k) % NG][g][lane]);
         }
       }
-      __syncthreads();      // gate derivatives in LDS
+      if (!LS) __syncthreads();      // gate derivatives in LDS
     }
     return;
   }
@@ -1506,7 +1534,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
   const bool epi = wave == 0 && col_ok;
   float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps
   float* dcs = e.dc_state ? e.dc_state + ((int64_t)d * N + n) * H + u0 : nullptr;
-  if (epi && i0 > 0 && dcs) dcv = ld4(dcs);
+  if (!LS && epi && i0 > 0 && dcs) dcv = ld4(dcs);
+  // LS: lane (q, r) of wave w owns unit 16 tile + 4 w + q of column n0 + r
+  float dc1 = 0.f;
+  float* dcs1 = e.dc_state ? e.dc_state + ((int64_t)d * N + n) * H + 16 * tile + 4 * wave + q : nullptr;
+  if (LS && col_ok && i0 > 0 && dcs1) dc1 = *dcs1;
+  if (LS) __syncthreads();      // the helper wave has published the coefficients of the first two steps
 
   for (int i = i0; i < i1; ++i) {
     const int s = d ? i : S - 1 - i;            // reverse of the forward order
@@ -1518,9 +1551,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
       // partial tiles for this workgroup's units from sources SPW*wave .. (+SPW)
       const unsigned base = (unsigned)((i - 1) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
       u32x4 raw[SPW];
+      // LS: 16-lane group q reads unit quad `wave` (256 bytes) of source 4 t + q; else wave w reads sources
+      // SPW w .. whole
+      const unsigned lo = LS ? (unsigned)(q * TILE_B + (wave * 16 + r) * 16) : (unsigned)(SPW * wave * TILE_B + lane * 16);
+      constexpr unsigned LSTEP = LS ? 4 * TILE_B : TILE_B;
 #pragma unroll
       for (int t = 0; t < SPW; ++t)
-        raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((SPW * wave + t) * TILE_B + lane * 16), (int)base, 16);
+        raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(lo + t * LSTEP), (int)base, 16);
       for (unsigned tries = 0;; ++tries) {
         bool anybad = false;
 #pragma unroll
@@ -1529,8 +1566,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
                            raw[t].z == PERSIST_SENTINEL || raw[t].w == PERSIST_SENTINEL;
           if (__any(bad)) {
             anybad = true;
-            raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((SPW * wave + t) * TILE_B + lane * 16),
-                                                           (int)base, 16);
+            raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(lo + t * LSTEP), (int)base, 16);
           }
         }
         if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
@@ -1541,11 +1577,49 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
 #pragma unroll
       for (int t = 0; t < SPW; ++t) part += __builtin_bit_cast(f32x4, raw[t]);
     }
+    if (LS) {
+      // the four 16-lane groups hold the sums of sources = 0, 1, 2, 3 (mod 4): add them on the permlane
+      // network (rows 0<->1, 2<->3, then the two halves) -- every lane ends with the same bits -- and run
+      // this lane's (unit, column) through the gate epilogue
+      float v4[4] = {part[0], part[1], part[2], part[3]};
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        float mine;
+        const float other = swap16_other(v4[k2], mine);
+        const float s2 = mine + other;
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+        v4[k2] = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+      }
+      const float dh_in = q == 0 ? v4[0] : q == 1 ? v4[1] : q == 2 ? v4[2] : v4[3];
+      SSASR_PTRACE(i, 4);
+      SSASR_PTRACE(i, 5);
+      const int el = 16 * wave + r;                 // the (unit quad, column) lane of the coefficient / sG arrays
+      float di = 0.f, df = 0.f, dg = 0.f, dov = 0.f;
+      if (col_ok) {
+        const float* cf = reinterpret_cast<const float*>(&coef[i % 3][0][el]) + q;
+        const float kA = cf[0 * 64 * 4], kO = cf[1 * 64 * 4], kI = cf[2 * 64 * 4], kG = cf[3 * 64 * 4],
+                    kF = cf[4 * 64 * 4], kC = cf[5 * 64 * 4], a1 = cf[6 * 64 * 4];
+        const float dh = dh_in + a1;
+        const float dc = dc1 + dh * kA;
+        dov = dh * kO;
+        di = dc * kI;
+        dg = dc * kG;
+        df = dc * kF;
+        dc1 = dc * kC;
+      }
+      float* sg = reinterpret_cast<float*>(&sG[i % NG][0][el]) + q;
+      sg[0 * 64 * 4] = di;
+      sg[1 * 64 * 4] = df;
+      sg[2 * 64 * 4] = dg;
+      sg[3 * 64 * 4] = dov;
+      SSASR_PTRACE(i, 6);
+    } else {
     red[wave * 64 + lane] = part;
     SSASR_PTRACE(i, 4);
     __syncthreads();        // partial sums in LDS
     SSASR_PTRACE(i, 5);
-    if (wave == 0) {
+    }
+    if (!LS && wave == 0) {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 di = z4, df = z4, dg = z4, dov = z4;
       if (epi) {
@@ -1641,7 +1715,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
       SSASR_PTRACE(i, 7);
     }
   }
-  if (epi && half == 0 && i1 < S && dcs) st4(dcs, dcv);
+  if (!LS && epi && half == 0 && i1 < S && dcs) st4(dcs, dcv);
+  if (LS && col_ok && half == 0 && i1 < S && dcs1) *dcs1 = dc1;
 }
 
 // out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:], plain store.  Used for the
