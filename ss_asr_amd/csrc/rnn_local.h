@@ -50,6 +50,9 @@
 #elif SSASR_FL_LOAD_MODE == 3
 #define FL_ACQUIRE() do {} while (0)
 #define FL_LOAD_AUX 1
+#elif SSASR_FL_LOAD_MODE == 4
+#define FL_ACQUIRE() asm volatile("buffer_inv sc0" ::: "memory")
+#define FL_LOAD_AUX 0
 #else
 #define FL_ACQUIRE() do {} while (0)
 #define FL_LOAD_AUX 16
