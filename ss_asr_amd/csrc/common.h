@@ -166,7 +166,9 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0 = 0, int64_t i1 = 0,
                                  float* dc_state = nullptr, const float* whh_f = nullptr, const float* whh_r = nullptr,
-                                 bool armed = false, const float* tsave = nullptr);
+                                 bool armed = false, const float* tsave = nullptr, void* stop_event = nullptr);
+// stop_event (a hipEvent_t, K-split form only): recorded by the kernel's OWN completion signal
+// (hipExtLaunchKernel) -- no barrier packet of its own between this launch and the next on the stream
 // Process-wide diagnostic switches (include/ssasr.h, ssasr_set_option): read from the environment
 // ONCE, when the first entry point runs, never per call; A/B tools change them through
 // ssasr_set_option.  Everything here selects between kernels that compute the same result.

@@ -1,6 +1,7 @@
 // Host entry points for the BiLSTM layers and the single LSTM cell step.
 // Kernels: rnn_kernels.h.
 #include <cstdlib>
+#include <hip/hip_ext.h>
 #include "../../include/ssasr.h"
 #include "rnn_kernels.h"
 #include "rnn_local.h"
@@ -310,7 +311,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0, int64_t i1,
                                  float* dc_state, const float* whh_f, const float* whh_r, bool armed,
-                                 const float* tsave) {
+                                 const float* tsave, void* stop_event) {
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int kpw = (int)(H / 16);
   const SsasrOptions& opt = ssasr_options();
@@ -393,11 +394,16 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     // (the attribute is a property of the loaded code object: setting it again is idempotent and costs
     // no device work)
     if (reserve) SSASR_HIP(hipFuncSetAttribute(bptt_rs_fn(kpw, halves, nw), hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
-    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<1, 1>), pgrid, pblock, reserve_now, st, p);
-    else if (kpw == 8 && halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 2>), pgrid, pblock, reserve_now, st, p);
-    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<2, 1>), pgrid, pblock, reserve_now, st, p);
-    else if (halves) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), pgrid, pblock, reserve_now, st, p);
-    else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), pgrid, pblock, reserve_now, st, p);
+    // stop_event: the range's completion event rides on the dispatch's own completion signal instead of a
+    // hipEventRecord behind it (a barrier packet between two ranges cost 6-7 us of idle stream each)
+    hipEvent_t stop = (hipEvent_t)stop_event;
+#define SSASR_RS_LAUNCH(TPW_, HV_) hipExtLaunchKernelGGL((lstm_enc_bwd_rs_kernel<TPW_, HV_>), pgrid, pblock, (unsigned)reserve_now, st, nullptr, stop, 0u, p)
+    if (kpw == 4) SSASR_RS_LAUNCH(1, 1);
+    else if (kpw == 8 && halves) SSASR_RS_LAUNCH(2, 2);
+    else if (kpw == 8) SSASR_RS_LAUNCH(2, 1);
+    else if (halves) SSASR_RS_LAUNCH(4, 2);
+    else SSASR_RS_LAUNCH(4, 1);
+#undef SSASR_RS_LAUNCH
   } else if (!opt.persistent_counter) {
     SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(dirs * S * 4 * H * Np), st));
     if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
@@ -409,6 +415,7 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, false>), pgrid, pblock, 0, st, p);
   }
   SSASR_LAUNCH_CHECK();
+  if (stop_event && !ksplit) SSASR_HIP(hipEventRecord((hipEvent_t)stop_event, st));   // (only the K-split launch carries it itself)
   return SSASR_OK;
 }
 
@@ -764,11 +771,10 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
   for (int k = 0; k < nseg; ++k) {
     const int64_t i0 = k * S / nseg, i1 = (k + 1) * S / nseg;
     // the K-split kernel takes its weight slices straight from W_hh: no transposed copy
-    rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
-                                      ws_dc, w_hh_f, w_hh_r, armed, tsave);
-    if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
     done[k] = evs->ev[k];
-    SSASR_HIP(hipEventRecord(done[k], st));
+    rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, i0, i1,
+                                      ws_dc, w_hh_f, w_hh_r, armed, tsave, done[k]);
+    if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
   }
   const int64_t rows = S * N;
   for (int d = 0; d < 2 && dx; ++d) {        // input gradient (critical path: the layer below needs it)
