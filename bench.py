@@ -168,7 +168,9 @@ def decode_loop_attention(device, B=32, T=100, U=52, A=128, E=512, D=256):
     s = 4
     nbytes = B * T * (A + E) * s + B * T * (s + 1) + B * (D + E) * s + D * A * s
     moved = B * T * A * s + 2 * B * T * s + B * (D + E) * s          # comp from L2, alpha out, h1 in, context out
-    stage_us, src = None, os.path.join(ROOT, 'profiles', 'r02_dectrace.txt')
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_dectrace.txt')))
+    stage_us, src = None, (found[-1] if found else '')
     try:
         with open(src) as f:
             for line in f:
@@ -181,7 +183,8 @@ def decode_loop_attention(device, B=32, T=100, U=52, A=128, E=512, D=256):
                note='whole ssasr_decoder_fwd call / U: includes the embedding gather, the workspace fill and the logits GEMM',
                algorithmic_bytes_per_step=nbytes, bytes_moved_per_step=moved, shape=dict(B=B, T=T, U=U))
     if stage_us:
-        out.update(attention_stage_us=round(stage_us, 2), stage_source='profiles/r02_dectrace.txt (trace build, s1 -> s4)',
+        out.update(attention_stage_us=round(stage_us, 2),
+                   stage_source='profiles/%s (trace build of the builder\'s box, s1 -> s4; not a measurement of this run)' % os.path.basename(src),
                    achieved_equivalent=round(nbytes / (stage_us * 1e-6) / 1e9, 1),
                    frac_equivalent=round(nbytes / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
     return out
