@@ -503,6 +503,53 @@ def test_four_train_steps_follow_the_oracle_trajectory():
     assert worst < 5e-4, worst
 
 
+def test_two_step_objects_alternating_in_one_process_do_not_disturb_each_other():
+    """BASELINE.json configs[4]'s Seed loop alternates trainers in one process.  The step objects share
+    process-wide plumbing (the second stream, the weight-gradient listener, the status rows): an ASR step
+    object and a joint CTC + attention step object on a second model take turns, and the ASR model's
+    losses, norms and final weights must equal a run in which it trained alone ("allows ONE
+    train-step object per process")."""
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.ctc import JointCTCASR, JointCTCTrainStep
+    from ss_asr_amd.engine import ASRTrainStep, label_geometry
+    from ss_asr_amd.synthetic import make_batch
+    dims = (50, 64, 64, 32, 80)
+    shapes = [([72, 64, 40, 17], [9, 7, 6, 3]), ([96, 95, 94, 50, 49, 8], [11, 10, 9, 6, 5, 2]), ([56, 24, 16], [7, 3, 2])]
+    batches = []
+    for k, (fr, ch) in enumerate(shapes):
+        x, y, lens = make_batch(np.array(fr), np.array(ch), 80, seed=60 + k)
+        batches.append((x.cuda(), y.cuda(), lens, label_geometry(y)[1]))
+
+    def run(interleave):
+        torch.manual_seed(0)
+        model = ASR(*dims, 1.0)
+        lo.seeded_weights(model, 31)
+        step = ASRTrainStep(model.to('cuda:0'))
+        other = None
+        if interleave:
+            joint = JointCTCASR(*dims, 1.0, ctc_weight=0.3)
+            lo.seeded_weights(joint, 32)
+            other = JointCTCTrainStep(joint.to('cuda:0'))
+        out = []
+        for k, (x, y, lens, ans_len) in enumerate(batches):
+            loss = float(step(x, y, lens, ans_len).detach())
+            if other is not None:
+                xo, yo, lo_, ao = batches[(k + 1) % len(batches)]
+                assert np.isfinite(float(other(xo, yo, lo_, ao).detach()))
+            out.append((loss,) + tuple(step.optim.poll(wait=True)))
+        if other is not None:
+            other.finish()
+        step.finish()
+        return out, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+
+    alone, w_alone = run(False)
+    mixed, w_mixed = run(True)
+    for (l0, n0, s0), (l1, n1, s1) in zip(alone, mixed):
+        assert not s0 and not s1
+        assert abs(l0 - l1) < 1e-6 and abs(n0 - n1) < 1e-6 * max(1.0, n0)
+    assert float((w_alone - w_mixed).abs().max()) < 1e-6
+
+
 @pytest.mark.parametrize('name', ['full_b16_t400', 'bench_b32_t800'])
 def test_backward_is_reproducible_with_overlapped_streams(golden, name):
     """The recurrences have no atomics, so repeated backward passes over the same batch may
