@@ -111,6 +111,9 @@ __global__ void chain_de_fixup_kernel(float* de, const float* att, const float* 
 #ifndef SSASR_WPACE_INIT
 #define SSASR_WPACE_INIT 100
 #endif
+#ifndef SSASR_WPACE_INIT_ATT          // the attention workgroups' first delay
+#define SSASR_WPACE_INIT_ATT 120
+#endif
 struct WavePacer {
   int delay, clean;
   __device__ __forceinline__ void sleep() const {
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(320) void decoder_bwd_chain_kernel(DecBwdChain p) {
       const int tl = hw + 8 * k;
       cvr[k] = tl < nrow ? aload4(cb + (int64_t)tl * A) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    WavePacer pacer{120, 0};
+    WavePacer pacer{SSASR_WPACE_INIT_ATT, 0};
     for (int t = U - 1; t >= 0; --t) {
       SSASR_DTRACE(U - 1 - t, 0);
       // alpha of this step's rows: independent of the hand-off, fetched while waiting for it
