@@ -149,6 +149,11 @@ struct GemmDesc {
   // which the other classes exit at once; ssasr_launch_gemm sets gx / gy / gz): work that runs on a
   // second stream beside an XCD-local persistent recurrence keeps to the XCDs that one leaves free
   int cls_lo, cls_n, gx, gy, gz;
+  // kcat > 1 (split-bf16 kernel, splitk == 1): the product runs over kcat K segments of length K each, the
+  // s-th taken at A + s * ska and B + s * skb, all into ONE accumulator: C = act(alpha * sum_s A_s . B_s ...)
+  // -- e.g. the input gradient dX = dG_f W_f + dG_r W_r of a BiLSTM layer as one launch, C written once
+  int kcat;
+  int64_t ska, skb;
 };
 // Side-stream work beside a persistent recurrence: restricts `g` to the free XCD classes when the
 // recurrences are placed XCD-locally (options), else leaves it unrestricted.
@@ -185,6 +190,7 @@ struct SsasrOptions {
   int delay_fwd, delay_bwd, delay_bwd_ksplit;   // SSASR_PERSIST_DELAY_FWD / _BWD (initial pacing, x 64 cycles; -1 = default)
   int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
   int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs (0: on v_mfma_f32_16x16x4_f32)
+  int gemm_kcat;                  // SSASR_GEMM_KCAT (1): a layer's input gradient as ONE launch over both directions' K segments
   int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches
   int test_drop_tile;             // SSASR_TEST_DROP_TILE (-1): fault injection, see EncPersist::drop_tile
   int attn_rph;                   // SSASR_ATTN_RPH: 0 model, 2 | 3 | 4 | 6 rows per half-wave of the split-T attention kernel

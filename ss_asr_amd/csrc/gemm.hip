@@ -81,6 +81,12 @@ struct TileLoader {
     }
   }
 
+  // K segments (GemmDesc::kcat): after the last step of a segment, move every source pointer to the next one
+  __device__ __forceinline__ void jump(int64_t delta) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ptr[i] += delta;
+  }
+
   // advance by one K step (BK)
   __device__ __forceinline__ void advance() {
 #pragma unroll
@@ -541,10 +547,15 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
   const int kz = bzz - bz * g.splitk;
   const int m0 = by * BM, n0 = bx * BN;
 
-  int kchunk = (g.K + g.splitk - 1) / g.splitk;
+  // kcat > 1 (splitk == 1, K % BK == 0, dense K layouts: checked by the launcher): the K loop runs over kcat
+  // segments of length K back to back; at a segment's end the loaders jump to the next segment's operands
+  const int ktot = g.kcat > 1 ? g.kcat * g.K : g.K;
+  int kchunk = (ktot + g.splitk - 1) / g.splitk;
   kchunk = (kchunk + BK - 1) / BK * BK;
   const int kbeg = kz * kchunk;
-  const int kend = min(g.K, kbeg + kchunk);
+  const int kend = min(ktot, kbeg + kchunk);
+  const int64_t jumpA = g.kcat > 1 ? g.ska - (TA ? (int64_t)g.K * g.ma.ld : (int64_t)g.K) : 0;
+  const int64_t jumpB = g.kcat > 1 ? g.skb - (TB ? (int64_t)g.K * g.mb.ld : (int64_t)g.K) : 0;
 
   Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
   Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
@@ -580,6 +591,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
     if (more) {
       la.advance();
       lb.advance();
+      if (g.kcat > 1 && (k0 + BK) % g.K == 0) { la.jump(jumpA); lb.jump(jumpB); }
       if (interior && k0 + 2 * BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
       else { la.load_guarded(ra, k0 + BK, kend, vecA); lb.load_guarded(rb, k0 + BK, kend, vecB); }
     }
@@ -687,9 +699,13 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   if (g.K < 0 || !g.A || !g.B || !g.C) return SSASR_EARG;
   if (g.splitk < 1) g.splitk = 1;
   if (g.splitk > 1 && g.act != 0) return SSASR_EARG;
+  // K segments: split-bf16 kernel only, whole K steps per segment, dense (row-major) K-side layouts
+  if (g.kcat > 1 && (g.splitk != 1 || !ssasr_options().gemm_x6 || g.K % 32 != 0 || (g.ta && g.ma.inner) ||
+                     (g.tb && g.mb.inner)))
+    return SSASR_EARG;
   if (g.batch * g.splitk > 65535) return SSASR_EARG;
-  const bool vecA = aligned16(g.A) && map_vec_ok(g.ma) && (g.sa % 4 == 0);
-  const bool vecB = aligned16(g.B) && map_vec_ok(g.mb) && (g.sb % 4 == 0);
+  const bool vecA = aligned16(g.A) && map_vec_ok(g.ma) && (g.sa % 4 == 0) && (g.kcat <= 1 || g.ska % 4 == 0);
+  const bool vecB = aligned16(g.B) && map_vec_ok(g.mb) && (g.sb % 4 == 0) && (g.kcat <= 1 || g.skb % 4 == 0);
   // 128x128 tiles only when they still give every CU work.
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
   if (const int forced = ssasr_options().gemm_tile) {       // diagnostic: force a tile shape

@@ -479,7 +479,8 @@ static int bilstm_bwd_impl(bool armed, const float* tsave, const float* dy, int6
   SSASR_LAUNCH_CHECK();
 
   // Input gradient (critical path: the layer below needs it).
-  for (int d = 0; d < 2 && dx; ++d) {
+  const bool kcat = dx && ssasr_options().gemm_x6 != 0 && ssasr_options().gemm_kcat != 0 && (4 * H) % 32 == 0;      // both directions as the two K segments of one launch
+  for (int d = 0; d < (kcat ? 1 : 2) && dx; ++d) {
     const float* dG = gates + d * rows * 4 * H;
     GemmDesc g{};
     g.A = dG; g.ma = rm_dense(4 * H);
@@ -487,6 +488,7 @@ static int bilstm_bwd_impl(bool armed, const float* tsave, const float* dy, int6
     g.C = dx; g.mc = RowMap{0, N, dxs_s, dxs_n};
     g.M = (int)rows; g.N = (int)I; g.K = (int)(4 * H);
     g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = d ? 1.f : 0.f; g.splitk = 1; g.batch = 1;
+    if (kcat) { g.kcat = 2; g.ska = rows * 4 * H; g.skb = wih[1] - wih[0]; }
     rc = ssasr_launch_gemm(g, st);
     if (rc) return rc;
   }
@@ -777,13 +779,18 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     if (rc) return rc;      // (ksplit_ok was checked: EARG here means misaligned arguments)
   }
   const int64_t rows = S * N;
-  for (int d = 0; d < 2 && dx; ++d) {        // input gradient (critical path: the layer below needs it)
+  // input gradient (critical path: the layer below needs it): dX = dG_f W_ih_f + dG_r W_ih_r.  On the
+  // split-bf16 kernel both directions are the two K segments of ONE launch (GemmDesc::kcat): dX is written
+  // once instead of written, read back and written again, and the second launch's tail is gone
+  const bool kcat = dx && ssasr_options().gemm_x6 != 0 && ssasr_options().gemm_kcat != 0 && (4 * H) % 32 == 0;
+  for (int d = 0; d < (kcat ? 1 : 2) && dx; ++d) {
     GemmDesc g{};
     g.A = gates + d * rows * 4 * H; g.ma = rm_dense(4 * H);
     g.B = wih[d]; g.mb = rm_dense(I);
     g.C = dx; g.mc = RowMap{0, N, dxs_s, dxs_n};
     g.M = (int)rows; g.N = (int)I; g.K = (int)(4 * H);
     g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = d ? 1.f : 0.f; g.splitk = 1; g.batch = 1;
+    if (kcat) { g.kcat = 2; g.ska = rows * 4 * H; g.skb = wih[1] - wih[0]; }
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   for (int k = 0; k < nseg; ++k) {
