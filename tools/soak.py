@@ -1,4 +1,4 @@
-"""240 train steps on eight bench batches; prints the loss every 40 steps, the last step's (grad norm,
+"""240 (SOAK_STEPS) train steps on eight bench batches; prints the loss every 40 steps, the last step's (grad norm,
 skipped) and the number of NaN-skipped steps.  Run twice (SSASR_GEMM_X6=1 / 0) to compare the
 trajectories of the two matrix-product forms: equal to 4 decimals for ~160 steps, then the usual
 divergence of a sampled (tf_rate 0.9) training run from rounding-level differences."""
@@ -21,3 +21,16 @@ for i in range(int(os.environ.get("SOAK_STEPS", "240"))):
     l = st(*bs[i % 8])
     if i % 40 == 39: out.append(round(float(l), 4))
 print(os.environ.get('SSASR_GEMM_X6', '1'), out, st.finish(), st.skipped_steps)
+# SOAK_LONG=n: n more steps on configs[3]'s batch (1500-3000 frames, ~300 label steps: the long decode loop and
+# the six-slice backward chain).  A persistent kernel that gave up waiting raises from the step / finish().
+n_long = int(os.environ.get("SOAK_LONG", "0"))
+if n_long:
+    from ss_asr_amd.synthetic import config4_batch
+    x, y, lens = config4_batch()
+    _, al = label_geometry(y)
+    x, y = x.to(dev), y.to(dev)
+    ls = []
+    for i in range(n_long):
+        l = st(x, y, lens, al)
+        if i % 50 == 49: ls.append(round(float(l), 4))
+    print('long', ls, st.finish(), st.skipped_steps)
