@@ -47,7 +47,7 @@ int ssasr_abi_version(void);
  * calls.  Names: SSASR_NO_PERSISTENT, SSASR_PERSISTENT_COUNTER, SSASR_NO_FUSED_INPUT,
  * SSASR_FWD_NB, SSASR_BPTT_GATHER, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
  * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
- * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_GEMM_X6, SSASR_GEMM_KCAT, SSASR_LAST_SEG_PCT, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
+ * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_GEMM_X6, SSASR_GEMM_KCAT, SSASR_LAST_SEG_PCT, SSASR_TAIL_INLINE, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
  * SSASR_TEST_DROP_TILE (fault injection for the timeout test, -1 = off), SSASR_BPTT_LOCAL, SSASR_FWD_LOCAL,
  * SSASR_XCD_ROUND_ROBIN (the probe's verdict, settable for tests).  Unknown name: -1. */
 int ssasr_set_option(const char* name, int value);

@@ -192,6 +192,7 @@ struct SsasrOptions {
   int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs (0: on v_mfma_f32_16x16x4_f32)
   int gemm_kcat;                  // SSASR_GEMM_KCAT (1): a layer's input gradient as ONE launch over both directions' K segments
   int last_seg_pct;               // SSASR_LAST_SEG_PCT (60): length of the LAST recurrence range of a segmented BPTT, in percent of an equal share
+  int tail_inline;                // SSASR_TAIL_INLINE (1): the first layer's last range of weight-gradient products on the main stream
   int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches
   int test_drop_tile;             // SSASR_TEST_DROP_TILE (-1): fault injection, see EncPersist::drop_tile
   int attn_rph;                   // SSASR_ATTN_RPH: 0 model, 2 | 3 | 4 | 6 rows per half-wave of the split-T attention kernel

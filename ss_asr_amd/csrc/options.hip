@@ -35,6 +35,7 @@ void init_options() {
   g_opt.gemm_x6 = env_int("SSASR_GEMM_X6", 1);
   g_opt.gemm_kcat = env_int("SSASR_GEMM_KCAT", 1);
   g_opt.last_seg_pct = env_int("SSASR_LAST_SEG_PCT", 60);
+  g_opt.tail_inline = env_int("SSASR_TAIL_INLINE", 1);
   g_opt.no_residency_check = env_flag("SSASR_NO_RESIDENCY_CHECK");
   g_opt.test_drop_tile = env_int("SSASR_TEST_DROP_TILE", -1);
   g_opt.attn_rph = env_int("SSASR_ATTN_RPH", 0);
@@ -62,6 +63,7 @@ const Named kNames[] = {
     {"SSASR_GEMM_X6", &SsasrOptions::gemm_x6},
     {"SSASR_GEMM_KCAT", &SsasrOptions::gemm_kcat},
     {"SSASR_LAST_SEG_PCT", &SsasrOptions::last_seg_pct},
+    {"SSASR_TAIL_INLINE", &SsasrOptions::tail_inline},
     {"SSASR_NO_RESIDENCY_CHECK", &SsasrOptions::no_residency_check},
     {"SSASR_TEST_DROP_TILE", &SsasrOptions::test_drop_tile},
     {"SSASR_ATTN_RPH", &SsasrOptions::attn_rph},

@@ -519,12 +519,12 @@ extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, con
 // Caller-owned events that order the second stream after the first (ssasr_events_create): one set
 // serves every call of its owner in turn -- a stream's wait refers to the record that preceded it,
 // so an event may be recorded again as soon as the wait on it has been enqueued.
-struct SsasrEvents { hipEvent_t ev[SSASR_MAX_SEGMENTS]; };
+struct SsasrEvents { hipEvent_t ev[SSASR_MAX_SEGMENTS + 1]; };   // + 1: second stream -> first
 
 extern "C" int ssasr_events_create(void** handle) {
   if (!handle) return SSASR_EARG;
   SsasrEvents* h = new SsasrEvents();
-  for (int i = 0; i < SSASR_MAX_SEGMENTS; ++i) {
+  for (int i = 0; i <= SSASR_MAX_SEGMENTS; ++i) {
     const hipError_t e = hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming);
     if (e != hipSuccess) {
       for (int j = 0; j < i; ++j) (void)hipEventDestroy(h->ev[j]);
@@ -805,11 +805,24 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     if (kcat) { g.kcat = 2; g.ska = rows * 4 * H; g.skb = wih[1] - wih[0]; }
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
+  // A layer without an input gradient is the first one: its last range ends the backward pass, nothing is left
+  // to run beside that range's weight-gradient products, and the two event hand-offs around them (first
+  // stream -> second -> first, ~10 + 20 us on the timeline) are exposed in front of the optimiser.  They go on
+  // `stream` itself, right behind the recurrence and on the whole chip, once the second stream's earlier
+  // ranges (which add into the same outputs) are done -- long before, so that wait costs nothing.
+  const bool tail_inline = !dx && ssasr_options().tail_inline != 0;
   for (int k = 0; k < nseg; ++k) {
     const int64_t i0 = bound[k], i1 = bound[k + 1];
-    SSASR_HIP(hipStreamWaitEvent(side, done[k], 0));
+    const bool inl = tail_inline && k == nseg - 1;
+    if (inl) {
+      SSASR_HIP(hipEventRecord(evs->ev[SSASR_MAX_SEGMENTS], side));
+      SSASR_HIP(hipStreamWaitEvent(st, evs->ev[SSASR_MAX_SEGMENTS], 0));
+    } else {
+      SSASR_HIP(hipStreamWaitEvent(side, done[k], 0));
+    }
     // iterations [i0, i1) cover steps S - i1 .. S - i0 - 1 of the forward direction and i0 .. i1 - 1 of the reverse
-    if ((rc = wgrad_pair_range(S - i1, S - i0, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih, dwhh, db, db2, side, true)))
+    if ((rc = wgrad_pair_range(S - i1, S - i0, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih, dwhh, db, db2,
+                               inl ? st : side, !inl)))
       return rc;
   }
   return SSASR_OK;
