@@ -231,6 +231,52 @@ def test_bilstm_segmented_bptt_with_overlapped_weight_gradients(N, S, I, H, segm
         close(a.grad - 0.25, b.grad, 3e-4, 'd' + name)
 
 
+@pytest.mark.parametrize('pct,inline,want_dx', [(10, 1, False), (100, 1, False), (60, 0, False), (35, 1, True)])
+def test_bilstm_segmented_bptt_range_options(pct, inline, want_dx, monkeypatch):
+    """The shape of the step ranges is a tuning choice, not part of the result: a short or an equal last range
+    (SSASR_LAST_SEG_PCT), the last range's weight gradients on the main stream (SSASR_TAIL_INLINE; taken by a
+    layer that is asked for no input gradient, as the first layer of the Listener) or on the second one."""
+    from ss_asr_amd import ops, _lib
+    from ss_asr_amd.optim import FlatParameters
+    monkeypatch.setattr(ops, 'bptt_segments', 4)
+    N, S, I, H = 20, 150, 24, 64
+    lens = sorted(np.random.default_rng(5).integers(S // 3, S + 1, size=N).tolist(), reverse=True)
+    lens[0] = S
+    x = rnd(N, S, I, seed=71)
+    for i, l in enumerate(lens):
+        x[i, l:] = 0
+    w = lstm_weights(I, H, 72)
+    xr = x.clone().requires_grad_(True)
+    wr = [t.clone().requires_grad_(True) for t in w]
+    yr = lo.bilstm_explicit(xr.transpose(0, 1), lens, wr).transpose(0, 1)
+    gy = rnd(N, S, 2 * H, seed=73)
+    (yr * gy).sum().backward()
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(t.float().to(dev())) for t in w])
+    holder = Holder()
+    flat = FlatParameters(holder)
+    flat.grad.zero_()
+    old = (_lib.set_option('SSASR_LAST_SEG_PCT', pct), _lib.set_option('SSASR_TAIL_INLINE', inline))
+    try:
+        xd = x.float().to(dev()).requires_grad_(want_dx)
+        ld = torch.tensor(lens, dtype=torch.int32, device=dev())
+        yd = ops.bilstm(xd, ld, S, True, list(holder.ps))
+        (yd * gy.float().to(dev())).sum().backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        ops.check_persistent_status()
+    finally:
+        _lib.set_option('SSASR_LAST_SEG_PCT', old[0])
+        _lib.set_option('SSASR_TAIL_INLINE', old[1])
+    if want_dx:
+        close(xd.grad, xr.grad, 5e-5, 'dx')
+    for name, a, b in zip(['w_ih', 'w_hh', 'b_ih', 'b_hh'] * 2, holder.ps, wr):
+        close(a.grad, b.grad, 3e-4, 'd' + name)
+
+
 def test_bilstm_sequence_major_no_lengths():
     """blstm_4 form: recurrence over dim 0, every column full length."""
     from ss_asr_amd import ops
