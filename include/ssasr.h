@@ -387,6 +387,25 @@ int ssasr_clip_adadelta(float* param, const float* grad, float* square_avg, floa
                         int64_t n, float grad_scale, float max_norm, float lr, float rho,
                         float eps, float* ws, float* stats, int zero_grad, void* stream);
 
+/* Solver.step with torch.optim.Adam as TAETrainer uses them (src/trainer.py:633-641: ONE Adam over the text
+ * autoencoder's parameters and the ASR model's embed / attention / decoder / char_trans; :676
+ * `self.step(self.text_autoenc.parameters(), self.optim)`: the norm that is clipped and tested for NaN
+ * is the text autoencoder's alone).  Parameters may therefore live in several flat buffers:
+ *   ssasr_adam_prepare  once per step, over the CLIPPED gradient range grad_clip[0 .. n_clip): L2 norm of
+ *     grad * grad_scale, NaN guard, clip coefficient; unless the step is skipped, advances the step count
+ *     state[0] (float[1], persistent, zero before the first step) and forms Adam's bias corrections.
+ *     ws: float[ssasr_adam_ws(n_clip)] scratch, read by the updates; stats: float[2] = {norm, skipped}.
+ *   ssasr_adam_update   per flat buffer: the Adam update (amsgrad off, no weight decay) of n values;
+ *     clipped != 0 multiplies the gradient by the clip coefficient * grad_scale (the clipped range),
+ *     else by grad_scale alone.  A skipped step changes nothing (optim.step() is not called for it).
+ *     zero_grad != 0 leaves grad zeroed, as for ssasr_clip_adadelta. */
+int64_t ssasr_adam_ws(int64_t n_clip);
+int ssasr_adam_prepare(const float* grad_clip, int64_t n_clip, float grad_scale, float max_norm, float lr,
+                       float beta1, float beta2, float* state, float* ws, float* stats, void* stream);
+int ssasr_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const float* ws, int clipped, float grad_scale, float beta1, float beta2, float eps,
+                      const float* stats, int zero_grad, void* stream);
+
 /* Frame lengths of zero-padded fbanks, prepare_x (src/ASRDataset.py:314):
  * lens[b] = number of frames whose feature sum is non-zero. */
 int ssasr_frame_lengths(const float* x, int64_t B, int64_t T, int64_t F, int32_t* lens,

@@ -332,6 +332,28 @@ def make_optimizer(model):
     return torch.optim.Adadelta(model.parameters(), lr=1.0, eps=1e-8)
 
 
+def make_tae_optimizer(tae, asr, lr=1e-4, kind='Adam'):
+    """TAETrainer.set_model, src/trainer.py:633-641 with conf/default.yaml:43-45: ONE optimizer over the
+    whole text autoencoder and the ASR model's embed / attention / decoder / char_trans (not its Listener)."""
+    params = (list(tae.parameters()) + list(asr.embed.parameters()) + list(asr.attention.parameters()) +
+              list(asr.decoder.parameters()) + list(asr.char_trans.parameters()))
+    return getattr(torch.optim, kind)(params, lr=lr, eps=1e-8)
+
+
+def tae_train_step(asr, tae, optim, y, y_noise):
+    """One iteration of TAETrainer.exec, src/trainer.py:652-677: decode for max(y_lens) steps, the loss of
+    :662-672, backward, then Solver.step on the TEXT AUTOENCODER's parameters -- so the norm that is
+    clipped (and tested for NaN) is the text autoencoder's alone, while the optimizer steps the shared
+    ASR parameters too.  Returns (loss, clipped-norm)."""
+    y_lens, noise_lens = label_lengths(y), label_lengths(y_noise)
+    optim.zero_grad()
+    _, logits = tae(asr, y, y_noise, max(y_lens), noise_lens=noise_lens)
+    loss = tae_loss(logits, y)
+    loss.backward()
+    norm, _ = solver_step(list(tae.parameters()), optim)
+    return float(loss.detach()), norm
+
+
 # --------------------------------------------------------------------------
 # explicit arithmetic (kernel-level oracle)
 # --------------------------------------------------------------------------

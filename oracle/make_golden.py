@@ -99,7 +99,12 @@ def capture(asr_mod, name, dims, lens, y_lens, tf_rate, seed, weights_seed=None,
     optim.step()                                                     # trainer.py:148
     sd1 = model.state_dict()
 
-    out = dict(dims=np.array(dims), tf_rate=np.float64(tf_rate), seed=np.int64(seed),
+    # the reference's own character accuracy (src/postprocess.py:7-29) on the first ans_len outputs, as
+    # ASRTrainer logs it (src/trainer.py:443) and valid() averages it (:486); calc_err needs the absent
+    # `editdistance` package and is not captured
+    import postprocess as ref_post                              # reference module (path set by import_reference)
+    acc = ref_post.calc_acc(logits[:, :ans_len], y[:, 1:ans_len + 1])
+    out = dict(dims=np.array(dims), tf_rate=np.float64(tf_rate), seed=np.int64(seed), acc=np.float64(acc),
                weights_seed=np.int64(-1 if weights_seed is None else weights_seed),
                teacher=np.int64(teacher), rng_seed=np.int64(seed + 7),
                y=y.numpy(), lens=np.array(lens), ans_len=np.int64(ans_len),
@@ -204,6 +209,94 @@ def capture_tae(asr_mod, tae_mod, name, dims, tae_dims, y_lens, tf_rate, seed, d
     print('%-18s loss %.6f  decode_step %d  %.1f KB' % (name, loss.item(), decode_step, os.path.getsize(path) / 1024))
 
 
+def ref_tae_step(tae, asr, optim, y, y_noise):
+    """The body of the reference's TAETrainer.exec (src/trainer.py:652-677) around the reference's own
+    TextAutoEncoder / ASR classes (TAETrainer itself needs tensorboardX and an index on disk)."""
+    y_l = [int(v) + 1 for v in (y != 0).sum(-1)]                 # prepare_y
+    noise_l = [int(v) + 1 for v in (y_noise != 0).sum(-1)]
+    optim.zero_grad()
+    _, logits = tae(asr, y, y_noise, max(y_l), noise_lens=noise_l)
+    metric = nn.CrossEntropyLoss(ignore_index=0, reduction='none')          # trainer.py:637-638
+    b, t, c = logits.shape
+    loss = metric(logits.view(b * t, c), y.view(-1))
+    loss = torch.mean(torch.sum(loss.view(b, t), dim=-1) / torch.sum(y != 0, dim=-1).to(torch.float32))
+    loss.backward()
+    grad_norm = nn.utils.clip_grad_norm_(tae.parameters(), 5)   # Solver.step(self.text_autoenc.parameters(), ...)
+    optim.step()
+    return float(loss.item()), float(grad_norm)
+
+
+def ref_tae_optimizer(tae, asr, lr):
+    # trainer.py:633-641 (conf/default.yaml:43-45: Adam, 1e-4)
+    return torch.optim.Adam(list(tae.parameters()) + list(asr.embed.parameters()) + list(asr.attention.parameters()) +
+                            list(asr.decoder.parameters()) + list(asr.char_trans.parameters()), lr=lr, eps=1e-8)
+
+
+def capture_tae_traj(asr_mod, tae_mod, name, dims, tae_dims, batches_y_lens, tf_rate, seed, lr=1e-4,
+                     asr_batches=None, drop_rate=0.2):
+    """A trajectory of TAETrainer steps on the real reference (config 5's first leg, src/trainer.py:594-758):
+    for every entry of `batches_y_lens` one TAE step (Adam over the text autoencoder + the ASR model's
+    embed / attention / decoder / char_trans; norm clipped over the text autoencoder only).  With
+    `asr_batches` (frame lengths, label lengths per round) an ASRTrainer step (src/trainer.py:415-438,
+    Adadelta over the whole ASR model) runs BEFORE each TAE step on the SAME ASR object: the two legs of
+    the Seed loop sharing parameters."""
+    seed_all(seed)
+    asr = asr_mod.ASR(*dims, tf_rate)
+    seeded_weights(asr, seed + 100)
+    tae = tae_mod.TextAutoEncoder(dims[0], *tae_dims)
+    seeded_tae_weights(tae, seed + 200)
+    tae_opt = ref_tae_optimizer(tae, asr, lr)
+    asr_opt = torch.optim.Adadelta(asr.parameters(), lr=1.0, eps=1e-8) if asr_batches else None
+    rng = np.random.default_rng(seed + 1000)
+    w0 = {('tae.' + k): v.clone() for k, v in tae.state_dict().items()}
+    w0.update({('asr.' + k): v.clone() for k, v in asr.state_dict().items()})
+    out = dict(dims=np.array(dims), tae_dims=np.array(tae_dims), tf_rate=np.float64(tf_rate), seed=np.int64(seed),
+               lr=np.float64(lr), asr_weights_seed=np.int64(seed + 100), tae_weights_seed=np.int64(seed + 200),
+               rounds=np.int64(len(batches_y_lens)), with_asr=np.int64(1 if asr_batches else 0))
+    tae_loss_l, tae_norm_l, asr_loss_l, asr_norm_l = [], [], [], []
+    for r, y_lens in enumerate(batches_y_lens):
+        if asr_batches:
+            lens, ylens = asr_batches[r]
+            x, ya = synth_batch(rng, lens, dims[4], ylens, dims[0])
+            ans_len = int(max((ya != 0).sum(-1) + 1)) - 1
+            asr_opt.zero_grad()
+            seed_all(seed + 7 + 2 * r)
+            _, logits, _ = asr(x, ans_len, teacher=ya, state_len=list(lens))
+            loss = ref_loss(logits, ya, ans_len)
+            loss.backward()
+            asr_norm_l.append(float(nn.utils.clip_grad_norm_(asr.parameters(), 5)))
+            asr_opt.step()
+            asr_loss_l.append(float(loss.item()))
+            out['asr_x%d' % r], out['asr_y%d' % r], out['asr_lens%d' % r] = x.numpy(), ya.numpy(), np.array(lens)
+        y, y_noise = noisy_text_batch(rng, y_lens, drop_rate, dims[0])
+        seed_all(seed + 8 + 2 * r)
+        l, n = ref_tae_step(tae, asr, tae_opt, y, y_noise)
+        tae_loss_l.append(l)
+        tae_norm_l.append(n)
+        out['y%d' % r], out['y_noise%d' % r] = y.numpy(), y_noise.numpy()
+        out['rng_seed%d' % r] = np.int64(seed + 8 + 2 * r)
+        out['asr_rng_seed%d' % r] = np.int64(seed + 7 + 2 * r)
+    out['tae_loss'], out['tae_norm'] = np.array(tae_loss_l), np.array(tae_norm_l)
+    if asr_batches:
+        out['asr_loss'], out['asr_norm'] = np.array(asr_loss_l), np.array(asr_norm_l)
+    w1 = {('tae.' + k): v for k, v in tae.state_dict().items()}
+    w1.update({('asr.' + k): v for k, v in asr.state_dict().items()})
+    names = sorted(w1)
+    out['param_names'] = np.array(names)
+    out['update_norms'] = np.array([(w1[k] - w0[k]).double().norm().item() for k in names])
+    small = sum(v.numel() for v in w1.values()) < 400000
+    for k in names:
+        if small:
+            out['w1/' + k] = w1[k].numpy()
+        else:
+            out['w1_head/' + k] = w1[k].reshape(-1)[:256].numpy()
+            out['dw_head/' + k] = (w1[k] - w0[k]).reshape(-1)[:256].numpy()
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-18s tae loss %s  norm %s  %.1f KB' % (name, np.round(tae_loss_l, 5), np.round(tae_norm_l, 5),
+                                                  os.path.getsize(path) / 1024))
+
+
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)
     asr_mod = import_reference()
@@ -246,6 +339,18 @@ def main(only=None):
     cap_tae('tae_full_b12', full, (128, 256, 2), [14, 12, 12, 11, 9, 9, 8, 6, 5, 5, 3, 2], 1.0, 31)
     cap_tae('tae_full_b40', full, (128, 256, 2), [3 + (7 * k) % 13 for k in range(40)], 1.0, 32)
     cap_tae('tae_small_tf05', small, (8, 32, 2), [10, 7, 5, 3, 3], 0.5, 33)
+    # config 5's first leg as a trainer (TAETrainer, src/trainer.py:594-758): three Adam steps at full layer
+    # sizes (12 rows: the persistent decode loop), and the two legs that this build has -- an ASRTrainer step
+    # and a TAETrainer step -- alternating on ONE shared ASR object, small model, all weights kept
+    if not only or 'tae_traj_full_b12' in only:
+        capture_tae_traj(asr_mod, tae_mod, 'tae_traj_full_b12', full, (128, 256, 2),
+                         [[14, 12, 12, 11, 9, 9, 8, 6, 5, 5, 3, 2], [13, 13, 10, 9, 9, 7, 7, 6, 4, 4, 3, 3],
+                          [15, 11, 10, 10, 8, 8, 6, 6, 5, 3, 2, 2]], 1.0, 41)
+    if not only or 'seed_alt_small' in only:
+        capture_tae_traj(asr_mod, tae_mod, 'seed_alt_small', small, (8, 32, 2),
+                         [[10, 7, 5, 3, 3], [9, 8, 4, 4, 2], [8, 8, 6, 3, 2]], 1.0, 42,
+                         asr_batches=[([64, 56, 48, 40], [10, 7, 5, 3]), ([72, 50, 33, 17], [9, 6, 4, 2]),
+                                      ([56, 56, 41, 24], [8, 8, 3, 5])])
     for name, pick, seed, wseed in (('bench_b32_t800', 0, 8, 14), ('bench_b32_median', 4, 9, 15)):
         x, y, lens = config2_batches(8, batch_size=32, feat_dim=80, seed=1)[pick]
         ylens = [int(v) - 1 for v in (y != 0).sum(-1)]

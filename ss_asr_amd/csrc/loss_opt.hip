@@ -156,6 +156,66 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* p, const float* g,
   }
 }
 
+// Adam, first half (one workgroup): clip coefficient and NaN guard of Solver.step over the partial sums of
+// the CLIPPED parameter range, then -- unless the step is skipped -- the step count and the bias corrections
+// of torch.optim.Adam.  ws[0] = clip coefficient * grad_scale, ws[1] = lr / (1 - beta1^t),
+// ws[2] = 1 / sqrt(1 - beta2^t); state[0] = t (persistent across steps; a skipped step does not count,
+// as optim.step() is not called for it: src/trainer.py:144-148).
+__global__ __launch_bounds__(256) void adam_prepare_kernel(float* ws, int nblk, float grad_scale, float max_norm,
+                                                           float lr, float beta1, float beta2, float* state,
+                                                           float* stats) {
+  __shared__ double sm[4];
+  double d = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) d += (double)ws[4 + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float total = (float)sqrt(sm[0] + sm[1] + sm[2] + sm[3]) * fabsf(grad_scale);
+    const bool bad = isnan(total);
+    float coef = max_norm / (total + 1e-6f);          // torch clip_grad_norm_
+    if (coef > 1.f) coef = 1.f;
+    ws[0] = bad ? 0.f : coef * grad_scale;
+    stats[0] = total;
+    stats[1] = bad ? 1.f : 0.f;
+    if (!bad) {
+      const double t = (double)state[0] + 1.0;
+      state[0] = (float)t;
+      ws[1] = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+      ws[2] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+    }
+  }
+}
+
+// torch.optim.Adam single-tensor update (amsgrad = False, weight_decay = 0):
+//   m += (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g;  p -= step_size * m / (sqrt(v) / sqrt(bc2) + eps)
+// `clipped`: the gradient is multiplied by ws[0] (clip coefficient * grad_scale), else by grad_scale alone --
+// the parameters OUTSIDE the range Solver.step clips are stepped with their gradient as it is.
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                   const float* ws, int clipped, float grad_scale, float beta1,
+                                                   float beta2, float eps, const float* stats, float* zero) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (stats[1] != 0.f) {                              // NaN guard: skip the step
+    if (zero)
+      for (int64_t j = i; j < n; j += stride) zero[j] = 0.f;
+    return;
+  }
+  const float mul = clipped ? ws[0] : grad_scale;
+  const float step_size = ws[1], inv_bc2_sqrt = ws[2];
+  for (int64_t j = i; j < n; j += stride) {
+    const float gr = g[j] * mul;
+    const float mo = m[j];
+    const float mn = mo + (1.f - beta1) * (gr - mo);
+    const float vn = v[j] * beta2 + (1.f - beta2) * gr * gr;
+    m[j] = mn;
+    v[j] = vn;
+    p[j] -= step_size * (mn / (sqrtf(vn) * inv_bc2_sqrt + eps));
+    if (zero) zero[j] = 0.f;                          // zero == g: the next step's zero_grad()
+  }
+}
+
 __global__ __launch_bounds__(256) void frame_len_kernel(const float* x, int T, int F, int32_t* lens) {
   __shared__ int sm[4];
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -238,6 +298,37 @@ extern "C" int ssasr_clip_adadelta(float* param, const float* grad, float* squar
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adadelta_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, square_avg, acc_delta,
                      n, ws, stats, lr, rho, eps, zero_grad ? const_cast<float*>(grad) : nullptr);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int64_t ssasr_adam_ws(int64_t n_clip) {
+  return 4 + (n_clip + NORM_PER_BLOCK - 1) / NORM_PER_BLOCK;
+}
+
+extern "C" int ssasr_adam_prepare(const float* grad_clip, int64_t n_clip, float grad_scale, float max_norm, float lr,
+                                  float beta1, float beta2, float* state, float* ws, float* stats, void* stream) {
+  if (!grad_clip || n_clip <= 0 || !state || !ws || !stats || !(beta1 >= 0.f && beta1 < 1.f) ||
+      !(beta2 >= 0.f && beta2 < 1.f))
+    return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)((n_clip + NORM_PER_BLOCK - 1) / NORM_PER_BLOCK);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(NORM_BLOCK), 0, st, grad_clip, n_clip, ws + 4);
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(256), 0, st, ws, nblk, grad_scale, max_norm, lr, beta1, beta2,
+                     state, stats);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 const float* ws, int clipped, float grad_scale, float beta1, float beta2, float eps,
+                                 const float* stats, int zero_grad, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !ws || !stats || n <= 0) return SSASR_EARG;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n, ws, clipped, grad_scale, beta1, beta2, eps, stats,
+                     zero_grad ? const_cast<float*>(grad) : nullptr);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }

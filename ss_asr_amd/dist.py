@@ -107,6 +107,12 @@ class GradReducer:
         if any(id(p) in ids for p in flat.params[len(ids):]) or n == 0 or n >= flat.numel:
             n = 0                      # head is not a proper prefix of the buffer: single collective
         self.flat, self.split = flat, n
+        # overlap: the tail's collective is issued on the second stream while the first layer's BPTT still
+        # runs (False, or SSASR_DDP_NO_OVERLAP in the environment: one collective after the backward pass);
+        # skip: no collective at all -- bench.py's attribution run ("the step with the reduce replaced by
+        # a no-op"), never a training mode
+        self.overlap = not os.environ.get('SSASR_DDP_NO_OVERLAP')
+        self.skip = False
         self.pending = None            # deferred tail gradients (data_ptr) still awaited this step
         self.learned = None            # the set of deferred tail gradients, observed in the first step
         self.seen = set()
@@ -116,7 +122,7 @@ class GradReducer:
         self.work = None
         self.seen = set()
         self.pending = None
-        if is_active() and self.split and self.learned and not os.environ.get('SSASR_DDP_NO_OVERLAP'):
+        if is_active() and self.split and self.learned and self.overlap and not self.skip:
             self.pending = set(self.learned)
 
     def wgrad_enqueued(self, sinks):
@@ -144,12 +150,21 @@ class GradReducer:
         else:
             self.work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
 
+    def buckets(self):
+        """Bytes of the collectives one step issues, in issue order."""
+        n = self.flat.grad.numel()
+        if self.split and self.overlap:
+            return [4 * (n - self.split), 4 * self.split]
+        return [4 * n]
+
     def finish(self):
         if not is_active():
             return 1.0
         if self.flat.grad.is_cuda:
             from . import ops
             ops.join_side_stream()
+        if self.skip:
+            return 1.0 / dist.get_world_size()
         if self.work is None:
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
         else:

@@ -6,7 +6,7 @@ import torch
 
 from . import dist as sdist
 from . import ops
-from .optim import FlatParameters, FusedAdadelta
+from .optim import FlatParameters, FusedAdadelta, FusedAdam
 
 
 class ASRTrainStep:
@@ -14,7 +14,7 @@ class ASRTrainStep:
         if not next(model.parameters()).is_cuda:
             raise RuntimeError('ASRTrainStep needs the model on the GPU (no CPU path)')
         self.model = model
-        self.flat = FlatParameters(model)
+        self.flat = FlatParameters.of(model)       # (a TAETrainStep over the same model may have made it already)
         sdist.broadcast_flat(self.flat.data)
         self.optim = FusedAdadelta(self.flat, lr=lr, rho=rho, eps=eps)
         self.grad_clip = grad_clip
@@ -22,7 +22,6 @@ class ASRTrainStep:
         self.reducer = sdist.GradReducer(self.flat, list(model.encoder.blstm_1.parameters()))
         ops.set_wgrad_listener(self.reducer.wgrad_enqueued)
         self._one = torch.ones((), device=self.flat.data.device)
-        self._grads_clean = False      # True right after a step that zeroed them in its update kernel
         self.last_logits = None        # [B, U, V] of the most recent step (for the trainer's logging)
         self.last_done = None          # (grad_norm, skipped) of the last step whose words have arrived
         self.skipped_steps = 0         # steps whose update was skipped because the gradient norm was NaN
@@ -43,9 +42,9 @@ class ASRTrainStep:
         # the weight-gradient listener is process-wide: claim it for THIS step object (several step
         # objects may alternate in one process -- the ASR and joint steps, the trainers of the Seed loop)
         ops.set_wgrad_listener(self.reducer.wgrad_enqueued)
-        if not self._grads_clean:
+        if not self.flat.clean:           # (True right after a step whose update kernel zeroed the gradients)
             self.optim.zero_grad()
-        self._grads_clean = False
+        self.flat.clean = False
         self.reducer.begin()
         # the attention map is only looked at by valid(): no device-to-host copy per train step
         keep, self.model.att_on_host = getattr(self.model, 'att_on_host', True), False
@@ -58,7 +57,7 @@ class ASRTrainStep:
             self.model.att_on_host = keep
         scale = self.reducer.finish()
         self.optim.clip_and_step(self.grad_clip, grad_scale=scale, zero_grad=True)
-        self._grads_clean = True
+        self.flat.clean = True
         return loss
 
     def _note(self, done):
@@ -70,6 +69,65 @@ class ASRTrainStep:
         """Waits for the last step's words: returns its (grad_norm, skipped); raises on a timeout."""
         self._note(self.optim.poll(wait=True))
         return self.last_done
+
+
+class TAETrainStep:
+    """One TAETrainer step (the body of TAETrainer.exec, src/trainer.py:652-677) as a reusable object: the
+    text autoencoder's forward through the shared attend-and-spell loop (text_autoencoder.py), the loss of
+    :662-672, backward, gradient all-reduce across ranks, then Solver.step as the reference calls it --
+    norm, NaN guard and clip over the TEXT AUTOENCODER's parameters only (:676), Adam (:633-641,
+    conf/default.yaml:43-45) over the text autoencoder AND the ASR model's embed / attention / decoder /
+    char_trans.  Those shared parameters stay where the ASR model's flat buffer has them (everything behind
+    the Listener is one run of it), so an ASRTrainStep and a TAETrainStep over the same ASR object train
+    the same storage, in turn: the two legs of the Seed loop (src/trainer.py:1126-1177) this build has."""
+
+    def __init__(self, asr_model, tae_model, lr=1e-4, eps=1e-8, grad_clip=5.0):
+        if not next(tae_model.parameters()).is_cuda or not next(asr_model.parameters()).is_cuda:
+            raise RuntimeError('TAETrainStep needs both models on the GPU (no CPU path)')
+        self.asr, self.tae = asr_model, tae_model
+        self.asr_flat = FlatParameters.of(asr_model)
+        self.tae_flat = FlatParameters.of(tae_model)
+        shared = (list(asr_model.attention.parameters()) + list(asr_model.decoder.parameters()) +
+                  list(asr_model.embed.parameters()) + list(asr_model.char_trans.parameters()))
+        self.lo, self.hi = self.asr_flat.range_of(shared)
+        sdist.broadcast_flat(self.tae_flat.data)
+        sdist.broadcast_flat(self.asr_flat.data)
+        self.optim = FusedAdam([(self.tae_flat.data, self.tae_flat.grad, True),
+                                (self.asr_flat.data[self.lo:self.hi], self.asr_flat.grad[self.lo:self.hi], False)],
+                               lr=lr, eps=eps)
+        self.grad_clip = grad_clip
+        self._one = torch.ones((), device=self.tae_flat.data.device)
+        self.last_logits = None
+        self.last_done = None
+        self.skipped_steps = 0
+
+    def forward_loss(self, y, y_noise, decode_step, noise_lens):
+        from .text_autoencoder import tae_loss
+        _, logits = self.tae(self.asr, y, y_noise, decode_step, noise_lens=noise_lens)
+        return tae_loss(logits, y), logits
+
+    def __call__(self, y, y_noise, y_lens, noise_lens):
+        """y [B, L] clean label rows, y_noise [B, <= L] noised rows (int64, on the GPU), their prepare_y
+        lengths.  Returns the loss tensor.  The previous step's verdict (norm, NaN skip, time-outs) is
+        picked up here without a synchronisation, as in ASRTrainStep."""
+        self._note(self.optim.poll())
+        ops.set_wgrad_listener(None)          # (an ASRTrainStep's reducer must not see this pass's gradients)
+        for flat in (self.tae_flat, self.asr_flat):
+            if not flat.clean:
+                flat.zero_grad()
+        self.tae_flat.clean = self.asr_flat.clean = False
+        with ops.shared_status_row(self.optim.status_row):
+            loss, self.last_logits = self.forward_loss(y, y_noise, max(y_lens), noise_lens)
+            loss.backward(self._one)
+        scale = sdist.allreduce_grad(self.tae_flat.grad)
+        sdist.allreduce_grad(self.asr_flat.grad[self.lo:self.hi])
+        self.optim.clip_and_step(self.grad_clip, grad_scale=scale, zero_grad=True)
+        # the Listener's gradients were never touched by this pass: the whole ASR buffer is clean again
+        self.tae_flat.clean = self.asr_flat.clean = True
+        return loss
+
+    _note = ASRTrainStep._note
+    finish = ASRTrainStep.finish
 
 
 def label_geometry(y_cpu):

@@ -1025,6 +1025,26 @@ def clip_adadelta_(param, grad, square_avg, acc_delta, ws, stats, grad_scale=1.0
                                   1 if zero_grad else 0, _stream()), 'ssasr_clip_adadelta')
 
 
+def adam_prepare(clip_grad, state_step, ws, stats, grad_scale=1.0, max_norm=5.0, lr=1e-4, betas=(0.9, 0.999)):
+    """First half of Solver.step + torch.optim.Adam on flat buffers (include/ssasr.h, ssasr_adam_prepare):
+    norm / NaN guard / clip coefficient over `clip_grad`, step count and bias corrections."""
+    lib = _lib.load()
+    _need_gpu(clip_grad, state_step, ws, stats)
+    check(lib.ssasr_adam_prepare(_p(clip_grad), clip_grad.numel(), grad_scale, float(max_norm), lr, betas[0], betas[1],
+                                 _p(state_step), _p(ws), _p(stats), _stream()), 'ssasr_adam_prepare')
+
+
+def adam_update_(param, grad, exp_avg, exp_avg_sq, ws, stats, clipped, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8,
+                 zero_grad=False):
+    """The Adam update of one flat buffer (ssasr_adam_update); `clipped`: this buffer is the range whose norm
+    adam_prepare clipped."""
+    lib = _lib.load()
+    _need_gpu(param, grad, exp_avg, exp_avg_sq, ws, stats)
+    check(lib.ssasr_adam_update(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(ws),
+                                1 if clipped else 0, grad_scale, betas[0], betas[1], eps, _p(stats),
+                                1 if zero_grad else 0, _stream()), 'ssasr_adam_update')
+
+
 def clip_adadelta_ws(n, device):
     lib = _lib.load()
     return torch.empty(int(lib.ssasr_clip_adadelta_ws(n)), device=device, dtype=torch.float32)

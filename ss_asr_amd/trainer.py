@@ -1,6 +1,6 @@
 """Solver / ASRTrainer with the surface of the reference's src/trainer.py
-(Solver :33-195, ASRTrainer :374-545) so that ``src/train.py`` drives it
-unchanged: ``getattr(trainer, 'ASRTrainer')(config, paras)`` then
+(Solver :33-195, ASRTrainer :374-545, TAETrainer :594-758, asr_seed_train :1126-1177) so that
+``src/train.py`` drives it unchanged: ``getattr(trainer, 'ASRTrainer')(config, paras)`` then
 ``load_data()``, ``set_model()``, ``exec()``.
 
 Differences, all inside the same call surface:
@@ -188,13 +188,18 @@ class ASRTrainer(Solver):
             (y, y_lens) = prepare_y(y, device=self.device)
             yield b_ind, x, x_lens, y, y_lens
 
-    def set_model(self):
+    def set_model(self, asrpath=None):
+        """asrpath (this build; the Seed loop passes it): (checkpoint to load, checkpoint to save) instead of
+        <ckpdir>/asr.cpt for both, as the other trainers of the reference take it (src/trainer.py:623)."""
+        if asrpath is not None:
+            self.ckppath_in, self.ckppath = self.genpath(asrpath, 'asr')
         # `ctc_weight` under asr.mdl is a key of this build (BASELINE.json configs[3], ss_asr_amd/ctc.py);
         # the reference's configs do not carry it and get the reference's model and loss
         joint = 'ctc_weight' in self.config['asr']['mdl']
         if joint:
             from .ctc import JointCTCASR, JointCTCTrainStep
-        self.asr_model = self.setup_module(JointCTCASR if joint else ASR, self.ckppath, self.mapper.get_dim(),
+        self.asr_model = self.setup_module(JointCTCASR if joint else ASR, getattr(self, 'ckppath_in', self.ckppath),
+                                           self.mapper.get_dim(),
                                            **self.config['asr']['mdl'])
         opt = self.config['asr']['opt']
         self.train_step = None
@@ -327,3 +332,177 @@ class ASRTrainer(Solver):
             self.train_step.finish()
         if self.rank == 0:
             torch.save(self.asr_model.state_dict(), self.ckppath)
+
+
+class TAETrainer(Solver):
+    """Trains the text autoencoder, and through it the ASR model's attention / speller / embedding /
+    char_trans (src/trainer.py:594-758; config 5's first leg).  With Adam (conf/default.yaml:43-45) on the
+    GPU one iteration of exec() is ONE engine.TAETrainStep call; any other optimizer type takes the
+    reference's sequence (zero_grad, forward, backward, Solver.step over the text autoencoder's parameters)."""
+
+    def __init__(self, config, paras):
+        super().__init__(config, paras, 'tae')
+
+    def load_data(self):
+        """Text only, with noise: the loaders yield (clean_y, noised_y) (src/trainer.py:601-614)."""
+        (self.mapper, self.dataset, self.train_set) = load_asr_dataset(
+            self.config['tae']['train_index'], batch_size=self.train_batch_size, use_gpu=self.paras.gpu,
+            text_only=True, drop_rate=self.config['tae']['drop_rate'],
+            n_jobs=self.set_if_exists('loader_jobs', 8))
+        (_, _, self.valid_set) = load_asr_dataset(
+            self.config['tae']['valid_index'], batch_size=self.valid_batch_size, use_gpu=self.paras.gpu,
+            text_only=True, drop_rate=self.config['tae']['drop_rate'],
+            n_jobs=self.set_if_exists('loader_jobs', 8))
+
+    def set_model(self, asrpath=None, asr_model=None):
+        """src/trainer.py:616-644.  asr_model (this build): an ASR object that is already in memory -- the
+        Seed loop's legs then train the SAME parameters in turn without going through a checkpoint."""
+        from .text_autoencoder import TextAutoEncoder
+        (self.asrpath_in, self.asrpath_out) = self.genpath(asrpath, 'asr')
+        self.asr_model = asr_model if asr_model is not None else self.setup_module(
+            ASR, self.asrpath_in, self.mapper.get_dim(), **self.config['asr']['mdl'])
+        self.text_autoenc = self.setup_module(TextAutoEncoder, self.ckppath, self.mapper.get_dim(),
+                                              **self.config['tae']['mdl'])
+        opt = self.config['tae']['opt']
+        self.train_step = None
+        if opt['type'] == 'Adam' and self.device.type == 'cuda':
+            from .engine import TAETrainStep
+            self.train_step = TAETrainStep(self.asr_model, self.text_autoenc, lr=opt['learning_rate'], eps=1e-8,
+                                           grad_clip=5.0)
+            self.optim = self.train_step.optim
+        else:
+            # the optimizer steps the text autoencoder, the ASR character embedding, attention module,
+            # speller and char_trans layer (src/trainer.py:625-641)
+            self.optim = getattr(torch.optim, opt['type'])(
+                list(self.text_autoenc.parameters()) + list(self.asr_model.embed.parameters()) +
+                list(self.asr_model.attention.parameters()) + list(self.asr_model.decoder.parameters()) +
+                list(self.asr_model.char_trans.parameters()), lr=opt['learning_rate'], eps=1e-8)
+
+    def _loss(self, enc_out, y):
+        """src/trainer.py:662-672."""
+        from .text_autoencoder import tae_loss
+        if not enc_out.is_cuda:
+            raise RuntimeError('ss_asr_amd computes on the GPU only')
+        return tae_loss(enc_out, y)
+
+    def _rank_batches(self):
+        from .gpu_loader import rank_batches
+        mine = set(rank_batches(len(self.train_set), self.rank, self.world))
+        for b_ind, (y, y_noise) in enumerate(self.train_set):
+            if b_ind in mine:
+                yield b_ind, y, y_noise
+
+    def exec(self):
+        self.verbose('Training set total {} batches'.format(len(self.train_set)))
+        nan_reported = self.train_step.skipped_steps if self.train_step is not None else 0
+        epoch = 0
+        while epoch < self.n_epochs:
+            self.verbose("Starting epoch {} out of {}".format(epoch + 1, self.n_epochs))
+            for b_ind, y, y_noise in self._rank_batches():
+                self.verbose('Batch: {}/{}, global step: {}'.format(
+                    b_ind, len(self.train_set), self.tr.step), progress=True)
+                y, y_lens = prepare_y(y, device=self.device)
+                y_noise, y_noise_lens = prepare_y(y_noise, device=self.device)
+                if self.train_step is not None:
+                    loss = self.train_step(y, y_noise, y_lens, y_noise_lens)
+                    if self.train_step.skipped_steps > nan_reported:
+                        nan_reported = self.train_step.skipped_steps
+                        self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+                else:
+                    self.optim.zero_grad()
+                    # decode steps == longest target
+                    _, enc_out = self.text_autoenc(self.asr_model, y, y_noise, max(y_lens), noise_lens=y_noise_lens)
+                    loss = self._loss(enc_out, y)
+                    loss.backward()
+                    self.step(self.text_autoenc.parameters(), self.optim)
+                    if self.tr.step % self.logging_step == 0:
+                        ops.check_persistent_status()
+                if self.rank == 0 and self.tr.step % self.logging_step == 0:
+                    self.lg.scalar('train_loss', loss.item(), self.tr.step)
+                if self.tr.step % self.valid_step == 0:
+                    self.valid()
+                if self.rank == 0 and self.tr.step % self.save_step == 0:
+                    if self.train_step is not None:
+                        self.train_step.finish()       # never checkpoint after a time-out
+                    self.verbose("Model saved at step {}".format(self.tr.step))
+                    torch.save(self.text_autoenc.state_dict(), self.ckppath)
+                    torch.save(self.asr_model.state_dict(), self.asrpath_out)
+                self.tr.do_step()
+            epoch += 1
+        if self.train_step is not None:
+            self.train_step.finish()
+
+    def valid(self):
+        """src/trainer.py:683-748."""
+        self.text_autoenc.eval()
+        self.asr_model.eval()
+        total, n_batches = 0.0, 0
+        y = enc_out = None
+        with torch.no_grad():
+            for b_idx, (y, y_noise) in enumerate(self.valid_set):
+                self.verbose('Validation step -( {} / {} )'.format(b_idx, len(self.valid_set)), progress=True)
+                y, y_lens = prepare_y(y, device=self.device)
+                y_noise, y_noise_lens = prepare_y(y_noise, device=self.device)
+                _, enc_out = self.text_autoenc(self.asr_model, y, y_noise, max(y_lens), noise_lens=y_noise_lens)
+                total += float(self._loss(enc_out, y))
+                n_batches += 1
+        ops.check_persistent_status()
+        self.text_autoenc.train()
+        self.asr_model.train()
+        if n_batches == 0:
+            return
+        avg_loss = total / n_batches
+        if self.rank != 0:
+            return
+        # compare the strings of the last batch
+        labels = [self.mapper.translate(l) for l in y.cpu()]
+        predicts = [self.mapper.translate(p) for p in np.argmax(enc_out.cpu().numpy(), axis=-1)]
+        for i in range(min(self.valid_batch_size, len(labels))):
+            self.lg.text('eval_text' + str(i), '{} |vs.| {}'.format(labels[i], predicts[i]), self.tr.step)
+        self.lg.scalar('eval_loss', avg_loss, self.tr.step)
+        if avg_loss < self.tr.get_best():
+            self.tr.set_best(avg_loss)
+            self.verbose('Best validation loss : {:.4f} @ global step {}'.format(self.tr.get_best(), self.tr.step))
+            torch.save(self.text_autoenc.state_dict(), self.best_ckppath)
+            self.verbose("Both the text autoencoder and ASR have been saved")
+        else:
+            self.verbose("Validation metric worse : ({:.4f} vs. {:.4f})".format(avg_loss, self.tr.get_best()))
+
+    def close(self):
+        self.verbose("Finished training! The most recent model will" +
+                     "be saved at step {} as well as the ASR model".format(self.tr.step))
+        if getattr(self, 'train_step', None) is not None:
+            self.train_step.finish()
+        if self.rank == 0:
+            torch.save(self.text_autoenc.state_dict(), self.ckppath)
+            torch.save(self.asr_model.state_dict(), self.asrpath_out)
+
+
+def asr_seed_train(config, paras):
+    """The Seed loop, src/trainer.py:1126-1177 (`train.py Seed`): `seed_train.its` super-iterations in which
+    several trainers take turns on ONE ASR model, handed from leg to leg through the checkpoint chain
+    asr_1.cpt -> ... under <ckpdir>/<name>/.  The reference's legs are TAETrainer -> ADVTrainer -> SAETrainer;
+    ADVTrainer's Discriminator and SAETrainer's SpeechAutoEncoder (CNN + batch norm) are outside this build's
+    scope, so the legs here are the two whose arithmetic runs on the kernels:
+    `seed_train.legs` (default ['tae', 'asr']) -- the text-autoencoder leg, which trains the shared attention /
+    speller, then the supervised ASRTrainer leg on the same checkpoint.  Naming 'adv' or 'sae' raises."""
+    ckpdir = os.path.join(paras.ckpdir, paras.name)
+    legs = config['seed_train'].get('legs', ['tae', 'asr'])
+    chain = os.path.join(ckpdir, 'asr_1.cpt')
+    for i in range(config['seed_train']['its']):
+        print('Starting Super Iteration {}'.format(i + 1))
+        for leg in legs:
+            if leg == 'tae':
+                print('Starting TAE training')
+                solver = TAETrainer(config, paras)
+            elif leg == 'asr':
+                print('Starting ASR training')
+                solver = ASRTrainer(config, paras)
+            else:
+                raise NotImplementedError("seed_train leg %r: ADVTrainer / SAETrainer (Discriminator, SpeechAutoEncoder) "
+                                          "are out of this build's scope (SURVEY.md section 2 rows 15-16)" % (leg,))
+            solver.load_data()
+            solver.set_model(asrpath=(chain, chain))
+            solver.exec()
+            solver.close()
+            del solver

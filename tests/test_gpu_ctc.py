@@ -204,6 +204,7 @@ def test_joint_step_at_config4_full_size_matches_the_oracle_fixture(golden):
     for k in fx.files:
         if k.startswith('g_head/'):
             np.testing.assert_allclose(grads[k[7:]].reshape(-1)[:256].cpu().numpy(), fx[k], atol=2e-5, rtol=0, err_msg=k)
-        if k.startswith('w1_head/'):
-            np.testing.assert_allclose(params[k[8:]].detach().reshape(-1)[:256].cpu().numpy(), fx[k], atol=1e-4,
-                                       rtol=0, err_msg=k)
+        if k.startswith('w1_head/'):       # an Adadelta first update is <= 3.2e-4 per element: 3e-6 = 1 % of it
+            got_w = params[k[8:]].detach().reshape(-1)[:256].cpu().numpy()
+            print('max abs post-step weight error %s: %.3g' % (k, float(np.abs(got_w - fx[k]).max())))
+            np.testing.assert_allclose(got_w, fx[k], atol=3e-6, rtol=0, err_msg=k)

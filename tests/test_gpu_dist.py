@@ -56,10 +56,12 @@ sdist.shutdown()
 '''
 
 
-def _run(single):
+def _run(single, no_overlap=False):
     env = dict(os.environ)
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND'):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND', 'SSASR_DDP_NO_OVERLAP'):
         env.pop(k, None)
+    if no_overlap:
+        env['SSASR_DDP_NO_OVERLAP'] = '1'
     if single:
         with socket.socket() as s:
             s.bind(('127.0.0.1', 0))
@@ -87,6 +89,53 @@ def test_rccl_single_rank_train_steps_equal_the_plain_run():
     assert max(abs(a - b) for a, b in zip(rccl['losses'], plain['losses'])) < 1e-5
     assert abs(rccl['norm'] - plain['norm']) < 1e-5 * max(1.0, plain['norm'])
     assert abs(rccl['wsum'] - plain['wsum']) < 1e-6 * plain['wsum']
+    # the other mode (SSASR_DDP_NO_OVERLAP=1, what bench.py falls back to after a persistent time-out): ONE
+    # collective over the whole buffer after every backward pass, same results
+    late = _run(True, no_overlap=True)
+    assert late['active'] and late['calls'] == [n, n, n], late['calls']
+    assert max(abs(a - b) for a, b in zip(late['losses'], plain['losses'])) < 1e-5
+    assert abs(late['wsum'] - plain['wsum']) < 1e-6 * plain['wsum']
+
+
+def _bench(extra_env, *flags):
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_BACKEND', 'SSASR_DDP_NO_OVERLAP', 'SSASR_DDP_FALLBACK'):
+        env.pop(k, None)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env.update(SSASR_DIST_SINGLE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), **extra_env)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-roofline',
+                          '--no-config4', '--no-cpu-baseline', '--no-epoch'] + list(flags), env=env, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0]), res.stderr
+
+
+@pytest.mark.timeout(1200)
+def test_bench_falls_back_to_the_late_all_reduce_after_a_persistent_time_out():
+    """the first multi-rank run must not be able to come back empty.  bench.py on a one-rank
+    RCCL process group (SSASR_DIST_SINGLE=1: the collective path is on) with a REAL missing producer injected
+    for as long as the overlapped two-bucket mode is selected: (a) the rank catches the time-out its status row
+    reports, every rank switches to one collective after the backward pass, the region is repeated and the
+    line says which mode produced the number; (b) when the ranks die of the time-out instead, the parent --
+    which never touches a GPU -- starts ONE fresh set of ranks with SSASR_DDP_NO_OVERLAP=1.  Both lines carry
+    the collective's self-description."""
+    clean, _ = _bench({})
+    assert clean['config']['ddp_overlap'] is True and clean['config']['ddp_fallback'] is None
+    col = clean['collective']
+    assert col['backend'] == 'nccl' and col['world_size'] == 1 and col['bytes_per_step'] == sum(col['buckets'])
+    assert len(col['buckets']) == 2 and col['allreduce_alone_ms']['reps'] == 20 and col['ms_per_step_without_reduce'] > 0
+    inproc, err = _bench({'SSASR_TEST_DROP_TILE_IF_OVERLAP': '3'})
+    assert inproc['config']['ddp_overlap'] is False and inproc['config']['ddp_fallback'].startswith('in-process'), inproc['config']
+    assert 'timed out' in err and inproc['collective']['buckets'] == [inproc['collective']['bytes_per_step']]
+    # (the timed-out steps were NaN-skipped by the optimizer kernel: the weights survive them)
+    assert inproc['value'] > 0 and abs(inproc['final_loss'] - clean['final_loss']) < 0.5
+    parent, err = _bench({'SSASR_TEST_DROP_TILE_IF_OVERLAP': '3', 'SSASR_TEST_BENCH_DIE_ON_TIMEOUT': '1'}, '--self-launch')
+    assert parent['config']['ddp_overlap'] is False and parent['config']['ddp_fallback'] == 'parent', parent['config']
+    assert err.count('starting 1 ranks') == 2 and 'starting fresh ranks with SSASR_DDP_NO_OVERLAP=1' in err
 
 
 # ---- two ranks on the one GPU, gloo between them, the REAL train step (SURVEY.md 8e) -------------
@@ -153,7 +202,7 @@ for k in mine:
     losses.append(float(step(x.cuda(), y.cuda(), lens, ans_len)))
 norm, skipped = step.finish()
 report(m, rank=rank, mine=mine, losses=losses, norm=norm, skipped=bool(skipped), split=step.reducer.split,
-       overlapped=bool(step.reducer.learned))
+       overlapped=bool(step.reducer.learned) and step.reducer.overlap)
 sdist.shutdown()
 '''
 
@@ -199,9 +248,10 @@ def _result(proc, timeout):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_on_one_gpu_follow_the_section_8e_statement_on_the_real_step(tmp_path):
+@pytest.mark.parametrize('overlap', [True, False])
+def test_two_ranks_on_one_gpu_follow_the_section_8e_statement_on_the_real_step(tmp_path, overlap):
     base = dict(os.environ)
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND'):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND', 'SSASR_DDP_NO_OVERLAP'):
         base.pop(k, None)
     single = _result(_child(DDP_SINGLE, base), 420)
     with socket.socket() as s:
@@ -212,6 +262,8 @@ def test_two_ranks_on_one_gpu_follow_the_section_8e_statement_on_the_real_step(t
     for r in range(2):
         env = dict(base, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), SSASR_DIST_BACKEND='gloo', SSASR_TEST_LOCK=lock)
+        if not overlap:
+            env['SSASR_DDP_NO_OVERLAP'] = '1'          # the mode bench.py falls back to
         procs.append(_child(DDP_RANK, env))
     try:
         ranks = [_result(p, 600) for p in procs]
@@ -225,7 +277,8 @@ def test_two_ranks_on_one_gpu_follow_the_section_8e_statement_on_the_real_step(t
     assert not single['skipped'] and not any(d['skipped'] for d in ranks)
     # the second step went through the two-bucket path: the tail of the flat gradient reduced on the second
     # stream while the first layer's BPTT ran, the head after the backward pass
-    assert all(d['overlapped'] and d['split'] > 0 for d in ranks)
+    # (or, overlap off, through one collective after the backward pass: same arithmetic)
+    assert all(d['overlapped'] == overlap and d['split'] > 0 for d in ranks)
     # rank-local loss == the single-process loss on that local batch (step 2: from the weights both ranks hold
     # after the first averaged update)
     for r in range(2):

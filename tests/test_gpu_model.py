@@ -22,6 +22,8 @@ BENCH_SHAPES = ['bench_b32_t800', 'bench_b32_median']
 # decode steps), 3000 / 1500 / 750 persistent recurrence steps with the exchange ring wrapping ~370 times
 LONG_SHAPES = ['long_b32_t3000']
 GRAD_NORM_RTOL = 2e-5      # measured on MI355X (round 3): <= 3.3e-6 on every fixture
+W1_ATOL = 3e-6             # post-step weights, absolute (an Adadelta first update is <= 3.2e-4 per element)
+UPDATE_NORM_RTOL = 2e-4    # per-tensor norm of the first update
 
 
 def build(fx):
@@ -78,6 +80,15 @@ def test_forward_matches_reference(golden, name):
     np.testing.assert_allclose(fixture_att(fx, att.numpy()), fx['att'], atol=2e-6, rtol=0)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), fx['logits'], atol=5e-5, rtol=0)
     assert abs(float(loss) - float(fx['loss'])) < 1e-4
+    if 'acc' in fx.files:
+        # the validation metric itself (north star: "loss/CER within 1e-3"): the reference's calc_acc on the
+        # reference's logits (captured through oracle/ref_harness.py) against the product's on the GPU's logits
+        from ss_asr_amd.postprocess import calc_acc
+        ans_len = int(fx['ans_len'])
+        label = torch.from_numpy(fx['y'])[:, 1:ans_len + 1]
+        acc = calc_acc(logits[:, :ans_len], label)
+        print('acc %s: %.6f (reference %.6f)' % (name, acc, float(fx['acc'])))
+        assert abs(acc - float(fx['acc'])) < 1e-3
 
 
 @pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'full_b4',
@@ -111,18 +122,25 @@ def test_backward_and_solver_step_match_reference(golden, name):
     norm, skipped = optim.poll(wait=True)
     assert not skipped and abs(norm - float(fx['grad_norm'])) < 1e-4
     upd = np.array([(params[n].detach() - before[n]).double().norm().item() for n in names])
-    np.testing.assert_allclose(upd, fx['update_norms'], rtol=2e-3, atol=1e-6)
-    checked = 0
+    # The first Adadelta update is at most sqrt(eps / 0.1) = 3.2e-4 per element, so the post-step weights are
+    # held to W1_ATOL = 3e-6 absolute (1 % of an update; VERDICT r3: 1e-4 passed an update that is 30 % wrong)
+    # and the per-tensor update norms to UPDATE_NORM_RTOL; measured maxima are printed.
+    np.testing.assert_allclose(upd, fx['update_norms'], rtol=UPDATE_NORM_RTOL, atol=1e-7)
+    print('max rel update-norm error %s: %.3g' % (name, np.max(np.abs(upd - fx['update_norms']) / np.maximum(fx['update_norms'], 1e-7))))
+    checked, worst = 0, 0.0
     for k in fx.files:
         if k.startswith('w1/'):
-            np.testing.assert_allclose(params[k[3:]].detach().cpu().numpy(), fx[k], atol=1e-4,
-                                       rtol=0, err_msg=k)
+            got_w = params[k[3:]].detach().cpu().numpy()
+            worst = max(worst, float(np.abs(got_w - fx[k]).max()))
+            np.testing.assert_allclose(got_w, fx[k], atol=W1_ATOL, rtol=0, err_msg=k)
             checked += 1
         if k.startswith('w1_head/'):       # compact fixtures: the first 256 post-step weights of selected tensors
-            np.testing.assert_allclose(params[k[8:]].detach().reshape(-1)[:256].cpu().numpy(), fx[k], atol=1e-4,
-                                       rtol=0, err_msg=k)
+            got_w = params[k[8:]].detach().reshape(-1)[:256].cpu().numpy()
+            worst = max(worst, float(np.abs(got_w - fx[k]).max()))
+            np.testing.assert_allclose(got_w, fx[k], atol=W1_ATOL, rtol=0, err_msg=k)
             checked += 1
     assert checked > 0, 'fixture %s holds no post-step weights' % name
+    print('max abs post-step weight error %s: %.3g' % (name, worst))
 
 
 def test_backward_matches_reference_on_the_fp32_mfma_instruction(golden):
@@ -141,7 +159,7 @@ def test_backward_matches_reference_on_the_fp32_mfma_instruction(golden):
         params = dict(model.named_parameters())
         names = [str(n) for n in fx['param_names']]
         got = np.array([params[n].grad.double().norm().item() for n in names])
-        np.testing.assert_allclose(got, fx['grad_norms'], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(got, fx['grad_norms'], rtol=GRAD_NORM_RTOL, atol=1e-6)
     finally:
         _lib.set_option('SSASR_GEMM_X6', old)
 
@@ -232,10 +250,13 @@ def test_sampled_steps_follow_the_categorical_law():
     assert abs(rate - probs[top].item()) < 0.25
 
 
-@pytest.mark.parametrize('dims,frames,chars', [
-    ((50, 256, 256, 128, 80), [168, 160, 152, 120, 96, 90, 64, 40], [14, 12, 12, 9, 8, 7, 5, 3]),   # persistent loop
-    ((50, 32, 32, 16, 12), [64, 56, 48, 40], [10, 7, 5, 3])])                                     # per-step kernels
-def test_sampled_steps_match_the_oracle_draw(dims, frames, chars):
+@pytest.mark.parametrize('dims,frames,chars,tf', [
+    ((50, 256, 256, 128, 80), [168, 160, 152, 120, 96, 90, 64, 40], [14, 12, 12, 9, 8, 7, 5, 3], 0.5),   # persistent loop
+    ((50, 32, 32, 16, 12), [64, 56, 48, 40], [10, 7, 5, 3], 0.5),                                      # per-step kernels
+    # BASELINE.json configs[1] at its own size and teacher-forcing rate: bench.py's longest bucket (32 x 800
+    # frames, 81 label steps) at tf_rate 0.9 -- the goldens of that shape are teacher forced
+    ((50, 256, 256, 128, 80), 'bench_b32_t800', None, 0.9)])
+def test_sampled_steps_match_the_oracle_draw(dims, frames, chars, tf):
     """The sampled branch of the decode loop (src/asr.py:94-98) against the oracle.  The kernel
     draws by inverse CDF from caller-visible uniforms, so every draw can be checked exactly: the
     oracle replays the loop on the characters the kernel fed (forced_chars), and for every
@@ -247,12 +268,18 @@ def test_sampled_steps_match_the_oracle_draw(dims, frames, chars):
     from ss_asr_amd.asr import ASR
     from ss_asr_amd.optim import FlatParameters
     from ss_asr_amd.synthetic import make_batch
-    x, y, lens = make_batch(np.array(frames), np.array(chars), dims[4], seed=17)
+    if isinstance(frames, str):
+        from ss_asr_amd.synthetic import config2_batches
+        x, y, lens = config2_batches(8, batch_size=32, feat_dim=dims[4], seed=1)[0]
+        frames = lens
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+    else:
+        x, y, lens = make_batch(np.array(frames), np.array(chars), dims[4], seed=17)
     ans_len = max(lo.label_lengths(y)) - 1
     torch.manual_seed(0)
-    ref = lo.OracleASR(*dims, 0.5)
+    ref = lo.OracleASR(*dims, tf)
     lo.seeded_weights(ref, 31)
-    model = ASR(*dims, 0.5)
+    model = ASR(*dims, tf)
     lo.seeded_weights(model, 31)
     model = model.to('cuda:0')
     flat = FlatParameters(model)
@@ -267,7 +294,7 @@ def test_sampled_steps_match_the_oracle_draw(dims, frames, chars):
     ops.check_persistent_status()
     modes = list(model.last_modes)
     random.seed(123)
-    assert modes == [0 if random.random() <= 0.5 else 1 for _ in range(ans_len)]   # the reference's coin flips
+    assert modes == [0 if random.random() <= tf else 1 for _ in range(ans_len)]   # the reference's coin flips
     assert 1 in modes and 0 in modes
     fed = model.last_chars.cpu().long()                     # [U + 1, B]
     uni = model.last_uniforms.cpu().numpy()                 # [U, B]
@@ -295,7 +322,8 @@ def test_sampled_steps_match_the_oracle_draw(dims, frames, chars):
     assert abs(float(loss) - float(ref_loss)) < 1e-4
     got = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())).item()
     want = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ref.parameters())).item()
-    assert abs(got - want) < 1e-3 * max(1.0, want), (got, want)
+    print('sampled pass: global grad norm %.6f (oracle %.6f)' % (got, want))
+    assert abs(got - want) < GRAD_NORM_RTOL * max(1.0, want), (got, want)
 
 
 def test_persistent_decode_loop_equals_multi_launch_loop():
@@ -697,7 +725,8 @@ def test_text_autoencoder_on_the_kernels_matches_reference(golden, name):
     names = [str(n) for n in fx['grad_names']]
     assert sorted(grads) == names                                    # the Listener gets no gradient
     got = np.array([grads[k].double().norm().item() for k in names])
-    np.testing.assert_allclose(got, fx['grad_norms'], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(got, fx['grad_norms'], rtol=GRAD_NORM_RTOL, atol=1e-6)
+    print('max rel grad-norm error %s: %.3g' % (name, np.max(np.abs(got - fx['grad_norms']) / np.maximum(fx['grad_norms'], 1e-6))))
     for k in fx.files:
         if k.startswith('g_head/'):
             np.testing.assert_allclose(grads[k[7:]].reshape(-1)[:256].cpu().numpy(), fx[k], atol=2e-5, rtol=0,

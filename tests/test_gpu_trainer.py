@@ -232,3 +232,149 @@ def test_corpus_built_from_waveforms_by_the_gpu_frontend_trains_a_step():
     loss = float(step(x, y, x_lens, max(y_lens) - 1))
     norm, skipped = step.finish()
     assert np.isfinite(loss) and np.isfinite(norm) and not skipped and 1.0 < loss < 10.0
+
+
+# ------------------------------------------------- config 5: the TAE leg as a trainer ----
+def _tae_pair(fx):
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.text_autoencoder import TextAutoEncoder
+    dims = [int(v) for v in fx['dims']]
+    torch.manual_seed(0)
+    asr = ASR(*dims, float(fx['tf_rate']))
+    lo.seeded_weights(asr, int(fx['asr_weights_seed']))
+    tae = TextAutoEncoder(dims[0], *[int(v) for v in fx['tae_dims']])
+    lo.seeded_tae_weights(tae, int(fx['tae_weights_seed']))
+    return asr.to('cuda:0'), tae.to('cuda:0')
+
+
+def _check_final_weights(fx, asr, tae, w0, atol):
+    w1 = {('tae.' + k): v.detach().cpu() for k, v in tae.state_dict().items()}
+    w1.update({('asr.' + k): v.detach().cpu() for k, v in asr.state_dict().items()})
+    names = [str(n) for n in fx['param_names']]
+    assert sorted(w1) == names
+    upd = np.array([(w1[k] - w0[k]).double().norm().item() for k in names])
+    rel = np.abs(upd - fx['update_norms']) / np.maximum(fx['update_norms'], 1e-9)
+    print('max rel update-norm error: %.3g (%s)' % (rel.max(), names[int(rel.argmax())]))
+    np.testing.assert_allclose(upd, fx['update_norms'], rtol=2e-4, atol=1e-8)
+    worst = 0.0
+    for k in fx.files:
+        if k.startswith('w1/'):
+            got, want = w1[k[3:]].numpy(), fx[k]
+        elif k.startswith('w1_head/'):
+            got, want = w1[k[8:]].reshape(-1)[:256].numpy(), fx[k]
+        else:
+            continue
+        worst = max(worst, float(np.abs(got - want).max()))
+        np.testing.assert_allclose(got, want, atol=atol, rtol=0, err_msg=k)
+    print('max abs final-weight error: %.3g' % worst)
+
+
+def test_tae_train_steps_follow_the_reference_trajectory(golden):
+    """Config 5's first leg as a TRAINER (src/trainer.py:594-758): three engine.TAETrainStep calls at the full
+    layer sizes against the trajectory captured from the reference's TextAutoEncoder + ASR classes with
+    TAETrainer's loss, Solver.step over the text autoencoder's parameters and Adam(1e-4) over the text
+    autoencoder and the shared ASR decoder half: every step's loss and clipped norm, the per-tensor norms of
+    the total update and the first 256 final weights of every tensor (an Adam step moves a weight by
+    ~1e-4: they are held to 1e-6)."""
+    from ss_asr_amd.engine import TAETrainStep
+    fx = golden('tae_traj_full_b12')
+    asr, tae = _tae_pair(fx)
+    w0 = {('tae.' + k): v.detach().cpu().clone() for k, v in tae.state_dict().items()}
+    w0.update({('asr.' + k): v.detach().cpu().clone() for k, v in asr.state_dict().items()})
+    step = TAETrainStep(asr, tae, lr=float(fx['lr']))
+    for r in range(int(fx['rounds'])):
+        y, y_noise = torch.from_numpy(fx['y%d' % r]), torch.from_numpy(fx['y_noise%d' % r])
+        random.seed(int(fx['rng_seed%d' % r]))
+        loss = float(step(y.cuda(), y_noise.cuda(), lo.label_lengths(y), lo.label_lengths(y_noise)))
+        norm, skipped = step.finish()
+        assert not skipped
+        print('tae step %d: loss %.6f (reference %.6f), norm %.6f (%.6f)' % (r, loss, fx['tae_loss'][r], norm, fx['tae_norm'][r]))
+        assert abs(loss - float(fx['tae_loss'][r])) < 1e-4
+        assert abs(norm - float(fx['tae_norm'][r])) < 2e-5 * max(1.0, norm)
+    # the Listener got no gradient and no update
+    for n, p in asr.named_parameters():
+        if n.startswith('encoder.'):
+            assert torch.equal(p.detach().cpu(), w0['asr.' + n]), n
+    _check_final_weights(fx, asr, tae, w0, atol=1e-6)
+
+
+def test_asr_and_tae_steps_alternate_on_one_shared_asr_object(golden):
+    """The two legs of the Seed loop that this build has (src/trainer.py:1126-1177), on ONE ASR object: three
+    rounds of (engine.ASRTrainStep -- Adadelta over the whole ASR model; engine.TAETrainStep -- Adam over the
+    text autoencoder and the ASR model's attention / speller / embed / char_trans, which live in the ASR
+    model's own flat buffer) against the same alternation run on the reference's classes: losses and
+    clipped norms of all six steps and EVERY final weight of both models."""
+    from ss_asr_amd.engine import ASRTrainStep, TAETrainStep, label_geometry
+    fx = golden('seed_alt_small')
+    asr, tae = _tae_pair(fx)
+    w0 = {('tae.' + k): v.detach().cpu().clone() for k, v in tae.state_dict().items()}
+    w0.update({('asr.' + k): v.detach().cpu().clone() for k, v in asr.state_dict().items()})
+    asr_step = ASRTrainStep(asr)
+    tae_step = TAETrainStep(asr, tae, lr=float(fx['lr']))
+    assert tae_step.asr_flat is asr_step.flat                      # shared storage, not a copy
+    for r in range(int(fx['rounds'])):
+        x, ya = torch.from_numpy(fx['asr_x%d' % r]), torch.from_numpy(fx['asr_y%d' % r])
+        random.seed(int(fx['asr_rng_seed%d' % r]))
+        loss = float(asr_step(x.cuda(), ya.cuda(), [int(v) for v in fx['asr_lens%d' % r]], label_geometry(ya)[1]))
+        norm, skipped = asr_step.finish()
+        assert not skipped
+        assert abs(loss - float(fx['asr_loss'][r])) < 1e-4, (r, loss)
+        assert abs(norm - float(fx['asr_norm'][r])) < 2e-5 * max(1.0, norm), (r, norm)
+        y, y_noise = torch.from_numpy(fx['y%d' % r]), torch.from_numpy(fx['y_noise%d' % r])
+        random.seed(int(fx['rng_seed%d' % r]))
+        loss = float(tae_step(y.cuda(), y_noise.cuda(), lo.label_lengths(y), lo.label_lengths(y_noise)))
+        norm, skipped = tae_step.finish()
+        assert not skipped
+        assert abs(loss - float(fx['tae_loss'][r])) < 1e-4, (r, loss)
+        assert abs(norm - float(fx['tae_norm'][r])) < 2e-5 * max(1.0, norm), (r, norm)
+    _check_final_weights(fx, asr, tae, w0, atol=3e-6)
+
+
+def test_tae_trainer_end_to_end(tmp_path):
+    """TAETrainer driven as src/train.py drives it (load_data -> set_model -> exec -> close) on a 16-row text
+    index: first-step loss against the CPU oracle from the same checkpoints and noised batch, validation,
+    both checkpoints written, and an update that moved the shared ASR decoder but not its Listener."""
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_y
+    from ss_asr_amd.trainer import TAETrainer
+    root = str(tmp_path)
+    index, _ = make_corpus(root, n=16, t_max=32, feat=80, seed=4)
+    conf = config_for(index)
+    conf['tae'] = {'opt': {'type': 'Adam', 'learning_rate': 0.0001}, 'mdl': {'state_size': 256, 'emb_dim': 128, 'num_layers': 2},
+                   'drop_rate': 0.1, 'train_index': index, 'valid_index': index, 'train_batch_size': 16,
+                   'valid_batch_size': 16, 'n_epochs': 2, 'logging_step': 1, 'save_step': 1, 'valid_step': 2,
+                   'loader_jobs': 0}
+    paras = types.SimpleNamespace(name='tae1', logdir=os.path.join(root, 'runs'), ckpdir=os.path.join(root, 'result'),
+                                  verbose=False, seed=1)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = TAETrainer(conf, paras)
+    tr.load_data()
+    tr.set_model()
+    asr0 = {k: v.detach().cpu().clone() for k, v in tr.asr_model.state_dict().items()}
+    tae0 = {k: v.detach().cpu().clone() for k, v in tr.text_autoenc.state_dict().items()}
+    np.random.seed(7)                      # the noise model draws from numpy's global stream (src/ASRDataset.py:124)
+    tr.exec()
+    tr.close()
+    ckpdir = os.path.join(root, 'result', 'tae1')
+    assert json.load(open(os.path.join(ckpdir, 'tracker.json')))['tae']['step'] == 2
+    for f in ('tae.cpt', 'tae_best.cpt', 'asr.cpt'):
+        assert os.path.isfile(os.path.join(ckpdir, f)), f
+    events = [json.loads(l) for l in open(os.path.join(root, 'runs', 'tae1', 'tae', 'events.jsonl'))]
+    losses = [e['value'] for e in events if e['key'] == 'tae_train_loss']
+    assert len(losses) == 2 and all(np.isfinite(losses))
+    assert any(e['key'] == 'tae_eval_loss' for e in events)
+    # the oracle on the first step's batch (same numpy stream -> same dropped characters)
+    np.random.seed(7)
+    _, _, loader = load_asr_dataset(index, batch_size=16, n_jobs=0, text_only=True, drop_rate=0.1)
+    y, y_noise = next(iter(loader))
+    y, y_lens = prepare_y(y)
+    y_noise, noise_lens = prepare_y(y_noise)
+    ref_asr = lo.OracleASR(50, 256, 256, 128, 80, 1.0)
+    ref_asr.load_state_dict(asr0)
+    ref_tae = lo.OracleTextAutoEncoder(50, 128, 256, 2)
+    ref_tae.load_state_dict(tae0)
+    _, logits = ref_tae(ref_asr, y, y_noise, max(y_lens), noise_lens=noise_lens)
+    want = float(lo.tae_loss(logits, y))
+    assert abs(losses[0] - want) < 1e-4, (losses[0], want)
+    asr1 = torch.load(os.path.join(ckpdir, 'asr.cpt'), map_location='cpu')
+    assert all(torch.equal(asr1[k], asr0[k]) for k in asr0 if k.startswith('encoder.'))
+    assert not torch.equal(asr1['decoder.layer_1.weight_ih'], asr0['decoder.layer_1.weight_ih'])

@@ -268,6 +268,19 @@ def test_postprocess_metrics():
     assert calc_err(logits, label, Mapper()) == pytest.approx((1.0 + 0.0) / 2)
 
 
+@pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_greedy', 'full_b4', 'full_b16_t400'])
+def test_calc_acc_equals_the_reference_value_on_reference_logits(golden, name):
+    """`acc` in the fixtures is the REFERENCE's own calc_acc (src/postprocess.py:7-29, imported through
+    oracle/ref_harness.py) on its own logits; the product's metric on those logits must give that number."""
+    import torch
+    from ss_asr_amd.postprocess import calc_acc
+    fx = golden(name)
+    ans_len = int(fx['ans_len'])
+    logits = torch.from_numpy(fx['logits'])[:, :ans_len]
+    label = torch.from_numpy(fx['y'])[:, 1:ans_len + 1]
+    assert abs(calc_acc(logits, label) - float(fx['acc'])) < 1e-12
+
+
 def test_tracker_format_and_resume(tmp_path):
     from ss_asr_amd.TrackerHandler import TrackerHandler
     path = os.path.join(str(tmp_path), 'tracker.json')
@@ -326,7 +339,8 @@ REFERENCE_TRAIN = '/root/reference/src/train.py'
 
 @pytest.mark.skipif(not os.path.isfile(REFERENCE_TRAIN),
                     reason='build-container only: the reference tree does not travel to the GPU box')
-def test_reference_train_script_runs_unchanged_against_the_shims(tmp_path):
+@pytest.mark.parametrize('kind', ['ASRTrainer', 'TAETrainer', 'Seed'])
+def test_reference_train_script_runs_unchanged_against_the_shims(tmp_path, kind):
     """`python -m ss_asr_amd.run_reference <reference>/src/train.py ...`
     executes the reference's unmodified entry point with its bare imports (`import trainer`,
     src/train.py:9) bound to ss_asr_amd.  Without a GPU the run must get all the way through
@@ -341,13 +355,20 @@ def test_reference_train_script_runs_unchanged_against_the_shims(tmp_path):
                     'mdl': {'encoder_state_size': 32, 'mlp_out_size': 16, 'decoder_state_size': 32,
                             'tf_rate': 0.9, 'feature_dim': 80},
                     'train_index': index, 'valid_index': index, 'wer_step': 1, 'train_batch_size': 16,
-                    'valid_batch_size': 16, 'n_epochs': 1, 'loader_jobs': 0}}
+                    'valid_batch_size': 16, 'n_epochs': 1, 'loader_jobs': 0},
+            # config 5's first leg and the Seed loop (src/train.py:66-70: `Seed` -> trainer.asr_seed_train,
+            # else getattr(trainer, type)): conf/default.yaml:42-53 in miniature
+            'tae': {'opt': {'type': 'Adam', 'learning_rate': 0.0001},
+                    'mdl': {'state_size': 32, 'emb_dim': 8, 'num_layers': 2}, 'drop_rate': 0.1,
+                    'train_index': index, 'valid_index': index, 'train_batch_size': 16, 'valid_batch_size': 16,
+                    'n_epochs': 1, 'loader_jobs': 0},
+            'seed_train': {'its': 1}}
     conf_path = os.path.join(root, 'conf.yaml')
     with open(conf_path, 'w') as f:
         yaml.safe_dump(conf, f)
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
     env.pop('PYTHONPATH', None)
-    res = subprocess.run([sys.executable, '-m', 'ss_asr_amd.run_reference', REFERENCE_TRAIN, 'ASRTrainer', 'dropin',
+    res = subprocess.run([sys.executable, '-m', 'ss_asr_amd.run_reference', REFERENCE_TRAIN, kind, 'dropin',
                           conf_path, os.path.join(root, 'runs'), os.path.join(root, 'result')],
                          cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     out = res.stdout

@@ -149,3 +149,47 @@ def test_text_autoencoder_oracle_matches_reference(golden, name):
     assert sorted(grads) == names
     got = np.array([grads[k].double().norm().item() for k in names])
     np.testing.assert_allclose(got, fx['grad_norms'], rtol=2e-4, atol=1e-7)
+
+
+def _seed(s):
+    random.seed(s); np.random.seed(s); torch.manual_seed(s)
+
+
+@pytest.mark.parametrize('name', ['tae_traj_full_b12', 'seed_alt_small'])
+def test_tae_trainer_trajectory_oracle_matches_reference(golden, name):
+    """Config 5's first leg as a TRAINER: the oracle's tae_train_step (src/trainer.py:652-677 + Solver.step on
+    the text autoencoder's parameters, Adam over the text autoencoder and the shared ASR decoder half)
+    against the trajectory captured from the reference's classes -- three steps at full layer sizes, and
+    three rounds of (ASRTrainer step, TAETrainer step) alternating on ONE shared ASR object."""
+    fx = golden(name)
+    dims = [int(v) for v in fx['dims']]
+    torch.manual_seed(0)
+    asr = lo.OracleASR(*dims, float(fx['tf_rate']))
+    lo.seeded_weights(asr, int(fx['asr_weights_seed']))
+    tae = lo.OracleTextAutoEncoder(dims[0], *[int(v) for v in fx['tae_dims']])
+    lo.seeded_tae_weights(tae, int(fx['tae_weights_seed']))
+    tae_opt = lo.make_tae_optimizer(tae, asr, lr=float(fx['lr']))
+    asr_opt = lo.make_optimizer(asr) if int(fx['with_asr']) else None
+    w0 = {('tae.' + k): v.clone() for k, v in tae.state_dict().items()}
+    w0.update({('asr.' + k): v.clone() for k, v in asr.state_dict().items()})
+    for r in range(int(fx['rounds'])):
+        if asr_opt is not None:
+            _seed(int(fx['asr_rng_seed%d' % r]))
+            loss, norm = lo.train_step(asr, asr_opt, torch.from_numpy(fx['asr_x%d' % r]), torch.from_numpy(fx['asr_y%d' % r]))
+            assert abs(loss - float(fx['asr_loss'][r])) < 1e-5, (r, loss)
+            assert abs(norm - float(fx['asr_norm'][r])) < 1e-5 * max(1.0, norm), (r, norm)
+        _seed(int(fx['rng_seed%d' % r]))
+        loss, norm = lo.tae_train_step(asr, tae, tae_opt, torch.from_numpy(fx['y%d' % r]), torch.from_numpy(fx['y_noise%d' % r]))
+        assert abs(loss - float(fx['tae_loss'][r])) < 1e-5, (r, loss)
+        assert abs(norm - float(fx['tae_norm'][r])) < 1e-5 * max(1.0, norm), (r, norm)
+    w1 = {('tae.' + k): v for k, v in tae.state_dict().items()}
+    w1.update({('asr.' + k): v for k, v in asr.state_dict().items()})
+    names = [str(n) for n in fx['param_names']]
+    assert sorted(w1) == names
+    upd = np.array([(w1[k] - w0[k]).double().norm().item() for k in names])
+    np.testing.assert_allclose(upd, fx['update_norms'], rtol=1e-4, atol=1e-9)
+    for k in fx.files:
+        if k.startswith('w1/'):
+            np.testing.assert_allclose(w1[k[3:]].numpy(), fx[k], atol=2e-6, rtol=0, err_msg=k)
+        if k.startswith('w1_head/'):
+            np.testing.assert_allclose(w1[k[8:]].reshape(-1)[:256].numpy(), fx[k], atol=2e-6, rtol=0, err_msg=k)
