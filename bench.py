@@ -220,7 +220,6 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
     gates = torch.empty(2, S * N, 4 * H, device=device)
     cs = torch.empty(2, S * N, H, device=device)
     hs = torch.empty(2, S * N, H, device=device)
-    ops.placement_probed()
     hx = torch.empty(int(lib.ssasr_bilstm_fwd_hx_floats(S, N, H)), device=device)
     gx = torch.empty(int(lib.ssasr_bilstm_bwd_gx_floats(S, N, H)), device=device)
     ws_t = torch.empty(2, H, 4 * H, device=device)

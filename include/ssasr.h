@@ -44,12 +44,11 @@ int ssasr_abi_version(void);
 /* Diagnostic switches (A/B measurements; every setting computes the same results).  Each is
  * initialised ONCE from the environment variable of the same name when the library is first
  * used -- entry points never read the environment -- and may be changed by tools between
- * calls.  Names: SSASR_NO_PERSISTENT, SSASR_PERSISTENT_COUNTER, SSASR_NO_FUSED_INPUT,
- * SSASR_FWD_NB, SSASR_BPTT_GATHER, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
+ * calls.  Names: SSASR_NO_PERSISTENT, SSASR_NO_FUSED_INPUT, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
  * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
  * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_GEMM_X6, SSASR_GEMM_KCAT, SSASR_LAST_SEG_PCT, SSASR_TAIL_INLINE, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
- * SSASR_TEST_DROP_TILE (fault injection for the timeout test, -1 = off), SSASR_BPTT_LOCAL, SSASR_FWD_LOCAL,
- * SSASR_XCD_ROUND_ROBIN (the probe's verdict, settable for tests).  Unknown name: -1. */
+ * SSASR_TEST_DROP_TILE / SSASR_TEST_DROP_ATTN_SLICE / SSASR_TEST_DROP_DEC_SLICE (fault injection for the
+ * time-out tests, one per kernel family, -1 = off).  Unknown name: -1. */
 int ssasr_set_option(const char* name, int value);
 int ssasr_get_option(const char* name, int* value);
 
@@ -57,18 +56,6 @@ int ssasr_get_option(const char* name, int* value);
  * behind the first.  One set serves all calls of its owner (one thread at a time). */
 int ssasr_events_create(void** handle);
 int ssasr_events_destroy(void* handle);
-
-/* Placement probe.  The persistent recurrences can keep each of their exchange groups on ONE XCD and
- * hand data over through that XCD's L2 instead of the fabric, on request: the forward recurrence of
- * H = 256, N <= 32 layers (SSASR_FWD_LOCAL, csrc/rnn_local.h) and the K-split BPTT (SSASR_BPTT_LOCAL;
- * `beside` GEMMs then keep to the other XCDs).  Both measured no faster than the spread placement
- * inside a train step and are off by default.  That rests on an observed property
- * of the dispatcher -- in a 1-D launch blocks b and b + 8 share an XCD, the classes b & 7 sit on
- * eight different XCDs -- which this call verifies on the current device, once (synchronous; the one
- * place where the library allocates: 8 KB of scratch, freed before it returns).  1 = holds, 0 = does
- * not (spread placement everywhere), negative = HIP error.  Until it has been called the spread
- * placement is used. */
-int ssasr_probe_placement(void* stream);
 
 /* C[b] = act(alpha * op(A[b]) . op(B[b]) + bias) + beta * C[b]; fp32 operands, fp32 accumulation on
  * the matrix cores (products as six bf16 MFMAs on the exact three-way operand split, or the fp32
@@ -96,9 +83,8 @@ int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
  * Saved for backward: gates [2][S*N][4H], cs [2][S*N][H], hs [2][S*N][H].
  * Optional workspaces that enable the single-launch persistent recurrence
  * (taken when H % 64 == 0 and N <= 128): hx, ssasr_bilstm_fwd_hx_floats(S, N, H) floats of
- * exchange image (layout internal: [2][S][H/4][roundup(N,8)][4] floats for the form whose exchange
- * groups spread over all XCDs, three bf16 planes for the XCD-local form of H = 256, N <= 32,
- * which ssasr_probe_placement enables), and sync_ws int32[8], ZERO ON ENTRY (sync_ws[4] != 0
+ * exchange image (layout internal: [2][S][H/4][roundup(N,8)][4] floats), and sync_ws int32[8],
+ * ZERO ON ENTRY (sync_ws[4] != 0
  * afterwards reports an exchange timeout); pass NULL for one launch per step.
  * armed != 0: hx already holds the fill pattern 0x7FC0DEAD in every word, written on the same
  * stream (a caller that arms the exchange workspaces of a whole pass with ONE fill: a dependent
@@ -163,14 +149,11 @@ int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_t ys_n, con
  * accumulate = 0 overwrites, 1 adds (e.g. straight into optimizer-zeroed
  * gradient buffers).  db2_* (optional) gets a second copy of the bias
  * gradient.  Not on the critical path of backward: may run on another stream.
- * beside != 0: the products are launched while a persistent recurrence of this library runs on
- * another stream of the same device; with the XCD-local BPTT placement (ssasr_probe_placement,
- * SSASR_BPTT_LOCAL) their workgroups then keep to the XCDs the recurrence leaves free.  Placement
- * only: results are the same for either value; pass 0 when nothing else is running. */
+ */
 int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t xs_s, int64_t xs_n,
                        const float* hs, int64_t S, int64_t N, int64_t I, int64_t H, float* dw_ih_f,
                        float* dw_hh_f, float* db_f, float* db2_f, float* dw_ih_r, float* dw_hh_r,
-                       float* db_r, float* db2_r, int accumulate, int beside, void* stream);
+                       float* db_r, float* db2_r, int accumulate, void* stream);
 
 /* One nn.LSTMCell step (src/asr.py:320-324); input given as column blocks
  * x1 | x2 (x2 may be NULL).  gates [N][4H] receives the activated i,f,g,o. */
@@ -199,7 +182,7 @@ int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const float* feat
  * ssasr_attn_precompute_bwd left in dcomp: dW_psi (+)= dpre^T feat, db_psi (+)= column sums.
  * accumulate = 1 adds into the outputs (optimizer-owned gradient buffers, any stream). */
 int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat, int64_t rows, int64_t E, int64_t A,
-                                float* dw_psi, float* db_psi, int accumulate, int beside, void* stream);
+                                float* dw_psi, float* db_psi, int accumulate, void* stream);
 
 /* One Attention.forward call after the cache exists (src/asr.py:383-390).
  * state [B][D], w_phi [A][D] (phi.weight), comp [B][T][A], feat [B][T][E],
@@ -340,7 +323,7 @@ int ssasr_decoder_bwd(const ssasr_decoder* d, const ssasr_decoder_grads* g, void
 /* Parameter gradients of the decode loop from what ssasr_decoder_bwd(defer_wgrad = 1)
  * left in d / g (gate derivatives, dqpre, dlogits): 11 products over all steps, off the
  * critical path of the backward pass.  accumulate = 0 overwrites the outputs, 1 adds. */
-int ssasr_decoder_wgrad(const ssasr_decoder* d, const ssasr_decoder_grads* g, int accumulate, int beside,
+int ssasr_decoder_wgrad(const ssasr_decoder* d, const ssasr_decoder_grads* g, int accumulate,
                         void* stream);
 
 /* Masked cross entropy of src/trainer.py:426-434 on the label matrix itself.

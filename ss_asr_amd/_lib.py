@@ -49,7 +49,6 @@ SIGNATURES = {
     'ssasr_get_option': (I32, [C.c_char_p, C.POINTER(C.c_int)]),
     'ssasr_events_create': (I32, [C.POINTER(P)]),
     'ssasr_events_destroy': (I32, [P]),
-    'ssasr_probe_placement': (I32, [P]),
     'ssasr_gemm_f32': (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32,
                              I64, I64, I64, I64, I32, P]),
     'ssasr_bilstm_fwd': (I32, [P, I64, I64, I64, I64, I64, I64, P] + [P] * 8 +
@@ -58,21 +57,21 @@ SIGNATURES = {
     'ssasr_bilstm_fwd_hx_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_bwd': (I32, [P, I64, I64, P, I64, I64, I64, I64, I64, I64, P] + [P] * 4 +
                          [P, P, P, P, I64, I64] + [P] * 6 + [P, P, P, P, I32, P, P]),
-    'ssasr_bilstm_wgrad': (I32, [P, P, I64, I64, P, I64, I64, I64, I64] + [P] * 8 + [I32, I32, P]),
+    'ssasr_bilstm_wgrad': (I32, [P, P, I64, I64, P, I64, I64, I64, I64] + [P] * 8 + [I32, P]),
     'ssasr_bilstm_bwd_overlapped': (I32, [P, I64, I64, P, I64, I64, I64, I64, I64, I64, P] + [P] * 4 +
                                     [P, P, P, P, I64, I64] + [P] * 8 + [P, P, P, P, I32, P, I32, P, P, P]),
     'ssasr_lstm_cell_fwd': (I32, [P, I64, I64, P, I64, I64, P, P, P, P, P, P, I64, I64, P, P, P, P]),
     'ssasr_lstm_cell_bwd': (I32, [P, P, P, P, P, I64, I64, P, P, P]),
     'ssasr_attn_precompute_fwd': (I32, [P, P, P, I64, I64, I64, P, P]),
     'ssasr_attn_precompute_bwd': (I32, [P, P, P, P, I64, I64, I64, P, P, P, P]),
-    'ssasr_attn_precompute_wgrad': (I32, [P, P, I64, I64, I64, P, P, I32, I32, P]),
+    'ssasr_attn_precompute_wgrad': (I32, [P, P, I64, I64, I64, P, P, I32, P]),
     'ssasr_attn_step_ws_floats': (I64, [I64, I64, I64, I64]),
     'ssasr_attn_step_fwd': (I32, [P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, I32, P, P]),
     'ssasr_attn_step_bwd': (I32, [P, P, P, P, P, P, P, I64, I64, I64, I64, P, P, P]),
     'ssasr_decoder_fwd_part_floats': (I64, [I64] * 6),
     'ssasr_decoder_fwd': (I32, [C.POINTER(Decoder), P]),
     'ssasr_decoder_bwd': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), P]),
-    'ssasr_decoder_wgrad': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), I32, I32, P]),
+    'ssasr_decoder_wgrad': (I32, [C.POINTER(Decoder), C.POINTER(DecoderGrads), I32, P]),
     'ssasr_ce_loss_fwd': (I32, [P, P, I64, I64, I64, I64, I64, P, P, P]),
     'ssasr_ce_loss_bwd': (I32, [P, P, I64, P, P, I64, I64, I64, P, P]),
     'ssasr_ctc_ws_floats': (I64, [I64, I64, I64, I64]),

@@ -145,44 +145,35 @@ struct GemmDesc {
   int splitk;          // >1: partial products are atomically added into C
   int batch;
   int64_t sa, sb, sc, sbias;
-  // cls_n != 0: run on the XCDs of launch classes cls_lo .. cls_lo + cls_n - 1 only (1-D launch in
-  // which the other classes exit at once; ssasr_launch_gemm sets gx / gy / gz): work that runs on a
-  // second stream beside an XCD-local persistent recurrence keeps to the XCDs that one leaves free
-  int cls_lo, cls_n, gx, gy, gz;
   // kcat > 1 (split-bf16 kernel, splitk == 1): the product runs over kcat K segments of length K each, the
   // s-th taken at A + s * ska and B + s * skb, all into ONE accumulator: C = act(alpha * sum_s A_s . B_s ...)
   // -- e.g. the input gradient dX = dG_f W_f + dG_r W_r of a BiLSTM layer as one launch, C written once
   int kcat;
   int64_t ska, skb;
 };
-// Side-stream work beside a persistent recurrence: restricts `g` to the free XCD classes when the
-// recurrences are placed XCD-locally (options), else leaves it unrestricted.
-void ssasr_gemm_beside_recurrence(GemmDesc& g);
 int ssasr_launch_gemm(const GemmDesc& g, hipStream_t st);
 int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);
-// Persistent BPTT of `dirs` LSTM directions over S steps x N <= 32 columns (rnn.hip):
-// gates [dirs][S*N][4H] activated gates in / gate derivatives out, whhT [dirs][H][4H],
-// dy[s * ys_s + n * ys_n + d * H + u], gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats.
+// Persistent (K-split) BPTT of `dirs` LSTM directions over S steps x N columns (rnn.hip):
+// gates [dirs][S*N][4H] activated gates in / gate derivatives out, whhT [dirs][H][4H] (or NULL with
+// whh_f / whh_r: the untransposed weights), dy[s * ys_s + n * ys_n + d * H + u],
+// gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats.
 // Returns SSASR_EARG when the shape has no persistent form.
 // armed: gx already holds the fill pattern (no fill here).
-// i0 / i1 / dc_state: iterations [i0, i1) of the S steps (K-split form only; i1 = 0 means S);
+// i0 / i1 / dc_state: iterations [i0, i1) of the S steps (i1 = 0 means S);
 // successive launches over one layer carry the recurrence through gx and dc_state [dirs][N][H].
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0 = 0, int64_t i1 = 0,
                                  float* dc_state = nullptr, const float* whh_f = nullptr, const float* whh_r = nullptr,
                                  bool armed = false, const float* tsave = nullptr, void* stop_event = nullptr);
-// stop_event (a hipEvent_t, K-split form only): recorded by the kernel's OWN completion signal
+// stop_event (a hipEvent_t): recorded by the kernel's OWN completion signal
 // (hipExtLaunchKernel) -- no barrier packet of its own between this launch and the next on the stream
 // Process-wide diagnostic switches (include/ssasr.h, ssasr_set_option): read from the environment
 // ONCE, when the first entry point runs, never per call; A/B tools change them through
 // ssasr_set_option.  Everything here selects between kernels that compute the same result.
 struct SsasrOptions {
   int no_persistent;              // SSASR_NO_PERSISTENT: one launch per step everywhere
-  int persistent_counter;         // SSASR_PERSISTENT_COUNTER: arrival-counter exchange instead of the sentinel form
   int no_fused_input;             // SSASR_NO_FUSED_INPUT: first layer's input projection as a GEMM
-  int fwd_nb;                     // SSASR_FWD_NB: 0 auto, 1 | 2 column tiles per forward workgroup
-  int bptt_gather;                // SSASR_BPTT_GATHER: gather form of the persistent BPTT
   int bptt_halves_off;            // SSASR_BPTT_HALVES_OFF
   int bptt_reserve_kb;            // SSASR_BPTT_RESERVE_KB (118); SSASR_BPTT_SHARED_CU=1 makes it 0
   int no_persistent_decoder;      // SSASR_NO_PERSISTENT_DECODER
@@ -195,14 +186,11 @@ struct SsasrOptions {
   int tail_inline;                // SSASR_TAIL_INLINE (1): the first layer's last range of weight-gradient products on the main stream
   int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches
   int test_drop_tile;             // SSASR_TEST_DROP_TILE (-1): fault injection, see EncPersist::drop_tile
+  int test_drop_attn_slice;       // SSASR_TEST_DROP_ATTN_SLICE (-1): the split-T attention kernel's (AttnSplit::drop_slice)
+  int test_drop_dec_slice;        // SSASR_TEST_DROP_DEC_SLICE (-1): the long-encoder decode loop's (DecLong::drop_slice)
   int attn_rph;                   // SSASR_ATTN_RPH: 0 model, 2 | 3 | 4 | 6 rows per half-wave of the split-T attention kernel
   int no_tsave;                   // SSASR_NO_TSAVE: saved gates / cell states row-major (in place) instead of tile-major
-  int bptt_local;                 // SSASR_BPTT_LOCAL (0): XCD-local placement of the K-split BPTT when the probe allows it
-  int fwd_local;                  // SSASR_FWD_LOCAL (0): XCD-local forward recurrence (rnn_local.h) when the probe allows it
-  int xcd_round_robin;            // verdict of ssasr_probe_placement(): -1 not probed, 0 no, 1 yes (not an environment switch)
 };
-// true when persistent recurrences may be placed XCD-locally (option on and the probe said yes)
-bool ssasr_local_placement();
 const SsasrOptions& ssasr_options();
 // Upper bound of co-resident workgroups of `kernel` (block threads, dynamic LDS bytes) on the current
 // device: occupancy per CU x CU count, cached per (kernel, LDS).  A persistent grid larger than this

@@ -38,7 +38,7 @@ bool dec_grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t work
 bool dec_long_taken(int64_t B, int64_t T, int64_t A, int64_t E, int64_t D, int64_t V) {
   const SsasrOptions& opt = ssasr_options();
   if (A != PD_A || E != PD_E || D != PD_D || V <= 0 || V > 64 || !pl_shape_ok(B, T)) return false;
-  if (opt.no_persistent || opt.no_persistent_decoder || opt.persistent_counter) return false;
+  if (opt.no_persistent || opt.no_persistent_decoder) return false;
   const void* fn = reinterpret_cast<const void*>(decoder_fwd_long_kernel);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)decoder_long_lds()) != hipSuccess) return false;
   return dec_grid_fits(fn, 512, decoder_long_lds(), (int64_t)pl_ns(T) * B + PL_NCMP);
@@ -81,7 +81,7 @@ extern "C" int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const 
     g.ta = 0; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.splitk = 1; g.batch = 1;
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
-  if (dw_psi || db_psi) return ssasr_attn_precompute_wgrad(dcomp, feat, rows, E, A, dw_psi, db_psi, 0, 0, stream);
+  if (dw_psi || db_psi) return ssasr_attn_precompute_wgrad(dcomp, feat, rows, E, A, dw_psi, db_psi, 0, stream);
   return SSASR_OK;
 }
 
@@ -90,7 +90,7 @@ extern "C" int ssasr_attn_precompute_bwd(float* dcomp, const float* comp, const 
 // into optimizer-owned gradient buffers.
 extern "C" int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat, int64_t rows, int64_t E,
                                            int64_t A, float* dw_psi, float* db_psi, int accumulate,
-                                           int beside, void* stream) {
+                                           void* stream) {
   if (!dcomp || !feat || rows <= 0 || E <= 0 || A <= 0) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -106,7 +106,6 @@ extern "C" int ssasr_attn_precompute_wgrad(const float* dcomp, const float* feat
       int sk = (int)(rows / 128);
       g.splitk = sk < 1 ? 1 : (sk > 16 ? 16 : sk);
     }
-    if (beside) ssasr_gemm_beside_recurrence(g);
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   if (db_psi) {
@@ -157,7 +156,7 @@ int launch_attn_fwd(const AttnFwd& p, hipStream_t st, float* ws = nullptr, int p
     sp.att = p.att; sp.att_sb = p.att_sb; sp.ctx = p.ctx; sp.ctx_ld = p.ctx_ld;
     sp.part = ws; sp.status = status;
     sp.B = p.B; sp.T = p.T; sp.phase = phase & 1;
-    sp.drop_slice = ssasr_options().test_drop_tile;
+    sp.drop_slice = ssasr_options().test_drop_attn_slice;
     const int rph = attn_split_rph(p.B, p.T);
     sp.NS = (p.T + 8 * rph - 1) / (8 * rph);
     const dim3 sgrid((unsigned)sp.NS, (unsigned)p.B);
@@ -275,8 +274,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
                     !opt.no_persistent && !opt.no_persistent_decoder;
   if (persistent) {
     const size_t lds = decoder_persistent_lds((int)T);
-    const void* fn = opt.persistent_counter ? reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<false>)
-                                            : reinterpret_cast<const void*>(decoder_fwd_persistent_kernel<true>);
+    const void* fn = reinterpret_cast<const void*>(decoder_fwd_persistent_kernel);
     SSASR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     persistent = dec_grid_fits(fn, 256, lds, PD_NATTWG + 128);
   }
@@ -284,7 +282,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
   // record ring: the same exchange images (ws_qx is not used) plus ws_part
   const bool longform = !persistent && d.ws_hx1 && d.ws_hx2 && d.ws_modes && d.ws_sync && d.ws_part &&
                         dec_long_taken(B, T, A, E, D, V);
-  const bool sentinel = (persistent && !opt.persistent_counter) || longform;
+  const bool sentinel = persistent || longform;
   if ((persistent || longform) && !d.modes_ready)
     SSASR_HIP(hipMemcpyAsync(d.ws_modes, d.step_mode, sizeof(int32_t) * U, hipMemcpyHostToDevice, st));
   // (self-verifying loop: rows the loop itself produces start as the fill pattern)
@@ -293,7 +291,6 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
                      (int)U);
   SSASR_LAUNCH_CHECK();
 
-  if (d.ws_sync && opt.persistent_counter) SSASR_HIP(hipMemsetAsync(d.ws_sync, 0, 5 * sizeof(int32_t), st));
   if (persistent) {
     DecPersist p{};
     p.feat = d.feat; p.comp = d.comp; p.enc_len = d.enc_len; p.w_phi = d.w_phi;
@@ -303,10 +300,10 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     p.att = d.att; p.q = d.q; p.ctx = d.ctx; p.emb_in = d.emb_in; p.chars = d.chars;
     p.gates1 = d.gates1; p.c1 = d.c1; p.h1 = d.h1; p.gates2 = d.gates2; p.c2 = d.c2; p.h2 = d.h2;
     p.hx1 = d.ws_hx1; p.hx2 = d.ws_hx2; p.qx = d.ws_qx;
-    p.cnt = reinterpret_cast<unsigned*>(d.ws_sync); p.status = d.ws_sync + 5;
+    p.status = d.ws_sync + 5;
     p.B = (int)B; p.T = (int)T; p.U = (int)U; p.V = (int)V;
     const size_t lds = decoder_persistent_lds((int)T);
-    if (sentinel) {
+    {
       // self-verifying hand-offs: every exchanged buffer starts as the fill pattern (one fill
       // when the caller laid the three exchange images out back to back)
       const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4, img_q = (size_t)(PD_A / 16) * PD_BP * 16;   // floats per step
@@ -324,9 +321,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_qx, (int)PERSIST_SENTINEL, img_q * U, st));
       }
       if (!ctx_filled) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ctx, (int)PERSIST_SENTINEL, n_ctx, st));
-      hipLaunchKernelGGL(decoder_fwd_persistent_kernel<true>, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
-    } else {
-      hipLaunchKernelGGL(decoder_fwd_persistent_kernel<false>, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
+      hipLaunchKernelGGL(decoder_fwd_persistent_kernel, dim3(PD_NATTWG + 128), dim3(256), lds, st, p);
     }
     SSASR_LAUNCH_CHECK();
   }
@@ -340,9 +335,9 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
     p.att = d.att; p.q = d.q; p.ctx = d.ctx; p.emb_in = d.emb_in; p.chars = d.chars;
     p.gates1 = d.gates1; p.c1 = d.c1; p.h1 = d.h1; p.gates2 = d.gates2; p.c2 = d.c2; p.h2 = d.h2;
     p.hx1 = d.ws_hx1; p.hx2 = d.ws_hx2; p.qx = nullptr;
-    p.cnt = reinterpret_cast<unsigned*>(d.ws_sync); p.status = d.ws_sync + 5;
+    p.status = d.ws_sync + 5;
     p.B = (int)B; p.T = (int)T; p.U = (int)U; p.V = (int)V;
-    lp.part = d.ws_part; lp.NS = pl_ns(T); lp.drop_slice = opt.test_drop_tile;
+    lp.part = d.ws_part; lp.NS = pl_ns(T); lp.drop_slice = opt.test_drop_dec_slice;
     if (!armed) {      // every exchanged buffer starts as the fill pattern
       const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4;
       SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)d.ws_hx1, (int)PERSIST_SENTINEL, img_h * U, st));
@@ -427,7 +422,7 @@ extern "C" int ssasr_decoder_fwd(const ssasr_decoder* dp, void* stream) {
 namespace {
 
 int gemm_tn_acc(const float* A, RowMap ma, const float* B, RowMap mb, float* C, int64_t ldc, int64_t M,
-                int64_t N, int64_t K, hipStream_t st, bool beside = false) {
+                int64_t N, int64_t K, hipStream_t st) {
   // C[M][N] += A^T . B with A stored [K][M], B stored [K][N]; C pre-zeroed.
   if (K <= 0) return SSASR_OK;
   GemmDesc g{};
@@ -438,7 +433,6 @@ int gemm_tn_acc(const float* A, RowMap ma, const float* B, RowMap mb, float* C, 
   int sk = (int)(256 / tiles); if (sk < 1) sk = 1; if (sk > 16) sk = 16;
   if (K < 128 * sk) sk = K >= 256 ? 2 : 1;
   g.splitk = sk < 2 ? 2 : sk;      // always the accumulate form
-  if (beside) ssasr_gemm_beside_recurrence(g);
   return ssasr_launch_gemm(g, st);
 }
 
@@ -650,12 +644,11 @@ extern "C" int ssasr_decoder_bwd(const ssasr_decoder* dp, const ssasr_decoder_gr
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
   if (g.defer_wgrad) return SSASR_OK;
-  return ssasr_decoder_wgrad(dp, gp, 0, 0, stream);
+  return ssasr_decoder_wgrad(dp, gp, 0, stream);
 }
 
 extern "C" int ssasr_decoder_wgrad(const ssasr_decoder* dp, const ssasr_decoder_grads* gp, int accumulate,
-                                   int beside_in, void* stream) {
-  const bool beside = beside_in != 0;
+                                   void* stream) {
   if (!dp || !gp) return SSASR_EARG;
   const ssasr_decoder& d = *dp;
   const ssasr_decoder_grads& g = *gp;
@@ -670,26 +663,26 @@ extern "C" int ssasr_decoder_wgrad(const ssasr_decoder* dp, const ssasr_decoder_
 #define SSASR_ZERO(ptr, n) do { if (!accumulate) SSASR_HIP(hipMemsetAsync((ptr), 0, sizeof(float) * (n), st)); } while (0)
   // char_trans: dW_ct = dlogits^T . h2 ; db_ct = colsum
   SSASR_ZERO(g.dw_ct, V * D);
-  if ((rc = gemm_tn_acc(g.dlogits, logit_rows, d.h2, rm_dense(D), g.dw_ct, D, V, D, rows, st, beside))) return rc;
+  if ((rc = gemm_tn_acc(g.dlogits, logit_rows, d.h2, rm_dense(D), g.dw_ct, D, V, D, rows, st))) return rc;
   SSASR_ZERO(g.db_ct, V);
   if ((rc = ssasr_launch_colsum(g.dlogits, B * U, (int)V, V, g.db_ct, st))) return rc;
   // dW_phi = sum_{t>=1} dqpre[t]^T . h1[t-1]
   SSASR_ZERO(g.dw_phi, A * D);
-  if ((rc = gemm_tn_acc(g.ws_dqpre + B * A, rm_dense(A), d.h1, rm_dense(D), g.dw_phi, D, A, D, (U - 1) * B, st, beside))) return rc;
+  if ((rc = gemm_tn_acc(g.ws_dqpre + B * A, rm_dense(A), d.h1, rm_dense(D), g.dw_phi, D, A, D, (U - 1) * B, st))) return rc;
   // cell 1: dW_ih1 = dG1^T . [emb_in | ctx], dW_hh1 = dG1[1:]^T . h1[:-1], db1
   SSASR_ZERO(g.dw_ih1, 4 * D * (D + E));
-  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.emb_in, rm_dense(D), g.dw_ih1, D + E, 4 * D, D, rows, st, beside))) return rc;
-  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.ctx, rm_dense(E), g.dw_ih1 + D, D + E, 4 * D, E, rows, st, beside))) return rc;
+  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.emb_in, rm_dense(D), g.dw_ih1, D + E, 4 * D, D, rows, st))) return rc;
+  if ((rc = gemm_tn_acc(d.gates1, rm_dense(4 * D), d.ctx, rm_dense(E), g.dw_ih1 + D, D + E, 4 * D, E, rows, st))) return rc;
   SSASR_ZERO(g.dw_hh1, 4 * D * D);
-  if ((rc = gemm_tn_acc(d.gates1 + B * 4 * D, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_hh1, D, 4 * D, D, (U - 1) * B, st, beside))) return rc;
+  if ((rc = gemm_tn_acc(d.gates1 + B * 4 * D, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_hh1, D, 4 * D, D, (U - 1) * B, st))) return rc;
   SSASR_ZERO(g.db1, 4 * D);
   if (g.db1_2) SSASR_ZERO(g.db1_2, 4 * D);
   if ((rc = ssasr_launch_colsum(d.gates1, rows, (int)(4 * D), 4 * D, g.db1, st, g.db1_2))) return rc;
   // cell 2
   SSASR_ZERO(g.dw_ih2, 4 * D * D);
-  if ((rc = gemm_tn_acc(d.gates2, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_ih2, D, 4 * D, D, rows, st, beside))) return rc;
+  if ((rc = gemm_tn_acc(d.gates2, rm_dense(4 * D), d.h1, rm_dense(D), g.dw_ih2, D, 4 * D, D, rows, st))) return rc;
   SSASR_ZERO(g.dw_hh2, 4 * D * D);
-  if ((rc = gemm_tn_acc(d.gates2 + B * 4 * D, rm_dense(4 * D), d.h2, rm_dense(D), g.dw_hh2, D, 4 * D, D, (U - 1) * B, st, beside))) return rc;
+  if ((rc = gemm_tn_acc(d.gates2 + B * 4 * D, rm_dense(4 * D), d.h2, rm_dense(D), g.dw_hh2, D, 4 * D, D, (U - 1) * B, st))) return rc;
   SSASR_ZERO(g.db2, 4 * D);
   if (g.db2_2) SSASR_ZERO(g.db2_2, 4 * D);
   if ((rc = ssasr_launch_colsum(d.gates2, rows, (int)(4 * D), 4 * D, g.db2, st, g.db2_2))) return rc;
@@ -701,7 +694,6 @@ extern "C" int ssasr_decoder_wgrad(const ssasr_decoder* dp, const ssasr_decoder_
     m.C = g.ws_demb; m.mc = rm_dense(D);
     m.M = (int)rows; m.N = (int)D; m.K = (int)(4 * D); m.ta = 0; m.tb = 1;
     m.alpha = 1.f; m.beta = 0.f; m.splitk = 1; m.batch = 1;
-    if (beside) ssasr_gemm_beside_recurrence(m);
     if ((rc = ssasr_launch_gemm(m, st))) return rc;
   }
   SSASR_ZERO(g.dembed, V * D);

@@ -40,7 +40,7 @@ constexpr int PL_PART = 512 + 32;     // floats per record: partial context, the
 constexpr int PL_RING = 3;            // steps of records alive at once
 
 struct DecLong {
-  DecPersist d;                       // (d.qx, d.cnt unused: sentinel hand-offs only, q is formed in place)
+  DecPersist d;                       // (d.qx unused: q is formed in place)
   float* part;                        // [PL_RING][B][NS][PL_PART] records, every word the fill pattern on entry
   int NS;
   int drop_slice;                     // fault injection for tests (SSASR_TEST_DROP_TILE, -1 = off): slice `drop_slice`
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void decoder_fwd_long_kernel(DecLong pp) {
   const int natt = NS * B;
   if ((int)blockIdx.x >= natt) {
     const int cw = (int)blockIdx.x - natt, grp = tid >> 8;
-    pd_compute_role<true>(p, 2 * cw + grp, tid & 255, smem + grp * PD_GROUP_LDS_FLOATS, 2 * cw < B,
+    pd_compute_role(p, 2 * cw + grp, tid & 255, smem + grp * PD_GROUP_LDS_FLOATS, 2 * cw < B,
                           smem + 2 * PD_GROUP_LDS_FLOATS, grp == 0);
     return;
   }
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512) void decoder_fwd_long_kernel(DecLong pp) {
       if (wave == 0) {          // the 64 16-byte pieces of h1_{t-1}[b] (image [D/4][BP][4])
         const unsigned hoff = (unsigned)((t - 1) * img_h + ((lane * PD_BP + b) * 4) * 4);
         float4 hv[1];
-        pd_fetch<true, 1>(hv, [=](int) { return pd_ld_raw(rh, hoff); }, 0, 1, p.status);
+        pd_fetch<1>(hv, [=](int) { return pd_ld_raw(rh, hoff); }, 0, 1, p.status);
         *reinterpret_cast<float4*>(sHq + 4 * lane) = hv[0];
       }
       __syncthreads();
@@ -234,12 +234,12 @@ __global__ __launch_bounds__(512) void decoder_fwd_long_kernel(DecLong pp) {
     float4 pc[PL_MAXNS];
     if (wave == 0) {
       const unsigned go = (unsigned)((32 * oline + 4 * (tid & 7)) * 4);
-      pd_fetch<true, PL_MAXNS>(pc, [=](int j) { return pd_ld_raw(rp, go + (unsigned)j * (PL_PART * 4)); }, 0,
+      pd_fetch<PL_MAXNS>(pc, [=](int j) { return pd_ld_raw(rp, go + (unsigned)j * (PL_PART * 4)); }, 0,
                                out_thread ? NS : 0, p.status);
     } else if (wave == 4) {
       const int j = tid - 256;
       float4 pr[1];
-      pd_fetch<true, 1>(pr, [=](int) { return pd_ld_raw(rp, (unsigned)((j * PL_PART + 512) * 4)); }, 0, j < NS ? 1 : 0,
+      pd_fetch<1>(pr, [=](int) { return pd_ld_raw(rp, (unsigned)((j * PL_PART + 512) * 4)); }, 0, j < NS ? 1 : 0,
                         p.status);
       const bool live = j < NS && pr[0].y > 0.f;
       const float M = wave_max(live ? pr[0].x : -INFINITY);

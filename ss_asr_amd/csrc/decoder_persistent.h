@@ -23,10 +23,10 @@
 // protocol of the persistent recurrences (rnn_kernels.h): write-through (sc1)
 // stores that cover whole 128-byte lines per store instruction into buffers the
 // host pre-filled with the NaN pattern PERSIST_SENTINEL; consumers read with sc1
-// loads and re-fetch any 16-byte piece that still holds the pattern (SEN =
-// true).  Measured with the arrival counters this kernel first used (SEN =
-// false: drain, one agent-scope add per producer, consumers poll): 128 adds to
-// one address plus 192 pollers cost 5.5 us per hand-off, 23 us per decode step.
+// loads and re-fetch any 16-byte piece that still holds the pattern.  (The arrival
+// counters this kernel first used -- drain, one agent-scope add per producer, consumers
+// poll -- cost 5.5 us per hand-off, 23 us per decode step: 128 adds to one address plus
+// 192 pollers.  That form was removed in round 4.)
 // Every step uses fresh addresses.  All spins are bounded; a timeout sets
 // *status and the launch still terminates.
 #pragma once
@@ -54,51 +54,33 @@ struct DecPersist {
   float* gates1; float* c1; float* h1; float* gates2; float* c2; float* h2;
   float* hx1; float* hx2;   // [U][D/4][BP][4] exchange images of h1 / h2
   float* qx;                // [U][A/16][BP][16] exchange image of q
-  unsigned* cnt;            // [0] h1  [1] q  [2] ctx  [3] h2  [4] char
   int* status;
   int B, T, U, V;
 };
 
-enum { PC_H1 = 0, PC_Q = 1, PC_CTX = 2, PC_H2 = 3, PC_CHAR = 4 };
-
-struct PdWaiter {
-  bool broken;
-  int* status;
-  __device__ __forceinline__ void wait_ge(unsigned* c, unsigned target) {
-    if (threadIdx.x == 0 && !broken) {
-      unsigned spins = 0;
-      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (persist_give_up(++spins, status, persist_code(PK_DEC_FWD, 0xfff))) { broken = true; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    __syncthreads();
-  }
-};
-
-// Fetches b[lo..hi) through ld(j) (an sc1 load returning the raw bits) and, when
-// SEN, re-fetches pieces that still hold the fill pattern.
-template <bool SEN, int NV, typename F>
+// Fetches b[lo..hi) through ld(j) (an sc1 load returning the raw bits) and re-fetches pieces that still
+// hold the fill pattern.
+template <int NV, typename F>
 __device__ __forceinline__ void pd_fetch(float4 (&b)[NV], F ld, int lo, int hi, int* status) {
   u32x4 raw[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) raw[j] = (j >= lo && j < hi) ? ld(j) : u32x4{0u, 0u, 0u, 0u};
-  if (SEN) {
-    for (unsigned tries = 0;; ++tries) {
-      bool anybad = false;
+  for (unsigned tries = 0;; ++tries) {
+    bool anybad = false;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const bool bad = raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
-                         raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
-        if (__any(bad)) {
-          anybad = true;
-          raw[j] = ld(j);
-        }
+    for (int j = 0; j < NV; ++j) {
+      const bool bad = raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
+                       raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
+      if (__any(bad)) {
+        anybad = true;
+        // per lane, as the first load: a lane outside [lo, hi) keeps its zeros instead of polling words
+        // it has no use for (other slices' records: it would then wait for THEIR writers too)
+        if (j >= lo && j < hi) raw[j] = ld(j);
       }
-      if (!anybad) break;
-      if (persist_give_up(tries, status, persist_code(PK_DEC_FWD, 0xfff))) break;
-      __builtin_amdgcn_s_sleep(2);
     }
+    if (!anybad) break;
+    if (persist_give_up(tries, status, persist_code(PK_DEC_FWD, 0xfff))) break;
+    __builtin_amdgcn_s_sleep(2);
   }
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -152,7 +134,6 @@ constexpr int PD_WCT_LD = PD_D + 4;
 constexpr int PD_WCT_FLOATS = 64 * PD_WCT_LD + 64;
 // `swct`: the table above (one per workgroup, shared by its groups) or unused when !any_chr;
 // `stage`: this group fills it (exactly one group of a workgroup with any_chr does).
-template <bool SEN>
 __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c, const int tid, float* smem,
                                                 const bool any_chr, float* swct, const bool stage) {
   const int wave = tid >> 6, lane = tid & 63;
@@ -167,9 +148,6 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
     __syncthreads();
   }
   const int B = p.B, U = p.U;
-  PdWaiter wt{false, p.status};
-  const unsigned n_att = (unsigned)(B * PD_NATT);     // ctx publishers per step (counter form only)
-  const unsigned n_cmp = 128u, n_chr = (unsigned)B;
   const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4 * sizeof(float);      // bytes per step
   const int tile = c >> 1, chunk = c & 1;          // 4 hidden units, 16 utterances
   const int r = lane & 15, q = lane >> 4;
@@ -212,11 +190,10 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
   const __amdgpu_buffer_rsrc_t rc = pd_rsrc(p.ctx, (size_t)U * B * E * sizeof(float));
   const __amdgpu_buffer_rsrc_t re = pd_rsrc(p.emb_in, (size_t)(U + 1) * B * D * sizeof(float));
   const unsigned xoi = (unsigned)((q * PD_BP + nc) * 16);          // lane part of an image read
-  unsigned nsamp = 0;                                              // non-teacher steps so far
 
   // cell epilogue shared by both cells: gates -> state, saves, image store, publish
   auto cell_finish = [&](const f32x4& acc, const f32x4& acc2, const float (&bias)[4], float& cst, int t,
-                         float* gates, float* cs, float* hs, const __amdgpu_buffer_rsrc_t& rimg, int counter) {
+                         float* gates, float* cs, float* hs, const __amdgpu_buffer_rsrc_t& rimg) {
     red[wave * 64 + lane] = acc + acc2;
     __syncthreads();
     if (wave == 0) {
@@ -244,10 +221,6 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
       if (lane < 16)
         pd_st_sc1(rimg, (unsigned)(t * img_h + ((tile * PD_BP + 16 * chunk + lane) * 16)),
                   *reinterpret_cast<const float4*>(sH + lane * 4));
-      if (!SEN) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(p.cnt + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
     __syncthreads();
   };
@@ -255,7 +228,6 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
   for (int t = 0; t <= U; ++t) {
     // (A) h1_{t-1} from every compute workgroup
     SSASR_DTRACE(t, 0);
-    if (!SEN && t > 0) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
     SSASR_DTRACE(t, 1);
 
     // (B) (phi_t = tanh(W_phi h1_{t-1}) is computed by the attention workgroups themselves)
@@ -263,33 +235,30 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
     // (C) cell 2 of step t-1 (overlaps the attention workgroups' step t)
     if (t > 0) {
       const int s = t - 1;
-      if (!SEN && s > 0) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)s);
       float4 b2[8];
       {
         const unsigned o1 = (unsigned)(s * img_h + wave * 4 * PD_BP * 16 + xoi);
         const unsigned o2 = (unsigned)((s > 0 ? s - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
-        pd_fetch<SEN, 8>(b2, [=](int j) {      // kb = wave + 4 j: 0..15 h1_s, 16..31 h2_{s-1}
+        pd_fetch<8>(b2, [=](int j) {      // kb = wave + 4 j: 0..15 h1_s, 16..31 h2_{s-1}
           return j < 4 ? pd_ld_raw(rh1, o1 + (unsigned)(4 * j) * 4 * PD_BP * 16)
                        : pd_ld_raw(rh2, o2 + (unsigned)(4 * (j - 4)) * 4 * PD_BP * 16);
         }, 0, s > 0 ? 8 : 4, p.status);
       }
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
       pd_mma<8>(acc, acc2, w2, b2, 0, s > 0 ? 8 : 4);
-      cell_finish(acc, acc2, bias2, cst2, s, p.gates2, p.c2, p.h2, rh2, PC_H2);
+      cell_finish(acc, acc2, bias2, cst2, s, p.gates2, p.c2, p.h2, rh2);
 
       // (D) next character after step s when it is not teacher forced
       const int mode = p.modes[s];
       if (mode != 0) {
-        ++nsamp;
         if (any_chr && s + 1 <= U) {        // (workgroup-uniform: groups without the role only keep the barriers)
-          if (!SEN) wt.wait_ge(p.cnt + PC_H2, n_cmp * (unsigned)(s + 1));
           const int b = c;
           float* sV = sH;                                       // [256] h2_s of utterance b
           float* sL = sH + 256;                                 // [V] logits
           if (is_chr && tid < 64) {
             const unsigned ho = (unsigned)(s * img_h + ((tid * PD_BP + b) * 16));
             float4 hv[1];
-            pd_fetch<SEN, 1>(hv, [=](int) { return pd_ld_raw(rh2, ho); }, 0, 1, p.status);
+            pd_fetch<1>(hv, [=](int) { return pd_ld_raw(rh2, ho); }, 0, 1, p.status);
             *reinterpret_cast<float4*>(sV + 4 * tid) = hv[0];
           }
           __syncthreads();
@@ -334,10 +303,6 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
             if (lane == 0) p.chars[(int64_t)(s + 1) * B + b] = best;
             pd_st_sc1(re, (unsigned)((((int64_t)(s + 1) * B + b) * D + 4 * lane) * 4),
                       aload4(p.embed + (int64_t)best * D + 4 * lane));
-            if (!SEN) {
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CHAR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
           }
           __syncthreads();
         }
@@ -347,10 +312,6 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
 
     // (E) ctx_t from the attention workgroups, emb_t from the character role
     SSASR_DTRACE(t, 3);
-    if (!SEN) {
-      wt.wait_ge(p.cnt + PC_CTX, n_att * (unsigned)(t + 1));
-      if (t > 0 && p.modes[t - 1] != 0) wt.wait_ge(p.cnt + PC_CHAR, n_chr * nsamp);
-    }
     SSASR_DTRACE(t, 4);
 
     // (F) cell 1 of step t: [emb_t | ctx_t | h1_{t-1}].  The emb and h1 thirds do not depend on
@@ -362,7 +323,7 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
         float4 bA[8];
         const unsigned oe = (unsigned)((((int64_t)t * B + nc) * D + 16 * wave + 4 * q) * 4);
         const unsigned oh = (unsigned)((t > 0 ? t - 1 : 0) * img_h + wave * 4 * PD_BP * 16 + xoi);
-        pd_fetch<SEN, 8>(bA, [=](int j) {      // kb = wave + 4 j: 0..15 emb; then 48..63 h1
+        pd_fetch<8>(bA, [=](int j) {      // kb = wave + 4 j: 0..15 emb; then 48..63 h1
           return j < 4 ? pd_ld_raw(re, oe + (unsigned)(64 * j) * 4)
                        : pd_ld_raw(rh1, oh + (unsigned)(4 * (j - 4)) * 4 * PD_BP * 16);
         }, 0, t > 0 ? 8 : 4, p.status);
@@ -372,11 +333,11 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
         const float4 wB[8] = {w1[4], w1[5], w1[6], w1[7], w1[8], w1[9], w1[10], w1[11]};
         float4 bB[8];
         const unsigned oc = (unsigned)((((int64_t)t * B + nc) * E + 16 * wave + 4 * q) * 4);
-        pd_fetch<SEN, 8>(bB, [=](int j) { return pd_ld_raw(rc, oc + (unsigned)(64 * j) * 4); }, 0, 8, p.status);   // kb 16..47
+        pd_fetch<8>(bB, [=](int j) { return pd_ld_raw(rc, oc + (unsigned)(64 * j) * 4); }, 0, 8, p.status);   // kb 16..47
         pd_mma<8>(acc, acc2, wB, bB, 0, 8);
       }
       SSASR_DTRACE(t, 5);
-      cell_finish(acc, acc2, bias1, cst1, t, p.gates1, p.c1, p.h1, rh1, PC_H1);
+      cell_finish(acc, acc2, bias1, cst1, t, p.gates1, p.c1, p.h1, rh1);
       SSASR_DTRACE(t, 6);
     }
   }
@@ -386,14 +347,10 @@ __device__ __forceinline__ void pd_compute_role(const DecPersist& p, const int c
 //       then 128 compute workgroups (tile = c >> 1, 16-column chunk = c & 1): 192 in all.
 // The kernel needs ~256 VGPRs, i.e. one workgroup per CU: 192 leaves 64 CUs of slack.
 // dynamic LDS: T * 256 floats (feat slice) + 2176 floats scratch
-template <bool SEN>
 __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int B = p.B, T = p.T, U = p.U;
-  PdWaiter wt{false, p.status};
-  const unsigned n_att = (unsigned)(B * PD_NATT);     // ctx publishers per step
-  const unsigned n_cmp = 128u, n_chr = (unsigned)B;
   const size_t img_h = (size_t)(PD_D / 4) * PD_BP * 4 * sizeof(float);      // bytes per step
   const size_t img_q = (size_t)(PD_A / 16) * PD_BP * 16 * sizeof(float);
 
@@ -456,11 +413,10 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
       }
       float4 q4 = z4;
       if (t > 0) {
-        if (!SEN) wt.wait_ge(p.cnt + PC_H1, n_cmp * (unsigned)t);
         if (wave == 0) {        // the 64 16-byte pieces of h1_{t-1}[b] (image [D/4][BP][4])
           const unsigned hoff = (unsigned)((t - 1) * img_h + ((lane * PD_BP + b) * 4) * 4);
           float4 hv[1];
-          pd_fetch<SEN, 1>(hv, [=](int) { return pd_ld_raw(rh, hoff); }, 0, 1, p.status);
+          pd_fetch<1>(hv, [=](int) { return pd_ld_raw(rh, hoff); }, 0, 1, p.status);
           *reinterpret_cast<float4*>(sHq + 4 * lane) = hv[0];
         }
         SSASR_DTRACE(t, 1);
@@ -559,10 +515,6 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
           }
           pd_st_sc1(rc, (unsigned)((((int64_t)t * B + b) * PD_E + chunk * 256 + 4 * lane) * 4), v);
         }
-        if (!SEN) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_fetch_add(p.cnt + PC_CTX, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         SSASR_DTRACE(t, 4);
       }
       __syncthreads();     // sM / sRed are rewritten next step
@@ -572,7 +524,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_persistent_kernel(DecPersist 
 
   // -------------------------------- compute role --------------------------------
   const int c = blockIdx.x - PD_NATTWG;
-  pd_compute_role<SEN>(p, c, tid, smem, c < B, smem + PD_GROUP_LDS_FLOATS, true);
+  pd_compute_role(p, c, tid, smem, c < B, smem + PD_GROUP_LDS_FLOATS, true);
 }
 
 inline size_t decoder_persistent_lds(int T) {

@@ -175,37 +175,18 @@ __device__ __forceinline__ bool map_vec_ok_dev(const RowMap& m) {
 // Workgroups are handed to the 8 XCDs round-robin in launch order and each
 // XCD has its own L2.  Re-map the launch index so that one XCD works on a
 // contiguous run of tiles (N fastest, then M, then the split-K / batch
-// slice): its A row-blocks are then fetched by that XCD only.  Returns false for a workgroup
-// of a class-restricted launch that has nothing to do.
-__device__ __forceinline__ bool gemm_tile_of_block(const GemmDesc& g, int& bx, int& by, int& bzz) {
-  bx = blockIdx.x; by = blockIdx.y; bzz = blockIdx.z;
-  if (g.cls_n) {
-    // restricted to the XCDs of launch classes cls_lo .. cls_lo + cls_n - 1 (1-D launch of
-    // 8 * ceil(tiles / cls_n) workgroups; see GemmDesc): the other classes exit at once
-    const int nx = g.gx, ny = g.gy;
-    const int total = nx * ny * g.gz;
-    const int c = (bx & 7) - g.cls_lo, j = bx >> 3;
-    if (c < 0 || c >= g.cls_n) return false;
-    const int per = total / g.cls_n, rem = total % g.cls_n;
-    if (j >= per + (c < rem ? 1 : 0)) return false;
-    const int t = c * per + min(c, rem) + j;
-    bx = t % nx;
-    const int u = t / nx;
-    by = u % ny;
-    bzz = u / ny;
-  } else {
-    const int nx = gridDim.x, ny = gridDim.y;
-    const int total = nx * ny * gridDim.z;
-    const int lin = bx + nx * (by + ny * bzz);
-    const int xcd = lin & 7, j = lin >> 3;
-    const int per = total >> 3, rem = total & 7;
-    const int t = xcd * per + min(xcd, rem) + j;
-    bx = t % nx;
-    const int u = t / nx;
-    by = u % ny;
-    bzz = u / ny;
-  }
-  return true;
+// slice): its A row-blocks are then fetched by that XCD only.
+__device__ __forceinline__ void gemm_tile_of_block(int& bx, int& by, int& bzz) {
+  const int nx = gridDim.x, ny = gridDim.y;
+  const int total = nx * ny * gridDim.z;
+  const int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+  const int xcd = lin & 7, j = lin >> 3;
+  const int per = total >> 3, rem = total & 7;
+  const int t = xcd * per + min(xcd, rem) + j;
+  bx = t % nx;
+  const int u = t / nx;
+  by = u % ny;
+  bzz = u / ny;
 }
 
 // Epilogue of both GEMM kernels: acc holds the wave's TM x TN fragments of 16 x 16 (D layout of
@@ -323,7 +304,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
   const int wm = wave >> 1, wn = wave & 1;
 
   int bx, by, bzz;
-  if (!gemm_tile_of_block(g, bx, by, bzz)) return;
+  gemm_tile_of_block(bx, by, bzz);
   const int bz = bzz / g.splitk;
   const int kz = bzz - bz * g.splitk;
   const int m0 = by * BM, n0 = bx * BN;
@@ -542,7 +523,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
   const int r = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   int bx, by, bzz;
-  if (!gemm_tile_of_block(g, bx, by, bzz)) return;
+  gemm_tile_of_block(bx, by, bzz);
   const int bz = bzz / g.splitk;
   const int kz = bzz - bz * g.splitk;
   const int m0 = by * BM, n0 = bx * BN;
@@ -637,12 +618,6 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
   GemmDesc g = gin;
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * g.splitk);
   dim3 block(256);
-  if (g.cls_n) {
-    if (g.cls_lo < 0 || g.cls_n < 1 || g.cls_lo + g.cls_n > 8) return SSASR_EARG;
-    g.gx = (int)grid.x; g.gy = (int)grid.y; g.gz = (int)grid.z;
-    const int64_t total = (int64_t)grid.x * grid.y * grid.z;
-    grid = dim3((unsigned)(8 * ((total + g.cls_n - 1) / g.cls_n)));
-  }
   // split-K launches add their partial products atomically: one float per lane in rows of 16
   // consecutive columns (TR = false); everything else stores 16 bytes per lane (TR = true)
   if (ssasr_options().gemm_x6) {
@@ -712,10 +687,8 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
     if (forced == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
     if (forced == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
   }
-  const int64_t cus = g.cls_n ? 32 * g.cls_n : 256;          // CUs this launch may use
-  // (a class-restricted launch keeps to 64 x 64 tiles: its workgroups of the idle classes must fit
-  // beside a recurrence workgroup to start and exit -- see ssasr_launch_bptt_persistent)
-  if (big < cus || g.cls_n) return launch_tiles<64, 64>(g, vecA, vecB, st);
+  const int64_t cus = 256;
+  if (big < cus) return launch_tiles<64, 64>(g, vecA, vecB, st);
   // Both tile shapes run at 85-110 TF once the chip is full; what differs is how the LAST round of
   // workgroups fills it.  Measured at K = 1024 (tools/gemm_tiles.py), in units of 150 us: 128 x 128
   // tiles, two per CU -- a CU's pair of tiles costs 1.0, a single one 0.9 (0.63 when every CU has at

@@ -20,10 +20,7 @@ int env_flag(const char* name) { return getenv(name) != nullptr; }
 
 void init_options() {
   g_opt.no_persistent = env_flag("SSASR_NO_PERSISTENT");
-  g_opt.persistent_counter = env_flag("SSASR_PERSISTENT_COUNTER");
   g_opt.no_fused_input = env_flag("SSASR_NO_FUSED_INPUT");
-  g_opt.fwd_nb = env_int("SSASR_FWD_NB", 0);
-  g_opt.bptt_gather = env_flag("SSASR_BPTT_GATHER");
   g_opt.bptt_halves_off = env_flag("SSASR_BPTT_HALVES_OFF");
   g_opt.bptt_reserve_kb = env_flag("SSASR_BPTT_SHARED_CU") ? 0 : env_int("SSASR_BPTT_RESERVE_KB", 118);
   g_opt.no_persistent_decoder = env_flag("SSASR_NO_PERSISTENT_DECODER");
@@ -38,21 +35,17 @@ void init_options() {
   g_opt.tail_inline = env_int("SSASR_TAIL_INLINE", 1);
   g_opt.no_residency_check = env_flag("SSASR_NO_RESIDENCY_CHECK");
   g_opt.test_drop_tile = env_int("SSASR_TEST_DROP_TILE", -1);
+  g_opt.test_drop_attn_slice = env_int("SSASR_TEST_DROP_ATTN_SLICE", -1);
+  g_opt.test_drop_dec_slice = env_int("SSASR_TEST_DROP_DEC_SLICE", -1);
   g_opt.attn_rph = env_int("SSASR_ATTN_RPH", 0);
   if (g_opt.attn_rph != 2 && g_opt.attn_rph != 3 && g_opt.attn_rph != 4 && g_opt.attn_rph != 6) g_opt.attn_rph = 0;
   g_opt.no_tsave = env_flag("SSASR_NO_TSAVE");
-  g_opt.bptt_local = env_int("SSASR_BPTT_LOCAL", 0);     // measured slower inside the train step: rnn.hip
-  g_opt.fwd_local = env_int("SSASR_FWD_LOCAL", 0);      // measured equal to the spread form: off
-  g_opt.xcd_round_robin = -1;
 }
 
 struct Named { const char* name; int SsasrOptions::*field; };
 const Named kNames[] = {
     {"SSASR_NO_PERSISTENT", &SsasrOptions::no_persistent},
-    {"SSASR_PERSISTENT_COUNTER", &SsasrOptions::persistent_counter},
     {"SSASR_NO_FUSED_INPUT", &SsasrOptions::no_fused_input},
-    {"SSASR_FWD_NB", &SsasrOptions::fwd_nb},
-    {"SSASR_BPTT_GATHER", &SsasrOptions::bptt_gather},
     {"SSASR_BPTT_HALVES_OFF", &SsasrOptions::bptt_halves_off},
     {"SSASR_BPTT_RESERVE_KB", &SsasrOptions::bptt_reserve_kb},
     {"SSASR_NO_PERSISTENT_DECODER", &SsasrOptions::no_persistent_decoder},
@@ -66,19 +59,11 @@ const Named kNames[] = {
     {"SSASR_TAIL_INLINE", &SsasrOptions::tail_inline},
     {"SSASR_NO_RESIDENCY_CHECK", &SsasrOptions::no_residency_check},
     {"SSASR_TEST_DROP_TILE", &SsasrOptions::test_drop_tile},
+    {"SSASR_TEST_DROP_ATTN_SLICE", &SsasrOptions::test_drop_attn_slice},
+    {"SSASR_TEST_DROP_DEC_SLICE", &SsasrOptions::test_drop_dec_slice},
     {"SSASR_ATTN_RPH", &SsasrOptions::attn_rph},
     {"SSASR_NO_TSAVE", &SsasrOptions::no_tsave},
-    {"SSASR_BPTT_LOCAL", &SsasrOptions::bptt_local},
-    {"SSASR_FWD_LOCAL", &SsasrOptions::fwd_local},
-    {"SSASR_XCD_ROUND_ROBIN", &SsasrOptions::xcd_round_robin},
 };
-
-// One workgroup per block records the XCD it runs on (XCC_ID, 0..7).
-__global__ void xcc_probe_kernel(int32_t* out) {
-  unsigned v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-  if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)(v & 0xf);
-}
 
 }  // namespace
 
@@ -105,46 +90,6 @@ extern "C" int ssasr_get_option(const char* name, int* value) {
   for (const Named& n : kNames)
     if (strcmp(n.name, name) == 0) { *value = g_opt.*(n.field); return SSASR_OK; }
   return SSASR_EARG;
-}
-
-bool ssasr_local_placement() {
-  const SsasrOptions& o = ssasr_options();
-  return o.bptt_local != 0 && o.xcd_round_robin == 1;
-}
-
-void ssasr_gemm_beside_recurrence(GemmDesc& g) {
-  if (ssasr_local_placement()) { g.cls_lo = 4; g.cls_n = 4; }
-}
-
-// XCD-local placement rests on an OBSERVED property of the dispatcher (MI355X_MICROARCH.md): in a
-// 1-D launch, blocks b and b + 8 run on the same XCD and the eight classes b & 7 on eight different
-// XCDs.  The probe checks exactly that on this device, once (a synchronous 2048-workgroup launch on
-// `stream`, a 8 KB scratch allocation of its own: the one place where the library allocates), and
-// keeps the verdict; the K-split BPTT then takes the XCD-local form only if it said yes.  Returns 1
-// (property holds), 0 (it does not; the spread placement stays), or a negative / HIP error code.
-extern "C" int ssasr_probe_placement(void* stream) {
-  std::call_once(g_opt_once, init_options);
-  if (g_opt.xcd_round_robin >= 0) return g_opt.xcd_round_robin;
-  constexpr int NB = 2048;
-  int32_t* dev = nullptr;
-  hipError_t e = hipMalloc(&dev, NB * sizeof(int32_t));
-  if (e != hipSuccess) return -(int)e;
-  int32_t host[NB];
-  hipStream_t st = (hipStream_t)stream;
-  bool ok = true;
-  for (int rep = 0; rep < 3 && ok; ++rep) {
-    hipLaunchKernelGGL(xcc_probe_kernel, dim3(NB), dim3(64), 0, st, dev);
-    e = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(dev); return -(int)e; }
-    unsigned seen = 0;
-    for (int c = 0; c < 8; ++c) seen |= 1u << host[c];
-    ok = seen == 0xffu;                                   // eight classes, eight XCDs
-    for (int b = 8; b < NB && ok; ++b) ok = host[b] == host[b & 7];
-  }
-  (void)hipFree(dev);
-  g_opt.xcd_round_robin = ok ? 1 : 0;
-  return g_opt.xcd_round_robin;
 }
 
 size_t ssasr_lds_reservation_against_gemm(const void* kernel) {

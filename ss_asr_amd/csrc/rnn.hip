@@ -4,7 +4,6 @@
 #include <hip/hip_ext.h>
 #include "../../include/ssasr.h"
 #include "rnn_kernels.h"
-#include "rnn_local.h"
 
 constexpr int SSASR_MAX_SEGMENTS = 8;
 
@@ -46,18 +45,12 @@ static bool grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t w
   return cap <= 0 || workgroups <= cap;
 }
 
-// The XCD-local forward recurrence (rnn_local.h) is taken for its shape when the option is on, the
-// sentinel exchange is selected and the placement probe has confirmed the dispatcher property.
-static bool ssasr_fwd_local_ok(int64_t S, int64_t N, int64_t H) {
-  const SsasrOptions& o = ssasr_options();
-  return o.fwd_local != 0 && o.xcd_round_robin == 1 && !o.no_persistent && !o.persistent_counter && fl_shape_ok(S, N, H);
-}
-
+// Floats of the forward recurrence's exchange image [2][S][H/4][Np][4], Np = N rounded up to whole 128-byte
+// lines (0: the shape has no persistent form).
 extern "C" int64_t ssasr_bilstm_fwd_hx_floats(int64_t S, int64_t N, int64_t H) {
   if (S <= 0 || N <= 0 || H <= 0 || N > 128 || H % 64 != 0) return 0;
   const int64_t Np = (N + 7) & ~(int64_t)7;
-  const int64_t spread = 2 * S * (H / 4) * Np * 4;
-  return fl_shape_ok(S, N, H) && fl_hx_floats(S, N) > spread ? fl_hx_floats(S, N) : spread;
+  return 2 * S * (H / 4) * Np * 4;
 }
 
 // ---------------------------------------------------------------------------
@@ -109,71 +102,35 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   // (2) the recurrence, one launch per step, both directions per launch
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31) || rows * 4 * H >= (1ll << 40)) return SSASR_EARG;
   if (!aligned16(w_hh_f) || !aligned16(w_hh_r) || !aligned16(hs)) return SSASR_EARG;   // 16-byte loads
-  // XCD-local form (rnn_local.h): one exchange group per XCD, one workgroup per CU, h exchanged as
-  // bf16 planes through that XCD's L2 -- when the placement probe has said yes (ssasr_probe_placement)
-  if (ssasr_fwd_local_ok(S, N, H) && hx && sync_ws && aligned16(hx) && aligned16(gates) && (tsave || aligned16(cs)) &&
-      aligned16(y) && ys_s % 4 == 0 && ys_n % 4 == 0) {
-    const bool fuse_in = I == 80 && bih[0] && bhh[0] && bih[1] && bhh[1] && aligned16(x) && aligned16(w_ih_f) &&
-                         aligned16(w_ih_r) && xs_s % 4 == 0 && xs_n % 4 == 0 && !opt.no_fused_input;
-    const void* kfn = fuse_in ? reinterpret_cast<const void*>(lstm_enc_fwd_local_kernel<5>)
-                              : reinterpret_cast<const void*>(lstm_enc_fwd_local_kernel<0>);
-    if (grid_fits(kfn, FWD_THREADS, 0, 8 * FL_TILES)) {
-      if (!fuse_in) {
-        const int rc = input_projection();
-        if (rc) return rc;
-      }
-      EncPersist p{};
-      p.tsave = tsave;
-      p.drop_tile = opt.test_drop_tile;
-      p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
-      p.x = x; p.xs_s = xs_s; p.xs_n = xs_n;
-      for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }
-      p.gates = gates; p.cs = cs; p.hs = hs; p.hx = hx; p.y = y; p.lens = lens;
-      p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
-      p.delay = persist_delay(opt.delay_fwd, 8);
-      p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
-      p.local = 2; p.nchunk = (int)((N + FL_COLS - 1) / FL_COLS);
-      if (!armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)fl_hx_floats(S, N), st));
-      if (fuse_in) hipLaunchKernelGGL(lstm_enc_fwd_local_kernel<5>, dim3(8 * FL_TILES), dim3(FWD_THREADS), 0, st, p);
-      else hipLaunchKernelGGL(lstm_enc_fwd_local_kernel<0>, dim3(8 * FL_TILES), dim3(FWD_THREADS), 0, st, p);
-      SSASR_LAUNCH_CHECK();
-      return SSASR_OK;
-    }
-  }
   // One persistent launch when the whole grid is certain to be resident
   // (rnn_kernels.h, "persistent forward recurrence"); else one launch per step.
   {
     // 16 columns per workgroup spreads a layer over twice the workgroups (shorter
     // product, half the exchange read per workgroup) when they all fit the chip;
-    // else 32 columns.  SSASR_FWD_NB=1|2 forces one for A/B.
+    // else 32 columns.
     const int kpw = (int)(H / 64);
     const int64_t Np = (N + 7) & ~(int64_t)7;
-    int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
-    if (opt.fwd_nb) nb = opt.fwd_nb == 1 ? 1 : 2;
+    const int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
     const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
     bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
                 (H / 4) * 2 * chunks <= 512 && S * Np * H * 4 < (1ll << 31) &&   // <= 2 workgroups per CU
                 aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
                 ys_n % 4 == 0 && !opt.no_persistent;
-    // status words are zero on entry (caller's contract); only the arrival counters of the
-    // counter form need clearing per launch
-    if (sync_ws && opt.persistent_counter) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 4 * sizeof(int32_t), st));
-    // narrow input (the 80 mel bins of the first layer): the persistent kernel's helper wave forms
-    // the pre-activations itself; no input projection GEMM (rnn_kernels.h, KI)
-    const bool sentinel_mode = !opt.persistent_counter;
-    bool fuse_in = fits && sentinel_mode && kpw == 4 && I == 80 && bih[0] && bhh[0] && bih[1] && bhh[1] &&
+    // status words are zero on entry (caller's contract)
+    // narrow input (the 80 mel bins of the first layer): the recurrence waves form the
+    // pre-activations themselves; no input projection GEMM (rnn_kernels.h, KI)
+    bool fuse_in = fits && kpw == 4 && I == 80 && bih[0] && bhh[0] && bih[1] && bhh[1] &&
                    aligned16(x) && aligned16(w_ih_f) && aligned16(w_ih_r) && xs_s % 4 == 0 && xs_n % 4 == 0 &&
                    !opt.no_fused_input;
     // the kernel instance that would run, for the residency check
     const void* kfn = nullptr;
-#define SSASR_FWD_FN(K, SEN, NBT) reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, SEN, NBT>)
-#define SSASR_FWD_FN_PICK(SEN, NBT) \
-    (kpw == 1 ? SSASR_FWD_FN(1, SEN, NBT) : kpw == 2 ? SSASR_FWD_FN(2, SEN, NBT) : kpw == 4 ? SSASR_FWD_FN(4, SEN, NBT) : SSASR_FWD_FN(8, SEN, NBT))
+#define SSASR_FWD_FN(K, NBT) reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, NBT>)
+#define SSASR_FWD_FN_PICK(NBT) \
+    (kpw == 1 ? SSASR_FWD_FN(1, NBT) : kpw == 2 ? SSASR_FWD_FN(2, NBT) : kpw == 4 ? SSASR_FWD_FN(4, NBT) : SSASR_FWD_FN(8, NBT))
     if (fits) {
-      if (fuse_in) kfn = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 1, 5>)
-                                 : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 2, 5>);
-      else if (sentinel_mode) kfn = nb == 1 ? SSASR_FWD_FN_PICK(true, 1) : SSASR_FWD_FN_PICK(true, 2);
-      else kfn = nb == 1 ? SSASR_FWD_FN_PICK(false, 1) : SSASR_FWD_FN_PICK(false, 2);
+      if (fuse_in) kfn = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 1, 5>)
+                                 : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 2, 5>);
+      else kfn = nb == 1 ? SSASR_FWD_FN_PICK(1) : SSASR_FWD_FN_PICK(2);
       if (!grid_fits(kfn, FWD_THREADS, 0, (H / 4) * 2 * chunks)) { fits = false; fuse_in = false; }
     }
 #undef SSASR_FWD_FN_PICK
@@ -193,29 +150,25 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       p.x = x; p.xs_s = xs_s; p.xs_n = xs_n;
       for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }
       p.gates = gates; p.cs = cs; p.hs = hs; p.hx = hx; p.y = y; p.lens = lens;
-      p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
+      p.status = sync_ws + 4;
       p.delay = persist_delay(opt.delay_fwd, 24);
       p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
       dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(FWD_THREADS);   // 4 recurrence waves + the helper
-      // exchange by sentinel (default) or by arrival counter (SSASR_PERSISTENT_COUNTER=1, for A/B)
-      const bool sentinel = sentinel_mode;
-      if (sentinel && !armed)
+      if (!armed)
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * Np * H), st));
-#define SSASR_FWD_LAUNCH(K, SEN, NBT) \
-      hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<K, SEN, NBT>), pgrid, pblock, 0, st, p)
-#define SSASR_FWD_PICK(SEN, NBT)                                    \
+#define SSASR_FWD_LAUNCH(K, NBT) \
+      hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<K, NBT>), pgrid, pblock, 0, st, p)
+#define SSASR_FWD_PICK(NBT)                                         \
       do {                                                          \
-        if (kpw == 1) SSASR_FWD_LAUNCH(1, SEN, NBT);                \
-        else if (kpw == 2) SSASR_FWD_LAUNCH(2, SEN, NBT);           \
-        else if (kpw == 4) SSASR_FWD_LAUNCH(4, SEN, NBT);           \
-        else SSASR_FWD_LAUNCH(8, SEN, NBT);                         \
+        if (kpw == 1) SSASR_FWD_LAUNCH(1, NBT);                     \
+        else if (kpw == 2) SSASR_FWD_LAUNCH(2, NBT);                \
+        else if (kpw == 4) SSASR_FWD_LAUNCH(4, NBT);                \
+        else SSASR_FWD_LAUNCH(8, NBT);                              \
       } while (0)
-      if (fuse_in && nb == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 1, 5>), pgrid, pblock, 0, st, p);
-      else if (fuse_in) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 2, 5>), pgrid, pblock, 0, st, p);
-      else if (sentinel && nb == 1) SSASR_FWD_PICK(true, 1);
-      else if (sentinel) SSASR_FWD_PICK(true, 2);
-      else if (nb == 1) SSASR_FWD_PICK(false, 1);
-      else SSASR_FWD_PICK(false, 2);
+      if (fuse_in && nb == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, 1, 5>), pgrid, pblock, 0, st, p);
+      else if (fuse_in) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, 2, 5>), pgrid, pblock, 0, st, p);
+      else if (nb == 1) SSASR_FWD_PICK(1);
+      else SSASR_FWD_PICK(2);
 #undef SSASR_FWD_PICK
 #undef SSASR_FWD_LAUNCH
       SSASR_LAUNCH_CHECK();
@@ -242,50 +195,57 @@ static bool fwd_persistent_shape_ok(int64_t S, int64_t N, int64_t H) {
   const int kpw = (int)(H / 64);
   if (!(kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8)) return false;
   const int64_t Np = (N + 7) & ~(int64_t)7;
-  int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
-  if (opt.fwd_nb) nb = opt.fwd_nb == 1 ? 1 : 2;
+  const int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
   const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
   if ((H / 4) * 2 * chunks > 512 || S * Np * H * 4 >= (1ll << 31)) return false;
-  const bool sen = !opt.persistent_counter;
-#define SSASR_FN(K, NBT) (sen ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, true, NBT>) \
-                              : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, false, NBT>))
+#define SSASR_FN(K, NBT) reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, NBT>)
   const void* fn = nb == 1 ? (kpw == 1 ? SSASR_FN(1, 1) : kpw == 2 ? SSASR_FN(2, 1) : kpw == 4 ? SSASR_FN(4, 1) : SSASR_FN(8, 1))
                            : (kpw == 1 ? SSASR_FN(1, 2) : kpw == 2 ? SSASR_FN(2, 2) : kpw == 4 ? SSASR_FN(4, 2) : SSASR_FN(8, 2));
 #undef SSASR_FN
   if (!grid_fits(fn, FWD_THREADS, 0, (H / 4) * 2 * chunks)) return false;
-  if (kpw == 4 && sen) {      // the first layer's variant (fused input projection) is the larger kernel
-    const void* ff = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 1, 5>)
-                             : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, true, 2, 5>);
+  if (kpw == 4) {      // the first layer's variant (fused input projection) is the larger kernel
+    const void* ff = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 1, 5>)
+                             : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 2, 5>);
     if (!grid_fits(ff, FWD_THREADS, 0, (H / 4) * 2 * chunks)) return false;
   }
   return true;
 }
 
-// Exchange workspace of the persistent BPTT: the larger of the gather form's
-// per-step image and the K-split form's ring (0: no persistent form for this shape).
+// Exchange workspace of the persistent BPTT: the K-split form's ring (0: no persistent form for this shape).
 extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
   if (S <= 0 || N <= 0 || N > 128 || (H != 64 && H != 128 && H != 256)) return 0;
-  const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
-  const int64_t gather = 2 * S * 4 * H * Np;
-  const int64_t ring = 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;
-  return gather > ring ? gather : ring;
+  const int64_t chunks = (N + 15) / 16;
+  return 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;
 }
 
-// Floats of the K-split form's ring alone, 0 when the shape (or the environment) does not take
-// that form: what a caller that arms several exchange workspaces with one fill has to reserve.
+// Floats of the ring, 0 when the shape (or the environment) does not take the persistent form:
+// what a caller that arms several exchange workspaces with one fill has to reserve.
 extern "C" int64_t ssasr_bilstm_bwd_ring_floats(int64_t S, int64_t N, int64_t H, int64_t dirs) {
   if (dirs < 1 || dirs > 2 || !ssasr_bptt_ksplit_ok(S, N, H, (int)dirs)) return 0;
   return dirs * ((N + 15) / 16) * BWD_RS_RING * (H / 16) * (H / 16) * 256;
 }
 
 // the K-split kernel instance for H (and halves), for the residency check and the launch
-static const void* bptt_rs_fn(int kpw, bool halves, int nw = 4) {
-  (void)nw;
+static const void* bptt_rs_fn(int kpw, bool halves) {
   if (kpw == 4) return reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<1, 1>);
   if (kpw == 8) return halves ? reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 2>)
                               : reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<2, 1>);
   return halves ? reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 2>)
                 : reinterpret_cast<const void*>(lstm_enc_bwd_rs_kernel<4, 1>);
+}
+
+// Dynamic LDS the launch of THAT instance reserves (and never touches) so that no side-stream GEMM workgroup
+// fits beside it on its CU (see "Placement" in ssasr_launch_bptt_persistent).  The option gives the size
+// (SSASR_BPTT_RESERVE_KB, 0 = off); it is RAISED to what the invariant needs -- the instance's own static LDS +
+// reservation + the smallest GEMM workgroup's LDS > 160 KB -- and the instance is the one that is launched:
+// HV = 1 and HV = 2 keep different numbers of gate-derivative stages in LDS.
+static int bptt_reserve_bytes(int kpw, bool halves) {
+  int reserve = ssasr_options().bptt_reserve_kb * 1024;
+  if (reserve) {
+    const size_t need = ssasr_lds_reservation_against_gemm(bptt_rs_fn(kpw, halves));
+    if ((size_t)reserve < need) reserve = (int)need;
+  }
+  return reserve;
 }
 
 // Floats of the tile-major save buffer of a layer, 0 when the shape does not take BOTH persistent
@@ -298,13 +258,11 @@ extern "C" int64_t ssasr_bilstm_tsave_floats(int64_t S, int64_t N, int64_t H) {
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
   const SsasrOptions& opt = ssasr_options();
   const int64_t chunks = (N + 15) / 16;
-  if (!(S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 &&
-        !opt.persistent_counter && !opt.bptt_gather && !opt.no_persistent))
+  if (!(S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 && !opt.no_persistent))
     return false;
   // every workgroup of the one-per-(tile, chunk) grid must be resident (the two-halves grid is checked at launch)
-  const int nw = 4;
-  return grid_fits(bptt_rs_fn((int)(H / 16), false, nw), 64 * (nw + 1), (size_t)opt.bptt_reserve_kb * 1024,
-                   (H / 16) * dirs * chunks);
+  const int kpw = (int)(H / 16);
+  return grid_fits(bptt_rs_fn(kpw, false), 320, (size_t)bptt_reserve_bytes(kpw, false), (H / 16) * dirs * chunks);
 }
 
 int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
@@ -315,107 +273,57 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
   const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
   const int kpw = (int)(H / 16);
   const SsasrOptions& opt = ssasr_options();
-  const bool ksplit = !opt.persistent_counter && !opt.bptt_gather;
   if (i1 <= 0) i1 = S;
   const bool ranged = i0 != 0 || i1 != S;
-  if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && (!ksplit || !dc_state)) || (tsave && !ksplit)) return SSASR_EARG;
-  // every workgroup must be resident: at most one (K-split) per CU; the gather form is kept to two chunks
-  if ((!whhT && !(ksplit && whh_f)) || !gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
-      (ksplit ? (H / 16) * dirs * chunks > 256 : chunks > 2) ||
-      S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) || (!tsave && !aligned16(cs)) ||
-      !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
+  if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && !dc_state)) return SSASR_EARG;
+  // every workgroup must be resident: at most one per CU
+  if ((!whhT && !whh_f) || !gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
+      (H / 16) * dirs * chunks > 256 || S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) ||
+      (!tsave && !aligned16(cs)) || !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
     return SSASR_EARG;
-  if (i0 == 0 && !ksplit) SSASR_HIP(hipMemsetAsync(sync_ws, 0, 4 * sizeof(int32_t), st));   // arrival counters
   EncPersistBwd p{};
   p.i0 = (int)i0; p.i1 = (int)i1; p.dc_state = dc_state;
-  if (ksplit && whh_f && (dirs == 1 || whh_r)) { p.whh[0] = whh_f; p.whh[1] = whh_r; }
+  if (whh_f && (dirs == 1 || whh_r)) { p.whh[0] = whh_f; p.whh[1] = whh_r; }
   p.whhT = whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens; p.tsave = tsave;
-  p.cnt = reinterpret_cast<unsigned*>(sync_ws); p.status = sync_ws + 4;
-  p.delay = persist_delay(opt.delay_bwd, 16);
+  p.status = sync_ws + 4;
+  p.delay = persist_delay(opt.delay_bwd_ksplit, 40);
   p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
   dim3 pgrid((unsigned)(H / 16), (unsigned)dirs, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
-  if (ksplit) {
-    // K-split form: ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
-    const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
-    p.delay = persist_delay(opt.delay_bwd_ksplit, 40);
-    // LDS reservation that keeps side-stream GEMM workgroups off this kernel's CUs (see "Placement" below).
-    // The option gives its size (SSASR_BPTT_RESERVE_KB, 0 = off); it is RAISED to what the invariant needs
-    // -- own static LDS + reservation + the smallest GEMM workgroup's LDS > 160 KB -- so that a change of
-    // the GEMM's tile or of this kernel's LDS cannot silently break the separation.
-    int reserve = opt.bptt_reserve_kb * 1024;
-    if (reserve) {
-      const size_t need = ssasr_lds_reservation_against_gemm(bptt_rs_fn(kpw, kpw >= 8, 4));
-      if ((size_t)reserve < need) reserve = (int)need;
-    }
-    // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
-    // (not for launches of fewer than three steps: see the note on in-place rows in rnn_kernels.h)
-    // (Eight recurrence waves per workgroup -- two partial tiles loaded and one unit tile multiplied per
-    // wave instead of four and two: lstm_enc_bwd_rs_kernel<4, HV, 8> -- measured the same alone (2.35
-    // against 2.33 us per step) and 0.5 % slower in the train step; not instantiated.)
-    const int nw = 4;                                                     // recurrence waves per workgroup (+ 1 helper)
-    pblock = dim3((unsigned)(64 * (nw + 1)));
-    const bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && i1 - i0 >= 3 && !opt.bptt_halves_off &&
-                        grid_fits(bptt_rs_fn(kpw, true, nw), 64 * (nw + 1), (size_t)reserve, (H / 16) * dirs * chunks * 2);
-    if (!halves && !grid_fits(bptt_rs_fn(kpw, false, nw), 64 * (nw + 1), (size_t)reserve, (H / 16) * dirs * chunks))
-      return SSASR_EARG;
-    if (i0 == 0 && !armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
-    if (halves) pgrid.z *= 2;
-    // XCD-local placement (rnn_kernels.h, persist_role; OFF by default, SSASR_BPTT_LOCAL=1): the <= 4
-    // exchange groups (direction, column chunk) of a layer on XCDs 0..3, one group per XCD, hand-offs
-    // through that XCD's L2; side-stream GEMMs then keep to XCDs 4..7 (ssasr_gemm_beside_recurrence).
-    // Needs the whole group on one XCD: (H / 16) * halves <= 32 workgroups, one per CU.
-    // Measured (tools/persistbench LOCAL=1, S = 400, N = 32): alone the kernel runs 2.52 -> 2.08 us per
-    // step (operand loads 0.72 -> 0.56, store -> release 0.40 -> 0.08); INSIDE the train step it loses,
-    // 6.7 -> 7.75 ms: a class-restricted GEMM still deals half of its workgroups to XCDs 0..3, where
-    // each has to be placed beside a recurrence workgroup just to exit (BPTT launches 220 -> 287 us,
-    // weight-gradient GEMMs 50 -> 81 us on their four XCDs); unrestricted GEMMs queue behind the
-    // recurrence instead (9.0 ms).  Kept as a measured alternative, covered by
-    // tests/test_gpu_model.py::test_backward_matches_reference_in_both_bptt_placements.
-    const int hv = halves ? 2 : 1;
-    int reserve_now = reserve;
-    if (ssasr_local_placement() && dirs * chunks <= 4 && (H / 16) * hv <= 32) {
-      p.local = dirs; p.nchunk = (int)chunks;
-      pgrid = dim3((unsigned)(8 * (H / 16) * hv), 1, 1);
-      // A `beside` GEMM is a 1-D launch of which the classes 0..3 exit at once -- but even those
-      // workgroups must first be PLACED on a CU of XCDs 0..3, all of which this launch occupies:
-      // with 118 KB reserved they (36 KB of static LDS) queue until the recurrence ends, and the
-      // whole GEMM behind them (measured: 6.8 -> 9.0 ms per train step).  40 KB stay free: room for
-      // one 64 x 64-tile workgroup to start and exit, never for a second recurrence workgroup.
-      if (reserve_now > 40 * 1024) reserve_now -= 40 * 1024;
-    }
-    // (a range shorter than the hand-off distance between the two halves could rewrite dc_state early)
-    if (halves && ranged && i1 < S && i1 - i0 < 4) return SSASR_EARG;
-    // Placement: the weight-gradient GEMMs of the previous range / layer run beside this kernel on
-    // the second stream.  A GEMM workgroup that shares a CU with a recurrence workgroup slows every
-    // step of it (shared MFMA pipe, LDS and memory pipeline): 2.4 -> 3.3 us per step.  The launch
-    // therefore reserves dynamic LDS it never touches, so that its 30-38 KB + 118 KB leave no room for
-    // a GEMM workgroup (36 KB) on the same CU: the GEMMs get the other CUs, the recurrence runs at
-    // its standalone speed (+4-5 % on the train step).  SSASR_BPTT_SHARED_CU=1 turns it off.
-    // (the attribute is a property of the loaded code object: setting it again is idempotent and costs
-    // no device work)
-    if (reserve) SSASR_HIP(hipFuncSetAttribute(bptt_rs_fn(kpw, halves, nw), hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
-    // stop_event: the range's completion event rides on the dispatch's own completion signal instead of a
-    // hipEventRecord behind it (a barrier packet between two ranges cost 6-7 us of idle stream each)
-    hipEvent_t stop = (hipEvent_t)stop_event;
-#define SSASR_RS_LAUNCH(TPW_, HV_) hipExtLaunchKernelGGL((lstm_enc_bwd_rs_kernel<TPW_, HV_>), pgrid, pblock, (unsigned)reserve_now, st, nullptr, stop, 0u, p)
-    if (kpw == 4) SSASR_RS_LAUNCH(1, 1);
-    else if (kpw == 8 && halves) SSASR_RS_LAUNCH(2, 2);
-    else if (kpw == 8) SSASR_RS_LAUNCH(2, 1);
-    else if (halves) SSASR_RS_LAUNCH(4, 2);
-    else SSASR_RS_LAUNCH(4, 1);
-#undef SSASR_RS_LAUNCH
-  } else if (!opt.persistent_counter) {
-    SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)(dirs * S * 4 * H * Np), st));
-    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, true>), pgrid, pblock, 0, st, p);
-    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, true>), pgrid, pblock, 0, st, p);
-    else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), pgrid, pblock, 0, st, p);
-  } else {
-    if (kpw == 4) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<4, false>), pgrid, pblock, 0, st, p);
-    else if (kpw == 8) hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<8, false>), pgrid, pblock, 0, st, p);
-    else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, false>), pgrid, pblock, 0, st, p);
+  // ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
+  const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
+  // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
+  // (not for launches of fewer than three steps: see the note on in-place rows in rnn_kernels.h)
+  bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && i1 - i0 >= 3 && !opt.bptt_halves_off;
+  int reserve = bptt_reserve_bytes(kpw, halves);
+  if (halves && !grid_fits(bptt_rs_fn(kpw, true), 320, (size_t)reserve, (H / 16) * dirs * chunks * 2)) {
+    halves = false;
+    reserve = bptt_reserve_bytes(kpw, false);
   }
+  if (!halves && !grid_fits(bptt_rs_fn(kpw, false), 320, (size_t)reserve, (H / 16) * dirs * chunks)) return SSASR_EARG;
+  if (i0 == 0 && !armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
+  if (halves) pgrid.z *= 2;
+  // (a range shorter than the hand-off distance between the two halves could rewrite dc_state early)
+  if (halves && ranged && i1 < S && i1 - i0 < 4) return SSASR_EARG;
+  // Placement: the weight-gradient GEMMs of the previous range / layer run beside this kernel on
+  // the second stream.  A GEMM workgroup that shares a CU with a recurrence workgroup slows every
+  // step of it (shared MFMA pipe, LDS and memory pipeline): 2.4 -> 3.3 us per step.  The launch
+  // therefore reserves dynamic LDS it never touches, so that its 30-38 KB + 118 KB leave no room for
+  // a GEMM workgroup (36 KB) on the same CU: the GEMMs get the other CUs, the recurrence runs at
+  // its standalone speed (+4-5 % on the train step).  SSASR_BPTT_SHARED_CU=1 turns it off.
+  // (the attribute is a property of the loaded code object: setting it again is idempotent and costs
+  // no device work)
+  if (reserve) SSASR_HIP(hipFuncSetAttribute(bptt_rs_fn(kpw, halves), hipFuncAttributeMaxDynamicSharedMemorySize, reserve));
+  // stop_event: the range's completion event rides on the dispatch's own completion signal instead of a
+  // hipEventRecord behind it (a barrier packet between two ranges cost 6-7 us of idle stream each)
+  hipEvent_t stop = (hipEvent_t)stop_event;
+#define SSASR_RS_LAUNCH(TPW_, HV_) hipExtLaunchKernelGGL((lstm_enc_bwd_rs_kernel<TPW_, HV_>), pgrid, pblock, (unsigned)reserve, st, nullptr, stop, 0u, p)
+  if (kpw == 4) SSASR_RS_LAUNCH(1, 1);
+  else if (kpw == 8 && halves) SSASR_RS_LAUNCH(2, 2);
+  else if (kpw == 8) SSASR_RS_LAUNCH(2, 1);
+  else if (halves) SSASR_RS_LAUNCH(4, 2);
+  else SSASR_RS_LAUNCH(4, 1);
+#undef SSASR_RS_LAUNCH
   SSASR_LAUNCH_CHECK();
-  if (stop_event && !ksplit) SSASR_HIP(hipEventRecord((hipEvent_t)stop_event, st));   // (only the K-split launch carries it itself)
   return SSASR_OK;
 }
 
@@ -444,7 +352,7 @@ static int bilstm_bwd_impl(bool armed, const float* tsave, const float* dy, int6
   float* db[2] = {db_f, db_r};
   int rc;
 
-  // the K-split persistent kernel reads W_hh as it is; every other form wants the transposed copy
+  // the persistent kernel reads W_hh as it is; the per-step form wants the transposed copy
   const bool direct = gx && sync_ws && w_hh_f && w_hh_r && ssasr_bptt_ksplit_ok(S, N, H, 2);
   bool transposed = false;
   auto transpose_whh = [&]() -> int {
@@ -461,10 +369,9 @@ static int bilstm_bwd_impl(bool armed, const float* tsave, const float* dy, int6
   // (rnn_kernels.h, "persistent backward recurrence"), else one launch per step.
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31)) return SSASR_EARG;
   bool persistent = false;
-  if (gx && sync_ws && !ssasr_options().no_persistent) {
-    rc = ssasr_launch_bptt_persistent(direct ? nullptr : ws_whhT, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H,
-                                      2, st, 0, 0, nullptr, direct ? w_hh_f : nullptr, direct ? w_hh_r : nullptr,
-                                      armed && direct, tsave);
+  if (direct) {
+    rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H,
+                                      2, st, 0, 0, nullptr, w_hh_f, w_hh_r, armed, tsave);
     if (rc == SSASR_OK) persistent = true;
     else if (rc != SSASR_EARG) return rc;
   }
@@ -494,7 +401,7 @@ static int bilstm_bwd_impl(bool armed, const float* tsave, const float* dy, int6
   }
   if (!dw_ih_f) return SSASR_OK;      // weight gradients deferred to ssasr_bilstm_wgrad
   return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, nullptr, dw_ih_r,
-                            dw_hh_r, db_r, nullptr, 0, 0, stream);
+                            dw_hh_r, db_r, nullptr, 0, stream);
 }
 
 extern "C" int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
@@ -548,7 +455,7 @@ extern "C" int ssasr_events_destroy(void* handle) {
 // outputs (which the caller zeroed if needed).
 static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgates, const float* x, int64_t xs_s,
                            int64_t xs_n, const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
-                           float* dwih, float* dwhh, float* db, float* db2, hipStream_t st, bool beside) {
+                           float* dwih, float* dwhh, float* db, float* db2, hipStream_t st) {
   const int64_t rows = S * N;
   const float* dG = dgates + d * rows * 4 * H;
   int rc;
@@ -564,7 +471,6 @@ static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgate
     int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
     if (g.K < 64 * sk) sk = 1;
     g.splitk = sk;
-    if (beside) ssasr_gemm_beside_recurrence(g);
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   {           // dW_hh += sum_s dG[s]^T . h[s_prev],  s_prev = s - 1 (forward direction) or s + 1 (reverse)
@@ -581,8 +487,7 @@ static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgate
       int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
       if (g.K < 64 * sk) sk = 1;
       g.splitk = sk;
-      if (beside) ssasr_gemm_beside_recurrence(g);
-      if ((rc = ssasr_launch_gemm(g, st))) return rc;
+        if ((rc = ssasr_launch_gemm(g, st))) return rc;
     }
   }
   return ssasr_launch_colsum(dG + s_lo * N * 4 * H, (s_hi - s_lo) * N, (int)(4 * H), 4 * H, db, st, db2);
@@ -595,16 +500,16 @@ static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgate
 static int wgrad_pair_range(int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1, const float* dgates, const float* x,
                             int64_t xs_s, int64_t xs_n, const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
                             float* const dwih[2], float* const dwhh[2], float* const db[2], float* const db2[2],
-                            hipStream_t st, bool beside) {
+                            hipStream_t st) {
   const int64_t rows = S * N;
   // the recurrent product skips the step without a predecessor: s = 0 (forward) / s = S - 1 (reverse)
   const int64_t a0f = lo0 > 1 ? lo0 : 1, a1f = hi0;
   const int64_t a0r = lo1, a1r = hi1 < S - 1 ? hi1 : S - 1;
   const bool same = hi0 - lo0 == hi1 - lo1 && a1f - a0f == a1r - a0r && hi0 > lo0;
   if (!same) {
-    int rc = wgrad_dir_range(0, lo0, hi0, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[0], dwhh[0], db[0], db2[0], st, beside);
+    int rc = wgrad_dir_range(0, lo0, hi0, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[0], dwhh[0], db[0], db2[0], st);
     if (rc) return rc;
-    return wgrad_dir_range(1, lo1, hi1, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], st, beside);
+    return wgrad_dir_range(1, lo1, hi1, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], st);
   }
   int rc;
   {           // dW_ih[d] += dG_d[range_d]^T . X[range_d]
@@ -621,7 +526,6 @@ static int wgrad_pair_range(int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1, 
     int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
     if (g.K < 64 * sk) sk = 1;
     g.splitk = sk;
-    if (beside) ssasr_gemm_beside_recurrence(g);
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   if (a1f > a0f) {           // dW_hh[d] += sum_s dG_d[s]^T . h_d[s_prev]
@@ -638,7 +542,6 @@ static int wgrad_pair_range(int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1, 
     int sk = (int)(512 / tiles); if (sk < 1) sk = 1; if (sk > 32) sk = 32;
     if (g.K < 64 * sk) sk = 1;
     g.splitk = sk;
-    if (beside) ssasr_gemm_beside_recurrence(g);
     if ((rc = ssasr_launch_gemm(g, st))) return rc;
   }
   if ((rc = ssasr_launch_colsum(dgates + lo0 * N * 4 * H, (hi0 - lo0) * N, (int)(4 * H), 4 * H, db[0], st, db2[0]))) return rc;
@@ -649,7 +552,7 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
                                   const float* hs, int64_t S, int64_t N, int64_t I, int64_t H,
                                   float* dw_ih_f, float* dw_hh_f, float* db_f, float* db2_f,
                                   float* dw_ih_r, float* dw_hh_r, float* db_r, float* db2_r,
-                                  int accumulate, int beside, void* stream) {
+                                  int accumulate, void* stream) {
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dgates || !x || !hs) return SSASR_EARG;
   if (!dw_ih_f || !dw_hh_f || !db_f || !dw_ih_r || !dw_hh_r || !db_r) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
@@ -664,8 +567,7 @@ extern "C" int ssasr_bilstm_wgrad(const float* dgates, const float* x, int64_t x
       SSASR_HIP(hipMemsetAsync(db[d], 0, sizeof(float) * 4 * H, st));
       if (db2[d]) SSASR_HIP(hipMemsetAsync(db2[d], 0, sizeof(float) * 4 * H, st));
     }
-    const int rc = wgrad_dir_range(d, 0, S, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[d], dwhh[d], db[d], db2[d], st,
-                                   beside != 0);
+    const int rc = wgrad_dir_range(d, 0, S, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[d], dwhh[d], db[d], db2[d], st);
     if (rc) return rc;
   }
   return SSASR_OK;
@@ -759,7 +661,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     SSASR_HIP(hipEventRecord(ev, st));
     SSASR_HIP(hipStreamWaitEvent(side, ev, 0));
     return ssasr_bilstm_wgrad(gates, x, xs_s, xs_n, hs, S, N, I, H, dw_ih_f, dw_hh_f, db_f, db2_f, dw_ih_r, dw_hh_r,
-                              db_r, db2_r, 1, 1, side_stream);
+                              db_r, db2_r, 1, side_stream);
   }
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || !dy || !x || !gates || (!cs && !tsave) || !hs || !ws_whhT || !ws_dc)
     return SSASR_EARG;
@@ -822,7 +724,7 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     }
     // iterations [i0, i1) cover steps S - i1 .. S - i0 - 1 of the forward direction and i0 .. i1 - 1 of the reverse
     if ((rc = wgrad_pair_range(S - i1, S - i0, i0, i1, gates, x, xs_s, xs_n, hs, S, N, I, H, dwih, dwhh, db, db2,
-                               inl ? st : side, !inl)))
+                               inl ? st : side)))
       return rc;
   }
   return SSASR_OK;

@@ -338,21 +338,18 @@ __global__ __launch_bounds__(256) void lstm_enc_fwd_kernel(EncFwd e, int i) {
 // workgroup reads only h_{s-1}.
 //
 // Exchange of h between the H/4 workgroups of one (direction, column chunk)
-// group follows MI355X_MICROARCH.md "Valid forms" (third table row) and
-// cdna_hip_programming.md Guideline 16: the payload is stored write-through
-// (sc1 buffer stores, every 128-byte line written whole by one store
-// instruction of one wave: the exchange image is [step][unit tile][column][4]),
-// the storing wave drains its stores (s_waitcnt vmcnt(0)) and then one lane
-// adds 1 to the group's monotonic arrival counter (agent-scope atomic); a
-// consumer polls that counter with relaxed agent-scope loads until it reaches
-// (H/4) * step, passes a workgroup barrier, and reads the payload with sc1
-// buffer loads only (L1 is bypassed; no acquire fence needed).  Every step
-// uses fresh addresses; counters are zeroed by a memset node before launch.
+// group (MI355X_MICROARCH.md "Valid forms", cdna_hip_programming.md Guideline 16):
+// the payload is stored write-through (sc1 buffer stores, every 128-byte line
+// written whole by one store instruction of one wave: the exchange image is
+// [step][unit tile][column][4]) into an image the host pre-filled with
+// PERSIST_SENTINEL, and read with sc1 buffer loads that verify themselves (see
+// PersistPacer below).  Every step uses fresh addresses.  (The textbook variant
+// -- drain, agent-scope arrival counter, poll -- ran 3.3 against 2.9 us per step
+// in round 1 and was removed in round 4 together with the XCD-local placements,
+// which measured no faster inside the train step: DESIGN.md 4.2.)
 // Correctness does not depend on placement; progress needs every workgroup
-// of a group resident, which the host guarantees by only taking this path for
-// grids of at most 256 workgroups of 256 threads (<= 256 VGPRs: two such
-// workgroups fit one CU, so 128 free CUs suffice).  Spins are bounded; a
-// timeout sets *status and the kernel still terminates.
+// of a group resident, which the host guarantees (ssasr_resident_capacity).
+// Spins are bounded; a timeout sets *status and the kernel still terminates.
 struct EncPersist {
   const float* whh[2];   // [4H][H] per direction
   float* gates;          // [2][S*N][4H]
@@ -361,8 +358,7 @@ struct EncPersist {
   float* hx;             // [2][S][H/4][Np][4] exchange image, Np = N rounded up to 8
   float* y;
   const int32_t* lens;
-  unsigned* cnt;         // [2][chunks] arrival counters, zero at launch
-  int* status;           // set to 1 if a spin timed out
+  int* status;           // set (persist_code) if a spin timed out
   int delay;             // initial pacing delay (PersistPacer)
   int ys_s, ys_n;
   int S, N, H;
@@ -382,9 +378,6 @@ struct EncPersist {
   // step, whole 128-byte lines (tsave_index).  When given, the row-major `gates` / `cs` are NOT
   // written: the pre-activations stay in `gates`, which the BPTT later overwrites with derivatives.
   float* tsave;
-  // XCD-local placement (see persist_role): != 0 = the number of directions; the launch is 1-D,
-  // 8 * (H / 4) workgroups, and `nchunk` column chunks x directions <= 8 exchange groups are dealt one to an XCD
-  int local, nchunk;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -397,41 +390,20 @@ __device__ __forceinline__ int64_t tsave_index(int d, int s, int chunk16, int ti
   return (((((int64_t)d * S + s) * C16 + chunk16) * T16 + tile16) * 5 + a) * 256;
 }
 
-// Which part of a persistent recurrence a workgroup runs.
-// Spread placement (local == 0): grid (tiles, directions, chunks [* halves]); the workgroups of an
-// exchange group (one direction, one column chunk) land on all 8 XCDs, so their hand-offs go
-// through the fabric: write-through (sc1) stores, sc1 loads, ~1.3 us store -> visible -> load.
-// XCD-local placement (local != 0): workgroups are dealt to the XCDs round-robin in launch order
-// (MI355X_MICROARCH.md: blocks b and b + 8 share an XCD), so in a 1-D launch the blocks with equal
-// (index & 7) sit on ONE XCD.  Class c < groups becomes exchange group c (workgroup index >> 3
-// inside it), classes >= groups exit at once.  Within an XCD the L2 is coherent: the group's
-// hand-offs are PLAIN stores (the line stays in that L2) read by sc1 loads (L1 bypassed, L2 hit).
-// Placement is still only a speed matter for CORRECT DATA -- a load can never return anything but
-// the fill pattern or the value stored -- but a group that straddled XCDs would wait for ever on
-// lines that never leave the other L2: the launchers take this form only behind the probe of
-// ssasr_xcd_round_robin() and every wait is bounded (persist_give_up).
+// Which part of a persistent recurrence a workgroup runs: grid (tiles, directions, chunks [* halves]).
+// The workgroups of an exchange group (one direction, one column chunk) land on all 8 XCDs, so their
+// hand-offs go through the fabric: write-through (sc1) stores, sc1 loads, ~1.0 us store -> visible -> load
+// (measured not to depend on where the producer sits: DESIGN.md 4.2, round 3).
 struct PersistRole {
   int tile, d, chunk, half, nchunk;
-  bool live;
 };
-__device__ __forceinline__ PersistRole persist_role(int local, int nchunk_local, int hv) {
+__device__ __forceinline__ PersistRole persist_role(int hv) {
   PersistRole r;
-  if (local) {
-    const int lin = blockIdx.x, cls = lin & 7, idx = lin >> 3;
-    r.nchunk = nchunk_local;
-    r.live = cls < local * nchunk_local;           // local = number of directions in the launch (1 or 2)
-    r.d = cls / nchunk_local;
-    r.chunk = cls - r.d * nchunk_local;
-    r.tile = idx / hv;
-    r.half = idx - r.tile * hv;
-  } else {
-    r.nchunk = gridDim.z / hv;
-    r.live = true;
-    r.tile = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // xcd_grouped_tile
-    r.d = blockIdx.y;
-    r.chunk = blockIdx.z / hv;
-    r.half = blockIdx.z % hv;
-  }
+  r.nchunk = gridDim.z / hv;
+  r.tile = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // xcd_grouped_tile
+  r.d = blockIdx.y;
+  r.chunk = blockIdx.z / hv;
+  r.half = blockIdx.z % hv;
   return r;
 }
 
@@ -461,7 +433,7 @@ constexpr unsigned PERSIST_SENTINEL = 0x7FC0DEADu;   // a NaN: h = o * tanh(c) c
 // would spin out its own second: a launch with ONE missing producer ran for minutes on NaN data
 // (ADVICE r1); with it the launch drains in milliseconds and the status word tells the host which
 // kernel, workgroup and step gave up first (ops.describe_status).
-enum { PK_ENC_FWD = 1, PK_ENC_BPTT = 2, PK_ENC_BPTT_GATHER = 3, PK_DEC_FWD = 4, PK_DEC_CHAIN = 5 };
+enum { PK_ENC_FWD = 1, PK_ENC_BPTT = 2, PK_DEC_FWD = 4, PK_DEC_CHAIN = 5 };
 __device__ __forceinline__ int persist_code(int kernel, int step) {
   const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   return (int)(0x40000000u | ((unsigned)kernel << 24) | ((wg & 0xfffu) << 12) | ((unsigned)step & 0xfffu));
@@ -474,12 +446,10 @@ __device__ __forceinline__ bool persist_give_up(unsigned tries, int* status, int
   return (tries & 255u) == 8u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
-// SENTINEL = true: no arrival counter.  The host pre-fills the exchange image
-// with PERSIST_SENTINEL; a consumer first polls one 16-byte piece per producer
-// tile, then loads its operands and re-loads until no element is the sentinel.
-// That removes the producer's store drain, the atomic and the counter poll
-// from the per-step critical path.
-// Pacing of the operand loads (SENTINEL mode).  Polling the exchange image costs
+// No arrival counter, no flag, no fence: the host pre-fills the exchange image with PERSIST_SENTINEL and
+// a consumer's operand loads verify themselves (any 16-byte piece that still holds the pattern is
+// re-fetched).
+// Pacing of the operand loads.  Polling the exchange image costs
 // fabric requests that slow down the very stores it waits for (measured: any
 // probe cadence is slower than none), so nothing polls: after a step closes,
 // the helper wave sleeps `delay` x 64 cycles, releases the operand loads through
@@ -511,8 +481,7 @@ struct PersistPacer {
 
 // Five waves.  Waves 0-3 own the recurrence (operand loads, matrix product;
 // waves 0 and 1 the gate epilogue, wave 0 the publishing store).  Wave 4 is a
-// helper: it paces the operand loads (SENTINEL: PersistPacer; else it polls the
-// arrival counter) and releases them through a barrier; one step ahead it
+// helper: it paces the operand loads (PersistPacer) and releases them through a barrier; one step ahead it
 // streams the step's input->hidden pre-activations from HBM into LDS, and one
 // step behind it writes the row-major copies of the results (gates, c, h, y),
 // so that no HBM latency, no scattered store and no address arithmetic for
@@ -530,7 +499,7 @@ struct PersistPacer {
 // at once) it shares SIMD 1 with a wave that only loads and multiplies.
 constexpr int FWD_HELPER_WAVE = SSASR_FWD_HELPER_WAVE;
 constexpr int FWD_THREADS = 64 * (FWD_HELPER_WAVE + 1);
-template <int KPW, bool SENTINEL, int NB, int KI = 0>   // k-blocks per wave = H / 64; NB x 16 batch columns per workgroup
+template <int KPW, int NB, int KI = 0>   // k-blocks per wave = H / 64; NB x 16 batch columns per workgroup
 __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(EncPersist e) {
   __shared__ __attribute__((aligned(16))) f32x4 red[4 * NB * 64];
   // step results staged for the helper wave: [i, f, g, o, c, h][column][4 units]
@@ -543,16 +512,12 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
   if (tid == 0) missed = 0;
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
-  const PersistRole role = persist_role(e.local, e.nchunk, 1);
-  if (!role.live) return;
+  const PersistRole role = persist_role(1);
   const int tile = role.tile, d = role.d, chunk = role.chunk;
-  const bool local = e.local != 0;
   const int S = e.S, N = e.N, H = e.H;
   const int n0 = chunk * 16 * NB;
   const int Np = (N + 7) & ~7;                 // image columns: 128-byte lines never shared by two tiles
-  const unsigned ntile = (unsigned)(H / 4);
   const int64_t rows = (int64_t)S * N;
-  unsigned* cnt = e.cnt + d * role.nchunk + chunk;
   float* gbase = e.gates + (int64_t)d * rows * 4 * H;
   const size_t xbytes = (size_t)S * Np * H * sizeof(float);
   float* xbase = e.hx + (int64_t)d * S * Np * H;
@@ -644,16 +609,7 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
     for (int i = 0; i < S; ++i) {
       if (i > 0) {
         SSASR_PTRACE_H(i, 8);
-        if (SENTINEL) {
-          pacer.sleep();
-        } else if (lane == 0) {
-          const unsigned target = ntile * (unsigned)i;
-          unsigned spins = 0;
-          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (persist_give_up(++spins, e.status, persist_code(PK_ENC_FWD, i))) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
+        pacer.sleep();
         SSASR_PTRACE_H(i, 9);
         __syncthreads();                              // operand loads released
       }
@@ -661,7 +617,7 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
       if (KI == 0 && i + 1 < S) { publish(i + 1); if (i + 2 < S) fetch(i + 2); }
       if (i > 0) flush(i - 1);                        // stage is rewritten after the next barrier
       __syncthreads();                                // product done
-      if (SENTINEL && i > 0) { pacer.update(missed != 0); missed = 0; }
+      if (i > 0) { pacer.update(missed != 0); missed = 0; }
       __syncthreads();                                // epilogue done
     }
     flush(S - 1);
@@ -756,27 +712,25 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
             else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wiq[j], xcur[t][j], acc[t], 0, 0, 0);
           }
       }
-      if (SENTINEL) {
-        // re-fetch any piece that still holds the fill pattern
-        for (unsigned tries = 0;; ++tries) {
-          bool anybad = false;
+      // re-fetch any piece that still holds the fill pattern
+      for (unsigned tries = 0;; ++tries) {
+        bool anybad = false;
 #pragma unroll
-          for (int j = 0; j < KPW; ++j) {
-            const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);
+        for (int j = 0; j < KPW; ++j) {
+          const unsigned koff = (unsigned)((wave + 4 * j) * 4 * Np * 16);
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-              const bool bad = raw[j][t].x == PERSIST_SENTINEL || raw[j][t].y == PERSIST_SENTINEL ||
-                               raw[j][t].z == PERSIST_SENTINEL || raw[j][t].w == PERSIST_SENTINEL;
-              if (__any(bad)) {
-                anybad = true;
-                raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, 16);
-              }
+          for (int t = 0; t < NB; ++t) {
+            const bool bad = raw[j][t].x == PERSIST_SENTINEL || raw[j][t].y == PERSIST_SENTINEL ||
+                             raw[j][t].z == PERSIST_SENTINEL || raw[j][t].w == PERSIST_SENTINEL;
+            if (__any(bad)) {
+              anybad = true;
+              raw[j][t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo[t] + koff), (int)sbase, 16);
             }
           }
-          if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
-          if (persist_give_up(tries, e.status, persist_code(PK_ENC_FWD, i))) break;
-          __builtin_amdgcn_s_sleep(2);
         }
+        if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
+        if (persist_give_up(tries, e.status, persist_code(PK_ENC_FWD, i))) break;
+        __builtin_amdgcn_s_sleep(2);
       }
       SSASR_PTRACE(i, 3);
       // NB: convert the whole vector at once; __builtin_bit_cast on a single
@@ -841,16 +795,10 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         u32x4 pv = {__builtin_bit_cast(unsigned, hv.x), __builtin_bit_cast(unsigned, hv.y),
                     __builtin_bit_cast(unsigned, hv.z), __builtin_bit_cast(unsigned, hv.w)};
-        if (local) __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
-                                                          (int)((int64_t)s * Np * H * 4), 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
-                                                    (int)((int64_t)s * Np * H * 4), 16);
+        __builtin_amdgcn_raw_buffer_store_b128(pv, xrs, (int)((tile * Np + n0 + lane) * 16),
+                                               (int)((int64_t)s * Np * H * 4), 16);
       }
       SSASR_PTRACE(i, 7);
-      if (!SENTINEL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
   }
 }
@@ -994,273 +942,31 @@ __global__ __launch_bounds__(256) void lstm_enc_bwd_kernel(EncBwd e, int i) {
 }
 
 // --------------------- persistent backward recurrence ----------------------
-// BPTT of one layer in one launch, same hand-off protocol as the forward
-// kernel.  A workgroup owns 16 hidden units x 16 columns; its slice of W_hh^T
-// (16 rows x 4H, 64 KB at H = 256) stays in registers, the cell-state
-// derivative of its (unit, column) pairs stays in registers, and per step it
-// reads the 16 x 4H gate derivatives of its column chunk that the H/16
-// workgroups of its (direction, chunk) group published one step earlier.
-// Exchange image per step: [k-block = gate * H/16 + unit tile][q][Np][4]
-// floats, so that a consumer lane's 16-byte read (4 consecutive k) and a
-// producer wave's 16-byte-per-lane store are both contiguous over the 16
-// columns (256 bytes = two whole 128-byte lines per (k-block, q)).
+// BPTT of one layer in one launch, same hand-off protocol as the forward kernel.  A workgroup owns 16
+// hidden units x 16 columns.  (The first form -- every workgroup multiplying the group's whole 16 x 4H
+// gate-derivative image of the previous step into its own units, 64 KB read per workgroup and step --
+// was bounded by that read: 3.45 against 3.05 us per step for the K-split form below; removed in round 4.)
 struct EncPersistBwd {
-  const float* whhT;     // [2][H][4H]
+  const float* whhT;     // [dirs][H][4H] transposed weights, used when whh[] is null
   float* gates;          // [2][S*N][4H]: activated gates in, gate derivatives out (row-major)
   const float* cs;       // [2][S*N][H]
   const float* dy;
-  float* gx;             // [2][S][H/4][4][Np][4] exchange image
+  float* gx;             // exchange ring [dir][chunk][BWD_RS_RING][dest tile][source tile][64 lanes][4]
   const int32_t* lens;
-  unsigned* cnt;         // [2][chunks]
   int* status;
   int delay;             // initial pacing delay (PersistPacer)
   int ys_s, ys_n;
   int S, N, H;
-  // K-split form only: iterations [i0, i1) of the S steps in this launch (i1 = 0 means S).
+  // iterations [i0, i1) of the S steps in this launch (i1 = 0 means S).
   // A launch that does not start at 0 resumes the cell-state derivative from dc_state
   // [2][N][H] and the partial tiles from the ring; one that stops early leaves both.
   int i0, i1;
   float* dc_state;
-  const float* whh[2];   // K-split form: the untransposed [4H][H] weights per direction (whhT unused) or null
-  int local, nchunk;     // K-split form: XCD-local placement (persist_role): local = directions, 1-D launch of 8 * (H / 16) * HV workgroups
-  // K-split form: tile-major saved gates and cell states written by the forward kernel (EncPersist::tsave)
+  const float* whh[2];   // the untransposed [4H][H] weights per direction (whhT unused) or null
+  // tile-major saved gates and cell states written by the forward kernel (EncPersist::tsave)
   // or null (then `gates` / `cs` hold them row-major and `gates` is overwritten in place)
   const float* tsave;
 };
-
-template <int KPW, bool SENTINEL>   // k-blocks per wave = (4H / 16) / 4 = H / 16
-__global__ __launch_bounds__(320) void lstm_enc_bwd_persistent_kernel(EncPersistBwd e) {
-  // Five waves.  Waves 0-3 own the recurrence (operand loads, matrix product;
-  // wave 0 also the gate epilogue and the publishing stores).  Wave 4 is a
-  // helper: it paces the operand loads (as in the forward kernel) and
-  // releases them through a barrier, and one step
-  // ahead it streams the saved activations of the next step from HBM and folds
-  // them into the per-element coefficients of the gate derivatives, which it
-  // leaves in LDS.  Its HBM latency sits on its own memory counter, and the
-  // 50-odd registers of saved activations and coefficients exist in its loop
-  // only.
-  __shared__ __attribute__((aligned(16))) f32x4 red[4 * 64];
-  __shared__ __attribute__((aligned(16))) float4 coef[2][7][64];   // [parity][A, O, I, G, F, C, dy][lane]
-  __shared__ int missed;                        // a wave of this step had to re-fetch (feeds the pacer)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid == 0) missed = 0;
-  __syncthreads();
-  const int r = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x, d = blockIdx.y, chunk = blockIdx.z;
-  const int S = e.S, N = e.N, H = e.H;
-  const int n0 = chunk * 16;
-  const int Np = (N + 15) & ~15;               // whole 128-byte lines per 16-column chunk
-  const unsigned ntile = gridDim.x;            // H / 16 producers per group
-  const int64_t rows = (int64_t)S * N;
-  unsigned* cnt = e.cnt + d * gridDim.z + chunk;
-
-  const int u0 = 16 * tile + 4 * q;             // lane (q, r) of waves 0 and 4: units u0..u0+3 of column n
-  const int n = n0 + r;
-  const bool col_ok = n < N;
-  float* gbase = e.gates + (int64_t)d * rows * 4 * H;
-  const float* cbase = e.cs + (int64_t)d * rows * H;
-
-  if (wave == 4) {
-    // ------------------------------ helper wave ------------------------------
-    const int len = (col_ok && e.lens) ? e.lens[n] : 0x7fffffff;
-    float4 gi, gf, gg, go, cpv, cv, ad;
-    auto fetch = [&](int i) {
-      const int s = d ? i : S - 1 - i;
-      const int sp = d ? s + 1 : s - 1;
-      const bool has_prev = d ? (s < S - 1) : (s > 0);
-      const int64_t hu = ((int64_t)s * N + n) * H + u0;
-      const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
-      gi = ld4(gbase + g0);
-      gf = ld4(gbase + g0 + H);
-      gg = ld4(gbase + g0 + 2 * (int64_t)H);
-      go = ld4(gbase + g0 + 3 * (int64_t)H);
-      cv = ld4(cbase + hu);
-      cpv = has_prev ? ld4(cbase + ((int64_t)sp * N + n) * H + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
-      ad = ld4(e.dy + (int64_t)s * e.ys_s + (int64_t)n * e.ys_n + d * H + u0);
-    };
-    // dh = product + dy;  dc = dc_carry + dh * A;  d_o = dh * O;  d_i = dc * I;
-    // d_g = dc * G;  d_f = dc * F;  dc_carry' = dc * C
-    auto publish = [&](int i) {
-      const int s = d ? i : S - 1 - i;
-      const bool live = s < len;
-      const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
-      const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
-      const float cp_[4] = {cpv.x, cpv.y, cpv.z, cpv.w}, c_[4] = {cv.x, cv.y, cv.z, cv.w};
-      float kA[4], kO[4], kI[4], kG[4], kF[4], kC[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float tc = fast_tanh(c_[k]);
-        kA[k] = go_[k] * (1.f - tc * tc);
-        kO[k] = live ? tc * go_[k] * (1.f - go_[k]) : 0.f;
-        kI[k] = live ? gg_[k] * gi_[k] * (1.f - gi_[k]) : 0.f;
-        kG[k] = live ? gi_[k] * (1.f - gg_[k] * gg_[k]) : 0.f;
-        kF[k] = live ? cp_[k] * gf_[k] * (1.f - gf_[k]) : 0.f;
-        kC[k] = live ? gf_[k] : 0.f;
-      }
-      float4* c = &coef[i & 1][0][lane];
-      c[0 * 64] = make_float4(kA[0], kA[1], kA[2], kA[3]);
-      c[1 * 64] = make_float4(kO[0], kO[1], kO[2], kO[3]);
-      c[2 * 64] = make_float4(kI[0], kI[1], kI[2], kI[3]);
-      c[3 * 64] = make_float4(kG[0], kG[1], kG[2], kG[3]);
-      c[4 * 64] = make_float4(kF[0], kF[1], kF[2], kF[3]);
-      c[5 * 64] = make_float4(kC[0], kC[1], kC[2], kC[3]);
-      c[6 * 64] = ad;
-    };
-    if (col_ok) { fetch(0); publish(0); if (S > 1) fetch(1); }
-    PersistPacer pacer{e.delay, 0};
-    for (int i = 0; i < S; ++i) {
-      if (i > 0) {
-        SSASR_PTRACE_H(i, 8);
-        if (SENTINEL) {
-          pacer.sleep();
-        } else if (lane == 0) {
-          const unsigned target = ntile * (unsigned)i;
-          unsigned spins = 0;
-          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (persist_give_up(++spins, e.status, persist_code(PK_ENC_BPTT_GATHER, i))) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        SSASR_PTRACE_H(i, 9);
-        __syncthreads();    // operand loads released
-      }
-      // coef[(i + 1) & 1] was last read in step i - 1, which ended at the closing barrier
-      if (col_ok && i + 1 < S) { publish(i + 1); if (i + 2 < S) fetch(i + 2); }
-      __syncthreads();      // product done
-      if (SENTINEL && i > 0) { pacer.update(missed != 0); missed = 0; }
-      __syncthreads();      // step closed
-    }
-    return;
-  }
-
-  // ---------------------------- recurrence waves -----------------------------
-  float4 wreg[KPW];
-  {
-    const float* wp = e.whhT + ((int64_t)d * H + 16 * tile + r) * 4 * H + 4 * q;
-#pragma unroll
-    for (int j = 0; j < KPW; ++j) wreg[j] = *reinterpret_cast<const float4*>(wp + (wave + 4 * j) * 16);
-  }
-  const bool epi = wave == 0 && col_ok;
-  float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps
-
-  const size_t step_bytes = (size_t)4 * H * Np * sizeof(float);
-  float* xbase = e.gx + (int64_t)d * S * 4 * H * Np;
-  const __amdgpu_buffer_rsrc_t xrs =
-      __builtin_amdgcn_make_buffer_rsrc(xbase, 0, (int)(step_bytes * S), 0x00020000);
-  const unsigned xo = (unsigned)((q * Np + (col_ok ? n : n0)) * 16);
-
-  for (int i = 0; i < S; ++i) {
-    const int s = d ? i : S - 1 - i;            // reverse of the forward order
-    const int sn = d ? s - 1 : s + 1;           // step published by the previous iteration
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-    SSASR_PTRACE(i, 0);
-    if (i > 0) {
-      const unsigned sbase = (unsigned)((size_t)sn * step_bytes);
-      __syncthreads();      // released by the helper wave
-      SSASR_PTRACE(i, 2);
-      // (SENTINEL) re-fetch any piece that still holds the fill pattern
-      u32x4 raw[KPW];
-#pragma unroll
-      for (int j = 0; j < KPW; ++j)
-        raw[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(xo + (unsigned)((wave + 4 * j) * 4 * Np * 16)),
-                                                       (int)sbase, 16);
-      if (SENTINEL) {
-        for (unsigned tries = 0;; ++tries) {
-          bool anybad = false;
-#pragma unroll
-          for (int j = 0; j < KPW; ++j) {
-            const bool bad = raw[j].x == PERSIST_SENTINEL || raw[j].y == PERSIST_SENTINEL ||
-                             raw[j].z == PERSIST_SENTINEL || raw[j].w == PERSIST_SENTINEL;
-            if (__any(bad)) {
-              anybad = true;
-              raw[j] = __builtin_amdgcn_raw_buffer_load_b128(
-                  xrs, (int)(xo + (unsigned)((wave + 4 * j) * 4 * Np * 16)), (int)sbase, 16);
-            }
-          }
-          if (!anybad) { SSASR_PRETRY(tries); if (tries && lane == 0) missed = 1; break; }
-          if (persist_give_up(tries, e.status, persist_code(PK_ENC_BPTT_GATHER, i))) break;
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-      SSASR_PTRACE(i, 3);
-      // NB: convert the whole vector at once; __builtin_bit_cast on a single
-      // ext-vector element silently reads element 0 with this compiler.
-#pragma unroll
-      for (int j = 0; j < KPW; j += 2) {
-        const f32x4 f0 = __builtin_bit_cast(f32x4, raw[j]);
-        const f32x4 f1 = __builtin_bit_cast(f32x4, raw[j + 1 < KPW ? j + 1 : j]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j].x, f0[0], acc, 0, 0, 0);
-        if (j + 1 < KPW) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j + 1 < KPW ? j + 1 : j].x, f1[0], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j].y, f0[1], acc, 0, 0, 0);
-        if (j + 1 < KPW) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j + 1 < KPW ? j + 1 : j].y, f1[1], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j].z, f0[2], acc, 0, 0, 0);
-        if (j + 1 < KPW) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j + 1 < KPW ? j + 1 : j].z, f1[2], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j].w, f0[3], acc, 0, 0, 0);
-        if (j + 1 < KPW) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j + 1 < KPW ? j + 1 : j].w, f1[3], acc2, 0, 0, 0);
-      }
-    }
-    red[wave * 64 + lane] = acc + acc2;
-    SSASR_PTRACE(i, 4);
-    __syncthreads();        // product done
-    SSASR_PTRACE(i, 5);
-    if (wave == 0) {
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 di = z4, df = z4, dg = z4, dov = z4;
-      if (epi) {
-        const float4* c = &coef[i & 1][0][lane];
-        const float4 cA = c[0 * 64], cO = c[1 * 64], cI = c[2 * 64], cG = c[3 * 64], cF = c[4 * 64],
-                     cC = c[5 * 64], ad1 = c[6 * 64];
-        f32x4 dhv = red[lane];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) dhv += red[w * 64 + lane];
-        const float kA[4] = {cA.x, cA.y, cA.z, cA.w}, kO[4] = {cO.x, cO.y, cO.z, cO.w};
-        const float kI[4] = {cI.x, cI.y, cI.z, cI.w}, kG[4] = {cG.x, cG.y, cG.z, cG.w};
-        const float kF[4] = {cF.x, cF.y, cF.z, cF.w}, kC[4] = {cC.x, cC.y, cC.z, cC.w};
-        const float dc_[4] = {dcv.x, dcv.y, dcv.z, dcv.w}, a1_[4] = {ad1.x, ad1.y, ad1.z, ad1.w};
-        float rdi[4], rdf[4], rdg[4], rdo[4], rdc[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float dh = dhv[k] + a1_[k];
-          const float dc = dc_[k] + dh * kA[k];
-          rdo[k] = dh * kO[k];
-          rdi[k] = dc * kI[k];
-          rdg[k] = dc * kG[k];
-          rdf[k] = dc * kF[k];
-          rdc[k] = dc * kC[k];
-        }
-        di = make_float4(rdi[0], rdi[1], rdi[2], rdi[3]);
-        df = make_float4(rdf[0], rdf[1], rdf[2], rdf[3]);
-        dg = make_float4(rdg[0], rdg[1], rdg[2], rdg[3]);
-        dov = make_float4(rdo[0], rdo[1], rdo[2], rdo[3]);
-        dcv = make_float4(rdc[0], rdc[1], rdc[2], rdc[3]);
-      }
-      // exchange image first (write-through), then the row-major copy for the GEMMs
-      if (n0 + r < Np) {
-        const unsigned so = (unsigned)((size_t)s * step_bytes);
-        const unsigned lo = (unsigned)((q * Np + n0 + r) * 16);
-        const int kt = H / 16;                  // k-blocks per gate
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, di), xrs, (int)(lo + (unsigned)((0 * kt + tile) * 4 * Np * 16)), (int)so, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, df), xrs, (int)(lo + (unsigned)((1 * kt + tile) * 4 * Np * 16)), (int)so, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dg), xrs, (int)(lo + (unsigned)((2 * kt + tile) * 4 * Np * 16)), (int)so, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dov), xrs, (int)(lo + (unsigned)((3 * kt + tile) * 4 * Np * 16)), (int)so, 16);
-      }
-      if (epi) {
-        const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
-        st4(gbase + g0, di);
-        st4(gbase + g0 + H, df);
-        st4(gbase + g0 + 2 * (int64_t)H, dg);
-        st4(gbase + g0 + 3 * (int64_t)H, dov);
-      }
-      SSASR_PTRACE(i, 6);
-      if (!SENTINEL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      SSASR_PTRACE(i, 7);
-    }
-    __syncthreads();      // step closed: red and coef[i & 1] may be rewritten
-  }
-}
 
 // ----------- persistent backward recurrence, K split (reduce-scatter) -----------
 // Same ownership as above (a workgroup = 16 hidden units x 16 columns of one
@@ -1365,16 +1071,15 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
 // other half may not have started): half 0 keeps their rows in LDS and writes
 // them during the third step.  A launch of fewer than three steps must not use
 // HV = 2 (the launcher falls back to HV = 1).
-// NW = recurrence waves (4, or 8 for H = 256: each wave then loads 2 instead of 4 partial tiles and
-// multiplies into 1 instead of 2 unit tiles -- the product is issue bound, 32 cycles per MFMA);
-// the helper wave is wave NW: 64 * (NW + 1) threads.
+// Four recurrence waves + the helper wave (wave NW): 64 * (NW + 1) threads.  (Eight recurrence waves -- two
+// partial tiles loaded and one unit tile multiplied per wave -- measured 2.35 against 2.33 us per step alone
+// and 0.5 % slower in the train step; not kept.)
 // which steps' gate-derivative rows go straight to `gates` (the two-halves in-place form holds the first two of a
 // launch back: see the note on in-place rows above)
 __device__ __forceinline__ bool epi_rows_ok(bool col_ok, int half, int hv, bool inplace, int i, int i0) {
   return col_ok && half == 0 && (hv == 1 || !inplace || i >= i0 + 2);
 }
-// LANE SPLIT (round 3, NW = 4; SSASR_BPTT_LANE_SPLIT=0 compiles the earlier form for A/B).  The sum of the
-// partial tiles used to be: wave w loads sources 4w .. 4w + 3 whole, adds them, writes its partial to LDS,
+// LANE SPLIT (round 3).  The sum of the partial tiles used to be: wave w loads sources 4w .. 4w + 3 whole, adds them, writes its partial to LDS,
 // barrier, wave 0 adds the four partials and runs the whole gate epilogue (4 units per lane) while waves
 // 1-3 wait.  Now wave w owns unit quad w of the tile: one load instruction fetches that quad's 256 bytes
 // of FOUR sources (16-lane group g reads source 4 t + g: 8 whole lines per instruction, as before), the
@@ -1382,19 +1087,15 @@ __device__ __forceinline__ bool epi_rows_ok(bool col_ok, int half, int hv, bool 
 // wave runs the epilogue of its own 64 (unit, column) pairs, one per lane.  No LDS reduction, one barrier
 // less per step, the epilogue's 16-deep dependent chain becomes 4 deep; the helper wave writes the
 // row-major gate derivatives for the GEMMs one barrier later, off the critical path.
-#ifndef SSASR_BPTT_LANE_SPLIT
-#define SSASR_BPTT_LANE_SPLIT 1
-#endif
-template <int TPW, int HV, int NW = 4>   // TPW = (H / 16) / 4; grid.z = chunks * HV
-__global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
-  constexpr bool LS = SSASR_BPTT_LANE_SPLIT != 0 && NW == 4;
+template <int TPW, int HV>   // TPW = (H / 16) / 4; grid.z = chunks * HV
+__global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
+  constexpr int NW = 4;
   if (SSASR_PERSIST_PRIO) __builtin_amdgcn_s_setprio(SSASR_PERSIST_PRIO);
   constexpr int T = 4 * TPW;                    // unit tiles = H / 16
   constexpr int SPW = T / NW;                   // source tiles loaded per wave
   constexpr int OT = (T / HV) / NW;             // product tiles per wave
   constexpr int LAG = HV >= 2 ? 3 : 1;          // steps between consuming a slot and re-arming it
   static_assert(TPW % HV == 0 && (T / HV) % NW == 0 && T % NW == 0 && OT >= 1 && LAG + 2 <= BWD_RS_RING, "ring too short");
-  __shared__ __attribute__((aligned(16))) f32x4 red[NW * 64];
   __shared__ __attribute__((aligned(16))) float4 coef[3][7][64];   // [step % 3][A, O, I, G, F, C, dy][lane]
   constexpr int NG = HV >= 2 ? 3 : 1;           // steps of gate derivatives kept in LDS
   __shared__ __attribute__((aligned(16))) float4 sG[NG][4][64];    // gate derivatives: [step % NG][gate][lane (q, r)]
@@ -1403,11 +1104,9 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
   if (tid == 0) missed = 0;
   __syncthreads();
   const int r = lane & 15, q = lane >> 4;
-  const PersistRole role = persist_role(e.local, e.nchunk, HV);
-  if (!role.live) return;
+  const PersistRole role = persist_role(HV);
   const int tile = role.tile, d = role.d, chunk = role.chunk, half = role.half;
   const int nchunk = role.nchunk;
-  const bool local = e.local != 0;
   // saved gates row-major in `gates` = overwritten in place by the derivatives (the hazard the note
   // above is about); with the forward kernel's tile-major copy there is nothing to protect
   const bool inplace = e.tsave == nullptr;
@@ -1447,8 +1146,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
     }
     PersistPacer pacer{e.delay, 0};
     const u32x4 fill = {PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL};
-    // LS: the waves read this launch's first coefficients before the first per-step barrier
-    if (LS) __syncthreads();
+    // the waves read this launch's first coefficients before the first per-step barrier
+    __syncthreads();
     for (int i = i0; i < i1; ++i) {
       if (i > 0) {
         if (i > i0) pacer.sleep();
@@ -1461,9 +1160,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
         sv.publish(&coef[(i + 2) % 3][0][lane], live(i + 2));
         if (i + 3 < S) sv.fetch(e, gbase, cbase, d, i + 3, n, u0);
       }
-      if (!LS) __syncthreads();      // partial tiles summed per wave (red), loads verified
-      else __syncthreads();          // LS: this IS the "gate derivatives in LDS" barrier (the loads are verified before it)
-      if (LS && epi_rows_ok(col_ok, half, HV, inplace, i, i0)) {
+      __syncthreads();               // gate derivatives in LDS (the loads are verified before it)
+      if (epi_rows_ok(col_ok, half, HV, inplace, i, i0)) {
         // row-major copy of this step's gate derivatives for the dX and weight-gradient GEMMs
         const int sr = d ? i : S - 1 - i;
         float* g0 = gbase + ((int64_t)sr * N + n) * 4 * H + u0;
@@ -1479,8 +1177,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
         const unsigned base = (unsigned)((i - LAG) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-          if (local) __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 0);
-          else __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(fill, xrs, (int)(j * TILE_B + lane * 16), (int)base, 16);
         }
       }
       if (HV >= 2 && inplace && half == 0 && col_ok && i == i0 + 2) {
@@ -1493,7 +1190,6 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
           for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[(i0 + k) % NG][g][lane]);
         }
       }
-      if (!LS) __syncthreads();      // gate derivatives in LDS
     }
     return;
   }
@@ -1531,15 +1227,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
   for (int t = 0; t < OT; ++t)
 #pragma unroll
     for (int b = 0; b < 2; ++b) x6_planes(wreg[t][2 * b], wreg[t][2 * b + 1], wA[t][b]);
-  const bool epi = wave == 0 && col_ok;
-  float4 dcv = make_float4(0.f, 0.f, 0.f, 0.f);   // cell-state derivative carried across steps
-  float* dcs = e.dc_state ? e.dc_state + ((int64_t)d * N + n) * H + u0 : nullptr;
-  if (!LS && epi && i0 > 0 && dcs) dcv = ld4(dcs);
-  // LS: lane (q, r) of wave w owns unit 16 tile + 4 w + q of column n0 + r
+  // lane (q, r) of wave w owns unit 16 tile + 4 w + q of column n0 + r; its cell-state derivative is carried
+  // across steps in a register (and across launches of a segmented layer through dc_state)
   float dc1 = 0.f;
   float* dcs1 = e.dc_state ? e.dc_state + ((int64_t)d * N + n) * H + 16 * tile + 4 * wave + q : nullptr;
-  if (LS && col_ok && i0 > 0 && dcs1) dc1 = *dcs1;
-  if (LS) __syncthreads();      // the helper wave has published the coefficients of the first two steps
+  if (col_ok && i0 > 0 && dcs1) dc1 = *dcs1;
+  __syncthreads();              // the helper wave has published the coefficients of the first two steps
 
   for (int i = i0; i < i1; ++i) {
     const int s = d ? i : S - 1 - i;            // reverse of the forward order
@@ -1551,10 +1244,9 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
       // partial tiles for this workgroup's units from sources SPW*wave .. (+SPW)
       const unsigned base = (unsigned)((i - 1) % BWD_RS_RING) * SLOT_B + (unsigned)tile * T * TILE_B;
       u32x4 raw[SPW];
-      // LS: 16-lane group q reads unit quad `wave` (256 bytes) of source 4 t + q; else wave w reads sources
-      // SPW w .. whole
-      const unsigned lo = LS ? (unsigned)(q * TILE_B + (wave * 16 + r) * 16) : (unsigned)(SPW * wave * TILE_B + lane * 16);
-      constexpr unsigned LSTEP = LS ? 4 * TILE_B : TILE_B;
+      // 16-lane group q reads unit quad `wave` (256 bytes) of source 4 t + q
+      const unsigned lo = (unsigned)(q * TILE_B + (wave * 16 + r) * 16);
+      constexpr unsigned LSTEP = 4 * TILE_B;
 #pragma unroll
       for (int t = 0; t < SPW; ++t)
         raw[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(lo + t * LSTEP), (int)base, 16);
@@ -1577,7 +1269,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
 #pragma unroll
       for (int t = 0; t < SPW; ++t) part += __builtin_bit_cast(f32x4, raw[t]);
     }
-    if (LS) {
+    {
       // the four 16-lane groups hold the sums of sources = 0, 1, 2, 3 (mod 4): add them on the permlane
       // network (rows 0<->1, 2<->3, then the two halves) -- every lane ends with the same bits -- and run
       // this lane's (unit, column) through the gate epilogue
@@ -1612,55 +1304,6 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
       sg[1 * 64 * 4] = df;
       sg[2 * 64 * 4] = dg;
       sg[3 * 64 * 4] = dov;
-      SSASR_PTRACE(i, 6);
-    } else {
-    red[wave * 64 + lane] = part;
-    SSASR_PTRACE(i, 4);
-    __syncthreads();        // partial sums in LDS
-    SSASR_PTRACE(i, 5);
-    }
-    if (!LS && wave == 0) {
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 di = z4, df = z4, dg = z4, dov = z4;
-      if (epi) {
-        const float4* c = &coef[i % 3][0][lane];
-        const float4 cA = c[0 * 64], cO = c[1 * 64], cI = c[2 * 64], cG = c[3 * 64], cF = c[4 * 64],
-                     cC = c[5 * 64], ad1 = c[6 * 64];
-        f32x4 dhv = red[lane];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) dhv += red[w * 64 + lane];
-        const float kA[4] = {cA.x, cA.y, cA.z, cA.w}, kO[4] = {cO.x, cO.y, cO.z, cO.w};
-        const float kI[4] = {cI.x, cI.y, cI.z, cI.w}, kG[4] = {cG.x, cG.y, cG.z, cG.w};
-        const float kF[4] = {cF.x, cF.y, cF.z, cF.w}, kC[4] = {cC.x, cC.y, cC.z, cC.w};
-        const float dc_[4] = {dcv.x, dcv.y, dcv.z, dcv.w}, a1_[4] = {ad1.x, ad1.y, ad1.z, ad1.w};
-        float rdi[4], rdf[4], rdg[4], rdo[4], rdc[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float dh = dhv[k] + a1_[k];
-          const float dc = dc_[k] + dh * kA[k];
-          rdo[k] = dh * kO[k];
-          rdi[k] = dc * kI[k];
-          rdg[k] = dc * kG[k];
-          rdf[k] = dc * kF[k];
-          rdc[k] = dc * kC[k];
-        }
-        di = make_float4(rdi[0], rdi[1], rdi[2], rdi[3]);
-        df = make_float4(rdf[0], rdf[1], rdf[2], rdf[3]);
-        dg = make_float4(rdg[0], rdg[1], rdg[2], rdg[3]);
-        dov = make_float4(rdo[0], rdo[1], rdo[2], rdo[3]);
-        dcv = make_float4(rdc[0], rdc[1], rdc[2], rdc[3]);
-      }
-      sG[i % NG][0][lane] = di;
-      sG[i % NG][1][lane] = df;
-      sG[i % NG][2][lane] = dg;
-      sG[i % NG][3][lane] = dov;
-      if (epi && half == 0 && (HV == 1 || !inplace || i >= i0 + 2)) {   // row-major copy for the dX and weight-gradient GEMMs
-        const int64_t g0 = ((int64_t)s * N + n) * 4 * H + u0;
-        st4(gbase + g0, di);
-        st4(gbase + g0 + H, df);
-        st4(gbase + g0 + 2 * (int64_t)H, dg);
-        st4(gbase + g0 + 3 * (int64_t)H, dov);
-      }
       SSASR_PTRACE(i, 6);
     }
     __syncthreads();        // gate derivatives in LDS
@@ -1707,16 +1350,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_enc_bwd_rs_kernel(EncPersi
       const unsigned base = (unsigned)(i % BWD_RS_RING) * SLOT_B + (unsigned)tile * TILE_B;   // source = this tile
 #pragma unroll
       for (int t = 0; t < OT; ++t) {
-        if (local) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t] + acc2[t]), xrs,
-                                                          (int)((otile0 + t) * T * TILE_B + lane * 16), (int)base, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t] + acc2[t]), xrs,
-                                                    (int)((otile0 + t) * T * TILE_B + lane * 16), (int)base, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t] + acc2[t]), xrs,
+                                               (int)((otile0 + t) * T * TILE_B + lane * 16), (int)base, 16);
       }
       SSASR_PTRACE(i, 7);
     }
   }
-  if (!LS && epi && half == 0 && i1 < S && dcs) st4(dcs, dcv);
-  if (LS && col_ok && half == 0 && i1 < S && dcs1) *dcs1 = dc1;
+  if (col_ok && half == 0 && i1 < S && dcs1) *dcs1 = dc1;
 }
 
 // out[n][u] = sum_seg X_seg[n,:] . W_seg[u,:], plain store.  Used for the

@@ -16,7 +16,7 @@ from ._lib import check
 
 _persist_status = []     # int32[8] workspaces of persistent launches not yet checked
 TIMEOUT_MESSAGE = 'ss_asr_amd: a persistent recurrence / decode loop timed out'
-_KERNELS = {1: 'encoder forward recurrence', 2: 'encoder BPTT (K-split)', 3: 'encoder BPTT (gather)',
+_KERNELS = {1: 'encoder forward recurrence', 2: 'encoder BPTT',
             4: 'decode loop forward', 5: 'decoder backward chain', 6: 'split-T attention step'}
 
 
@@ -56,11 +56,10 @@ _shared_status = None    # one int32[8] row for every persistent launch of the s
 
 class shared_status_row:
     """Context manager: every persistent launch inside it reports into `row` (int32[8] on the
-    device, zero on entry) instead of a row of its own.  The sentinel exchange only ever writes
-    1 into words 4 / 5, so the launches of a whole train step can share one row, which the
-    caller then reads back with its other per-step statistics (no extra copy, no
-    synchronisation).  Not taken when the arrival-counter form is selected: its counters
-    (words 0..3) are per launch."""
+    device, zero on entry) instead of a row of its own.  The launches only ever write a time-out
+    code into words 4 / 5 (first failure wins), so the launches of a whole train step can share one
+    row, which the caller then reads back with its other per-step statistics (no extra copy, no
+    synchronisation)."""
 
     def __init__(self, row):
         self.row = row
@@ -68,9 +67,7 @@ class shared_status_row:
     def __enter__(self):
         global _shared_status
         self.prev = _shared_status
-        counter_form = C.c_int(0)
-        _lib.load().ssasr_get_option(b'SSASR_PERSISTENT_COUNTER', C.byref(counter_form))
-        _shared_status = None if counter_form.value else self.row
+        _shared_status = self.row
         return self
 
     def __exit__(self, *exc):
@@ -131,48 +128,10 @@ def _overlap_events():
 _side = None
 
 
-_probed = None
-
-
-def probe_placement():
-    """Verifies once, on the current device, the dispatcher property that the XCD-local BPTT placement
-    rests on (include/ssasr.h, ssasr_probe_placement: an allocation and three synchronous launches);
-    returns the verdict (1 holds, 0 does not).  Until it has run the library uses the spread placement."""
-    global _probed
-    if _probed is None:
-        rc = _lib.load().ssasr_probe_placement(C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        if rc < 0:
-            raise RuntimeError('ssasr_probe_placement: HIP error %d' % -rc)
-        _probed = rc
-    return _probed
-
-
-def placement_probed():
-    """Runs the placement probe on first use when a form that needs it is switched on
-    (SSASR_FWD_LOCAL / SSASR_BPTT_LOCAL, both off by default)."""
-    if _probed is None:
-        lib = _lib.load()
-        for name in (b'SSASR_FWD_LOCAL', b'SSASR_BPTT_LOCAL'):
-            v = C.c_int(0)
-            lib.ssasr_get_option(name, C.byref(v))
-            if v.value:
-                probe_placement()
-                break
-        else:
-            return False
-    return bool(_probed)
-
-
 def side_stream():
     global _side
     if _side is None:
         _side = torch.cuda.Stream()
-        # First use of the overlapped backward: the probe only when the XCD-local placement is asked
-        # for (SSASR_BPTT_LOCAL, default off) -- it synchronises the device.
-        local = C.c_int(0)
-        _lib.load().ssasr_get_option(b'SSASR_BPTT_LOCAL', C.byref(local))
-        if local.value:
-            probe_placement()
     return _side
 
 
@@ -344,7 +303,6 @@ class _BiLSTM(torch.autograd.Function):
         tsave = torch.empty(ts_floats, device=x.device, dtype=torch.float32) if ts_floats else None
         cs = None if ts_floats else torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         # workspaces of the persistent recurrence (exchange image + counters)
-        placement_probed()
         hx_floats = int(lib.ssasr_bilstm_fwd_hx_floats(S, N, H))
         armed = 0
         if slots is not None and slots[1] is not None and hx_floats:
@@ -766,17 +724,17 @@ class _DecoderLoop(torch.autograd.Function):
             if sinks is None:
                 dpsi = (f(A, E), f(A))
                 check(lib.ssasr_attn_precompute_wgrad(_p(out['dcomp']), _p(feat), B * T, E, A, _p(dpsi[0]),
-                                                      _p(dpsi[1]), 0, 0, _stream()), 'ssasr_attn_precompute_wgrad')
+                                                      _p(dpsi[1]), 0, _stream()), 'ssasr_attn_precompute_wgrad')
         if sinks is not None:
             main = torch.cuda.current_stream()
             side = side_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                check(lib.ssasr_decoder_wgrad(C.byref(d), C.byref(g), 1, 1, C.c_void_p(side.cuda_stream)),
+                check(lib.ssasr_decoder_wgrad(C.byref(d), C.byref(g), 1, C.c_void_p(side.cuda_stream)),
                       'ssasr_decoder_wgrad')
                 if ctx.psi:
                     check(lib.ssasr_attn_precompute_wgrad(_p(out['dcomp']), _p(feat), B * T, E, A, _p(sinks[-2]),
-                                                          _p(sinks[-1]), 1, 1, C.c_void_p(side.cuda_stream)),
+                                                          _p(sinks[-1]), 1, C.c_void_p(side.cuda_stream)),
                           'ssasr_attn_precompute_wgrad')
             for t in list(bufs.values()) + list(ws.values()) + [dlogits, out['dcomp'], feat]:
                 t.record_stream(side)

@@ -9,7 +9,7 @@ int main(void) {
   printf("abi %d\n", v);
   /* every size 0 / pointer NULL: argument error, nothing launched */
   int rc_wgrad = ssasr_bilstm_wgrad(NULL, NULL, 0, 0, NULL, 0, 0, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL,
-                                    NULL, NULL, /*accumulate*/ 1, /*beside*/ 0, /*stream*/ NULL);
+                                    NULL, NULL, /*accumulate*/ 1, /*stream*/ NULL);
   int rc_attn = ssasr_attn_step_fwd(NULL, NULL, NULL, NULL, NULL, 0, 0, 0, 0, 0, NULL, NULL, NULL,
                                     /*ws*/ NULL, /*ws_phase*/ 0, /*ws_status*/ NULL, /*stream*/ NULL);
   int rc_dec = ssasr_decoder_fwd(NULL, NULL);

@@ -154,43 +154,6 @@ def test_bilstm_packed_forward_backward(N, T, I, H, lens):
         close(a.grad, b.grad, 2e-4, 'd' + name)
 
 
-@pytest.mark.parametrize('I', [80, 1024])
-def test_xcd_local_forward_recurrence_equals_the_spread_form(I):
-    """The same layer through both placements of the persistent forward recurrence (SSASR_FWD_LOCAL
-    1 / 0) at a bench-like shape, 32 ragged columns x 300 steps: the XCD-local form (exchange through
-    one XCD's L2, product on the bf16 pipeline in the exact three-way split) and the spread form
-    (fabric hand-off, fp32 MFMA instruction) agree to fp32 rounding on y and on what the BPTT reads
-    back -- checked through the gradients of a backward pass -- and the local form is the one that
-    ran when the placement probe allows it."""
-    from ss_asr_amd import _lib, ops
-    N, S, H = 32, 300, 256
-    lens = [300 - 7 * k for k in range(N)]
-    x = rnd(N, S, I, seed=91, scale=0.5).float()
-    for i, l in enumerate(lens):
-        x[i, l:] = 0
-    w = [t.float().to(dev()) for t in lstm_weights(I, H, 92)]
-    ld = torch.tensor(lens, dtype=torch.int32, device=dev())
-    gy = rnd(N, S, 2 * H, seed=93).float().to(dev())
-    probed = ops.probe_placement()
-    outs = []
-    for local in (1, 0):
-        old = _lib.set_option('SSASR_FWD_LOCAL', local)
-        try:
-            xd = x.to(dev()).requires_grad_(True)
-            wd = [t.clone().requires_grad_(True) for t in w]
-            y = ops.bilstm(xd, ld, S, True, wd)
-            (y * gy).sum().backward()
-            torch.cuda.synchronize()
-            ops.check_persistent_status()
-            outs.append((y.detach(), xd.grad, wd[1].grad, wd[5].grad))
-        finally:
-            _lib.set_option('SSASR_FWD_LOCAL', old)
-    if not probed:
-        pytest.skip('placement probe says no: both runs took the spread form')
-    for a, b, tol, what in zip(outs[0], outs[1], (2e-6, 2e-5, 2e-4, 2e-4), ('y', 'dx', 'dw_hh', 'dw_hh_r')):
-        close(a, b, tol, what)
-
-
 @pytest.mark.parametrize('N,S,I,H,segments', [(20, 150, 24, 64, 4), (9, 130, 16, 128, 3), (20, 150, 24, 64, 1)])
 def test_bilstm_segmented_bptt_with_overlapped_weight_gradients(N, S, I, H, segments, monkeypatch):
     """The path the train step takes: gradients live in an optimizer-owned flat buffer, so the
@@ -387,7 +350,7 @@ def test_split_attention_repeated_calls_share_one_workspace():
 
 
 def test_split_attention_missing_slice_times_out_and_is_reported():
-    """Fault injection (SSASR_TEST_DROP_TILE): slice 2 of utterance 0 never publishes its partial
+    """Fault injection (SSASR_TEST_DROP_ATTN_SLICE): slice 2 of utterance 0 never publishes its partial
     softmax.  The utterance's other workgroups give up after their bounded wait, say so in the
     status word (this kernel used to `break` and consume the fill pattern silently), and
     the next call on the same workspace is healthy."""
@@ -401,7 +364,7 @@ def test_split_attention_missing_slice_times_out_and_is_reported():
     ld = torch.tensor([300 - 7 * k for k in range(B)], dtype=torch.int32, device=dev())
     good_a, good_c = ops.attn_step(state, w_phi, comp, feat, ld)
     ops.check_persistent_status()
-    old = _lib.set_option('SSASR_TEST_DROP_TILE', 2)
+    old = _lib.set_option('SSASR_TEST_DROP_ATTN_SLICE', 2)
     try:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -409,7 +372,7 @@ def test_split_attention_missing_slice_times_out_and_is_reported():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     finally:
-        _lib.set_option('SSASR_TEST_DROP_TILE', old)
+        _lib.set_option('SSASR_TEST_DROP_ATTN_SLICE', old)
     with pytest.raises(RuntimeError, match='split-T attention'):
         ops.check_persistent_status()
     assert elapsed < 20.0, elapsed

@@ -164,40 +164,6 @@ def test_backward_matches_reference_on_the_fp32_mfma_instruction(golden):
         _lib.set_option('SSASR_GEMM_X6', old)
 
 
-def test_backward_matches_reference_in_both_bptt_placements(golden):
-    """The K-split BPTT runs XCD-locally (one exchange group per XCD, hand-offs through that XCD's
-    L2, side-stream GEMMs on the other XCDs) when the placement probe allows it, else spread over
-    all XCDs with write-through hand-offs.  Both placements against the reference's gradients."""
-    from ss_asr_amd import _lib, ops
-    from ss_asr_amd.optim import FlatParameters
-    fx = golden('full_b16_t400')
-    ops.probe_placement()                        # (side_stream() only probes when SSASR_BPTT_LOCAL is set)
-    probed = _lib.set_option('SSASR_XCD_ROUND_ROBIN', 1)
-    _lib.set_option('SSASR_XCD_ROUND_ROBIN', probed)
-    assert probed in (0, 1)
-    names = [str(n) for n in fx['param_names']]
-    for local in (1, 0):
-        old = _lib.set_option('SSASR_BPTT_LOCAL', local)
-        try:
-            model = build(fx)
-            flat = FlatParameters(model)
-            flat.zero_grad()
-            _, _, _, loss = forward(fx, model)
-            loss.backward()
-            ops.join_side_stream()
-            torch.cuda.synchronize()
-            ops.check_persistent_status()
-        finally:
-            _lib.set_option('SSASR_BPTT_LOCAL', old)
-        params = dict(model.named_parameters())
-        got = np.array([params[n].grad.double().norm().item() for n in names])
-        np.testing.assert_allclose(got, fx['grad_norms'], rtol=1e-3, atol=1e-6, err_msg='local=%d' % local)
-        for k in fx.files:
-            if k.startswith('g_head/'):
-                np.testing.assert_allclose(params[k[7:]].grad.reshape(-1)[:256].cpu().numpy(), fx[k], atol=2e-5,
-                                           rtol=0, err_msg=k)
-
-
 def test_module_level_loop_equals_fused_loop(golden):
     """Driving Attention / Speller step by step (the way TextAutoEncoder does,
     src/text_autoencoder.py:55-88) gives the fused decode loop's result."""
@@ -423,7 +389,7 @@ def test_long_encoder_persistent_decode_loop_equals_multi_launch_loop(B, Tp, U, 
 
 
 def test_long_encoder_decode_loop_with_a_missing_record_times_out_and_is_reported():
-    """Fault injection (SSASR_TEST_DROP_TILE): slice 1 of utterance 0 stops publishing its partial-softmax
+    """Fault injection (SSASR_TEST_DROP_DEC_SLICE): slice 1 of utterance 0 stops publishing its partial-softmax
     record after the first decode step of the long-encoder persistent loop.  Its peers' bounded waits give
     up, every other wait of the launch drains through the latch (40 steps x 192 + 64 workgroups: seconds,
     not minutes), the status word names the decode loop, and the next call is healthy."""
@@ -442,14 +408,14 @@ def test_long_encoder_decode_loop_with_a_missing_record_times_out_and_is_reporte
         good, _, _ = ops.decoder_loop(feat, comp, enc_len, teacher, modes, None, model._decoder_params())
         torch.cuda.synchronize()
         ops.check_persistent_status()
-        old = _lib.set_option('SSASR_TEST_DROP_TILE', 1)
+        old = _lib.set_option('SSASR_TEST_DROP_DEC_SLICE', 1)
         try:
             t0 = time.perf_counter()
             ops.decoder_loop(feat, comp, enc_len, teacher, modes, None, model._decoder_params())
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
         finally:
-            _lib.set_option('SSASR_TEST_DROP_TILE', old)
+            _lib.set_option('SSASR_TEST_DROP_DEC_SLICE', old)
         with pytest.raises(RuntimeError, match='decode loop forward'):
             ops.check_persistent_status()
         assert elapsed < 30.0, elapsed
@@ -462,9 +428,12 @@ def test_long_encoder_decode_loop_with_a_missing_record_times_out_and_is_reporte
 @pytest.mark.slow
 def test_long_utterances_config4_shape_against_the_oracle():
     """BASELINE.json configs[3] in miniature: 1,500+ frame utterances (T' = 192 > 128, so the
-    decode loop takes the per-step kernels while the encoder runs 1,536 / 768 / 384 persistent
-    steps with the exchange ring wrapping around hundreds of times and the BPTT cut into
-    segments).  One train step against the CPU oracle on the same seeded weights."""
+    decode loop takes the long-encoder persistent form of csrc/decoder_long.h and the 4-slice
+    backward chain -- the per-step split-T loop is what
+    test_long_encoder_persistent_decode_loop_equals_multi_launch_loop forces and compares it with --
+    while the encoder runs 1,536 / 768 / 384 persistent steps with the exchange ring wrapping
+    around hundreds of times and the BPTT cut into segments).  One train step against the CPU
+    oracle on the same seeded weights."""
     from ss_asr_amd.asr import ASR
     from ss_asr_amd.engine import ASRTrainStep, label_geometry
     from ss_asr_amd.synthetic import make_batch

@@ -25,7 +25,6 @@ __device__ unsigned g_retry[TR_WG * 4 * 4];   // per (workgroup, wave): steps ne
   unsigned long long t_; asm volatile(SSASR_CLK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
   g_trace[((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * TR_N + ((step) - TR_LO)) * TR_SLOTS + (slot)] = t_; } } while (0)
 #include "rnn_kernels.h"
-#include "rnn_local.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d at %s:%d\n", e_, __FILE__, __LINE__); return 1; } } while (0)
 
@@ -113,11 +112,11 @@ int main(int argc, char** argv) {
 
   EncPersist pf{};
   pf.whh[0] = whh; pf.whh[1] = whh + 4 * H * H; pf.gates = gates; pf.cs = cs; pf.hs = hs; pf.hx = hx; pf.y = y;
-  pf.delay = getenv("DELAY_F") ? atoi(getenv("DELAY_F")) : 24; pf.lens = nullptr; pf.cnt = (unsigned*)sync; pf.status = sync + 4;
+  pf.delay = getenv("DELAY_F") ? atoi(getenv("DELAY_F")) : 24; pf.lens = nullptr; pf.status = sync + 4;
   pf.ys_s = (int)ys_s; pf.ys_n = (int)ys_n; pf.S = (int)S; pf.N = (int)N; pf.H = (int)H; pf.drop_tile = -1;
   EncPersistBwd pb{};
   pb.whhT = whhT; pb.gates = gates; pb.cs = cs; pb.dy = dy; pb.gx = gx; pb.lens = nullptr;
-  pb.cnt = (unsigned*)sync; pb.status = sync + 4; pb.delay = getenv("DELAY_B") ? atoi(getenv("DELAY_B")) : 16;
+  pb.status = sync + 4; pb.delay = getenv("DELAY_B") ? atoi(getenv("DELAY_B")) : 16;
   pb.ys_s = (int)ys_s; pb.ys_n = (int)ys_n; pb.S = (int)S; pb.N = (int)N; pb.H = (int)H;
   const int nbF = getenv("NB_F") ? atoi(getenv("NB_F")) : 2;
   const int chF = (int)((N + 16 * nbF - 1) / (16 * nbF)), chB = (int)((N + 15) / 16);
@@ -127,58 +126,31 @@ int main(int argc, char** argv) {
     CK(hipMemsetAsync(sync, 0, 32, st));
     CK(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * NpF * H), st));
     CK(hipEventRecord(e0, st));
-    const bool localF = getenv("LOCAL") != nullptr && 2 * chF <= 8;
-    pf.local = localF ? 2 : 0; pf.nchunk = chF;
-    const dim3 gridF = localF ? dim3(8 * (H / 4)) : dim3(H / 4, 2, chF);
-    if (nbF == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 1>), gridF, dim3(FWD_THREADS), 0, st, pf);
-    else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, true, 2>), gridF, dim3(FWD_THREADS), 0, st, pf);
+    const dim3 gridF = dim3(H / 4, 2, chF);
+    if (nbF == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, 1>), gridF, dim3(FWD_THREADS), 0, st, pf);
+    else hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, 2>), gridF, dim3(FWD_THREADS), 0, st, pf);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
     printf("fwd persistent: %.3f us / step (status %d)\n", ms * 1e3 / S, status);
   }
-  if (getenv("LOCALF")) {        // the XCD-local forward recurrence (rnn_local.h), phases per workgroup
-    float* hxl; CK(hipMalloc(&hxl, sizeof(float) * fl_hx_floats(S, N)));
-    pf.hx = hxl; pf.local = 2; pf.nchunk = (int)((N + FL_COLS - 1) / FL_COLS);
-    pf.delay = getenv("DELAY_F") ? atoi(getenv("DELAY_F")) : 8;
-    for (int rep = 0; rep < 3; ++rep) {
-      CK(hipMemsetAsync(sync, 0, 32, st));
-      CK(hipMemsetD32Async((hipDeviceptr_t)hxl, (int)PERSIST_SENTINEL, (size_t)fl_hx_floats(S, N), st));
-      CK(hipEventRecord(e0, st));
-      hipLaunchKernelGGL(lstm_enc_fwd_local_kernel<0>, dim3(8 * FL_TILES), dim3(FWD_THREADS), 0, st, pf);
-      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
-      CK(hipEventElapsedTime(&ms, e0, e1));
-      CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
-      printf("fwd local: %.3f us / step (status %d)\n", ms * 1e3 / S, status);
-    }
-    return report("fwd local", 8 * FL_TILES, 0.01, 8 * FL_TILES);
-  }
   // tick calibration: stamps span of the traced window vs the event-timed period is
   // not exact, so calibrate s_memtime against the wall clock with a sleep kernel instead
   double us_per_tick = 0.01;   // 100 MHz
-  if (getenv("LOCAL")) { printf("(LOCAL: per-phase report skipped)\n"); }
-  else if (report("fwd", (int)(H / 4) * 2 * chF, us_per_tick, (int)(H / 4))) return 1;
+  if (report("fwd", (int)(H / 4) * 2 * chF, us_per_tick, (int)(H / 4))) return 1;
   CK(hipMemset(gates, 0, sizeof(float) * 2 * rows * 4 * H));
-  const bool rs = getenv("GATHER") == nullptr;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemsetAsync(sync, 0, 32, st));
     CK(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL,
-                         rs ? (size_t)2 * chB * BWD_RS_RING * 256 * 256 : (size_t)(2 * S * 4 * H * NpB), st));
+                         (size_t)2 * chB * BWD_RS_RING * 256 * 256, st));
     CK(hipEventRecord(e0, st));
-    if (rs && getenv("HALVES_OFF")) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
-    else if (rs && getenv("QUARTERS")) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 4>), dim3(H / 16, 2, chB * 4), dim3(320), 0, st, pb);
-    else if (rs && getenv("LOCAL") && 2 * chB <= 8) {
-      pb.local = 2; pb.nchunk = chB;
-      hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), dim3(8 * (H / 16) * 2), dim3(320), 0, st, pb);
-    }
-    else if (rs) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), dim3(H / 16, 2, chB * 2), dim3(320), 0, st, pb);
-    else hipLaunchKernelGGL((lstm_enc_bwd_persistent_kernel<16, true>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
+    if (getenv("HALVES_OFF")) hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 1>), dim3(H / 16, 2, chB), dim3(320), 0, st, pb);
+    else hipLaunchKernelGGL((lstm_enc_bwd_rs_kernel<4, 2>), dim3(H / 16, 2, chB * 2), dim3(320), 0, st, pb);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(&status, sync + 4, 4, hipMemcpyDeviceToHost));
-    printf("bwd %s: %.3f us / step (status %d)\n", rs ? "K-split" : "gather", ms * 1e3 / S, status);
+    printf("bwd K-split: %.3f us / step (status %d)\n", ms * 1e3 / S, status);
   }
-  if (getenv("LOCAL")) return report("bwd (local)", 256, us_per_tick, 256);
-  if (report("bwd", (int)(H / 16) * 2 * chB * (rs && getenv("QUARTERS") ? 4 : rs && !getenv("HALVES_OFF") ? 2 : 1), us_per_tick, (int)(H / 16))) return 1;
+  if (report("bwd", (int)(H / 16) * 2 * chB * (!getenv("HALVES_OFF") ? 2 : 1), us_per_tick, (int)(H / 16))) return 1;
   return 0;
 }
