@@ -405,13 +405,32 @@ int ssasr_gather_batch(const float* frames, const int64_t* offsets, const int32_
 /* Log-mel filterbank of one waveform: log_fbank, src/preprocess.py:187-208
  * (librosa 0.6.3 melspectrogram defaults: centred reflect-padded STFT with a
  * periodic Hann window of n_fft samples, power 2, Slaney mel filters, then
- * log(S + 2.22e-16)).  F = ssasr_logmel_frames(n_samples, hop) = 1 + n/hop.
+ * log(S + 2.22e-16)).  F = ssasr_logmel_frames(n_samples, n_fft, hop) = 1 + (n + 2 (n_fft / 2) - n_fft) / hop,
+ * librosa's centred framing (1 + n / hop for an even window).
  * Constants (host-built, device-resident): window [n_fft]; dft_basis
  * [2*nb][Kp] with nb = n_fft/2+1, Kp = roundup(n_fft,4), rows 0..nb-1 =
  * cos(2 pi k n / n_fft), rows nb.. = sin; mel_basis [n_mels][nbp], nbp =
  * roundup(nb,4).  Workspaces: ws_frames [F][Kp], ws_spec [F][2*nb], ws_power
  * [F][nbp].  out [F][n_mels]. */
-int64_t ssasr_logmel_frames(int64_t n_samples, int64_t hop);
+int64_t ssasr_logmel_frames(int64_t n_samples, int64_t n_fft, int64_t hop);
+/* The same for a BATCH of utterances in three launches instead of four per utterance, without the
+ * framed copy and without the complex spectrum in memory: (1) every waveform, reflect-extended, is laid
+ * out hop-aligned in ws_wave -- utterance u at sample first_row_u * hop, occupying
+ * ssasr_logmel_batch_rows(n_u, n_fft, hop) rows of `hop` samples, of which the first
+ * ssasr_logmel_frames(n_u, n_fft, hop) are its frames (the rest straddle into the next utterance: ignore them);
+ * (2) ONE DFT product over all rows, whose A operand is ws_wave read as overlapping rows of stride hop,
+ * against dft_basis_w [2*nb][Kp]: the window folded into the basis and the cos / sin rows of a bin
+ * interleaved (w cos_0, w sin_0, w cos_1, ...), so that the epilogue writes re^2 + im^2; (3) the mel
+ * product with the log epilogue.
+ * wav: all waveforms (any layout); utt: DEVICE int64 [n_utts][3] = {offset of the utterance in wav, its
+ * sample count, its first row}; max_samples / total_rows: the longest utterance / the sum of all rows
+ * (host values).  ws_wave: total_rows * hop + n_fft floats; ws_power: total_rows * nbp floats;
+ * out [total_rows][n_mels] (rows of utterance u: first_row_u ... + frames_u). */
+int64_t ssasr_logmel_batch_rows(int64_t n_samples, int64_t n_fft, int64_t hop);
+int ssasr_logmel_batch(const float* wav, const int64_t* utt, int64_t n_utts, int64_t max_samples,
+                       int64_t total_rows, int64_t n_fft, int64_t hop, int64_t n_mels,
+                       const float* dft_basis_w, const float* mel_basis, float* ws_wave, float* ws_power,
+                       float* out, void* stream);
 int ssasr_logmel(const float* wav, int64_t n_samples, int64_t n_fft, int64_t hop, int64_t n_mels,
                  const float* window, const float* dft_basis, const float* mel_basis,
                  float* ws_frames, float* ws_spec, float* ws_power, float* out, void* stream);

@@ -87,7 +87,9 @@ SIGNATURES = {
     'ssasr_decoder_bwd_chain_floats': (I64, [I64] * 6),
     'ssasr_frame_lengths': (I32, [P, I64, I64, I64, P, P]),
     'ssasr_gather_batch': (I32, [P, P, P, I64, I64, I64, P, P]),
-    'ssasr_logmel_frames': (I64, [I64, I64]),
+    'ssasr_logmel_frames': (I64, [I64, I64, I64]),
+    'ssasr_logmel_batch_rows': (I64, [I64, I64, I64]),
+    'ssasr_logmel_batch': (I32, [P, P, I64, I64, I64, I64, I64, I64, P, P, P, P, P, P]),
     'ssasr_logmel': (I32, [P, I64, I64, I64, I64, P, P, P, P, P, P, P, P]),
 }
 

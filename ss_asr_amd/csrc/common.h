@@ -140,11 +140,28 @@ struct GemmDesc {
   int tb;              // 0: B stored [N][K]   1: B stored [K][N]
   const float* bias1;  // per output column, optional
   const float* bias2;  // per output column, optional
-  int act;             // 0 none, 1 tanh, 2 log(x + 2.22e-16)
+  int act;             // 0 none, 1 tanh, 2 log(x + 2.22e-16), 3 pairs of columns -> C[m][n / 2] = c0^2 + c1^2 (splitk == 1)
   float alpha, beta;   // C = act(alpha * A.B + bias) + beta * C
   int splitk;          // >1: partial products are atomically added into C
   int batch;
   int64_t sa, sb, sc, sbias;
+  // nseg > 0 (split-bf16 kernel, ta = tb = 1, batch <= 2): the N axis is a CONCATENATION of up to two column
+  // segments that share the A operand's rows but bring their own B, C and K window -- the weight gradients of
+  // an LSTM range in one pass over the gate derivatives, dG^T . [X | H_prev] (rnn.hip, wgrad_fused).  B, C, N,
+  // K, mb, mc, sb, sc of the descriptor are then unused; M, ma, ta / tb, alpha / beta, splitk apply to all.
+  // colsum[b] / colsum2[b] (optional): the workgroups of the first column tile also add the column sums of
+  // their A rows (over segment 0's K window) into these [M] vectors: the two bias gradients.
+  int nseg;
+  struct Seg {
+    const float* A[2];     // per batch: first row (k) of this segment's K window of A
+    const float* B[2];     // per batch
+    float* C[2];           // per batch
+    RowMap mb;             // maps k (tb = 1)
+    int64_t ldc;
+    int N, K;
+  } seg[2];
+  float* colsum[2];
+  float* colsum2[2];
   // kcat > 1 (split-bf16 kernel, splitk == 1): the product runs over kcat K segments of length K each, the
   // s-th taken at A + s * ska and B + s * skb, all into ONE accumulator: C = act(alpha * sum_s A_s . B_s ...)
   // -- e.g. the input gradient dX = dG_f W_f + dG_r W_r of a BiLSTM layer as one launch, C written once
@@ -182,6 +199,7 @@ struct SsasrOptions {
   int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
   int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs (0: on v_mfma_f32_16x16x4_f32)
   int gemm_kcat;                  // SSASR_GEMM_KCAT (1): a layer's input gradient as ONE launch over both directions' K segments
+  int wgrad_fused;                // SSASR_WGRAD_FUSED (1): a range's dW_ih, dW_hh and bias gradients as ONE launch, one pass over dG
   int last_seg_pct;               // SSASR_LAST_SEG_PCT (60): length of the LAST recurrence range of a segmented BPTT, in percent of an equal share
   int tail_inline;                // SSASR_TAIL_INLINE (1): the first layer's last range of weight-gradient products on the main stream
   int no_residency_check;         // SSASR_NO_RESIDENCY_CHECK: skip the occupancy query before persistent launches

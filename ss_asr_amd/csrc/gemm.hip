@@ -263,6 +263,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x4 (&a
           if (nb + e < g.N) atomicAdd(C + rowoff + nb + e, v[e]);
         continue;
       }
+      if (g.act == 3) {
+        // columns come in (re, im) pairs (a DFT against a basis whose cos / sin rows are interleaved): the
+        // lane's four columns are two bins, C[m][n / 2] = re^2 + im^2 -- the power spectrum leaves the
+        // product's epilogue, the complex spectrum never exists in memory (frontend.hip)
+        float* dst = C + rowoff + (nb >> 1);
+        if (nb + 1 < g.N) dst[0] = v[0] * v[0] + v[1] * v[1];
+        if (nb + 3 < g.N) dst[1] = v[2] * v[2] + v[3] * v[3];
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (g.act == 1) v[e] = tanhf(v[e]);
@@ -512,11 +521,15 @@ __device__ __forceinline__ bf16x8 x_operand(const char* img, int plane, int base
   else return x_frag<BMN>(img, plane, base + r, q);
 }
 
-template <int BM, int BN, bool TA, bool TB, bool TR>
-__global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, bool vecB) {
+// SEG (GemmDesc::nseg > 0, TA = TB = true): the column tiles of the launch belong to up to two segments, each
+// with its own B / C / K window over shared A rows; the workgroups of the first column tile also sum the
+// columns of the A rows they stream (GemmDesc::colsum).  One launch = one pass over A.
+template <int BM, int BN, bool TA, bool TB, bool TR, bool SEG = false>
+__global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc gin, bool vecA, bool vecB) {
   constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
   constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 fragments per wave
   extern __shared__ __attribute__((aligned(16))) char xlds[];
+  static_assert(!SEG || (TA && TB), "column segments: both operands MN-contiguous");
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -524,8 +537,21 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
   const int wm = wave >> 1, wn = wave & 1;
   int bx, by, bzz;
   gemm_tile_of_block(bx, by, bzz);
+  GemmDesc g = gin;
   const int bz = bzz / g.splitk;
   const int kz = bzz - bz * g.splitk;
+  bool do_colsum = false;
+  if constexpr (SEG) {
+    // which segment this column tile belongs to; from here on the descriptor is that segment's product
+    const int nt0 = (gin.seg[0].N + BN - 1) / BN;
+    const int sidx = bx >= nt0 ? 1 : 0;
+    do_colsum = bx == 0 && gin.colsum[bz] != nullptr;
+    if (sidx) bx -= nt0;
+    g.A = gin.seg[sidx].A[bz]; g.sa = 0;
+    g.B = gin.seg[sidx].B[bz]; g.sb = 0; g.mb = gin.seg[sidx].mb;
+    g.C = gin.seg[sidx].C[bz]; g.sc = 0; g.mc = RowMap{gin.seg[sidx].ldc, 0, 0, 0};
+    g.N = gin.seg[sidx].N; g.K = gin.seg[sidx].K;
+  }
   const int m0 = by * BM, n0 = bx * BN;
 
   // kcat > 1 (splitk == 1, K % BK == 0, dense K layouts: checked by the launcher): the K loop runs over kcat
@@ -545,6 +571,15 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
   la.init(opA, m0, kbeg, tid, 0);
   lb.init(opB, n0, kbeg, tid, 128);
   const bool interior = vecA && vecB && (!TA || g.M % 4 == 0) && (!TB || g.N % 4 == 0);
+  // column sums of the A rows this workgroup streams: thread tid always holds the same four columns
+  // m0 + 4 * (tid % (BM / 4)) .. + 3 of every K step (XTLoader's layout), so it sums them in registers
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto colsum_add = [&](const float4 (&v)[XLoaderOf<BM, TA>::NV]) {
+    if (la.idx[0] < g.M) {        // (columns past M alias valid ones on the predicate-free path)
+#pragma unroll
+      for (int i = 0; i < XLoaderOf<BM, TA>::NV; ++i) { csum.x += v[i].x; csum.y += v[i].y; csum.z += v[i].z; csum.w += v[i].w; }
+    }
+  };
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -558,6 +593,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
     else { la.load_guarded(ra, kbeg, kend, vecA); lb.load_guarded(rb, kbeg, kend, vecB); }
     la.store(xlds, ra);
     lb.store(xlds + XGeom<BM>::BYTES, rb);
+    if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
   }
   __syncthreads();
 
@@ -598,6 +634,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
     if (more) {
       la.store(xlds, ra);
       lb.store(xlds + XGeom<BM>::BYTES, rb);
+      if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
     }
     SSASR_X6_STEP(1, 0);
     SSASR_X6_STEP(0, 1);
@@ -606,6 +643,31 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc g, bool vecA, boo
     __syncthreads();          // the next tile is in place
   }
   gemm_epilogue<TM, TN, WM, WN, TR>(g, acc, m0, n0, wm, wn, r, q, bz, kz);
+  if constexpr (SEG) {
+    if (do_colsum) {          // (workgroup-uniform) the 256 / (BM / 4) threads of a column quad meet in LDS
+      constexpr int PER_ROW = BM / 4;
+      float4* red = reinterpret_cast<float4*>(xlds);          // the operand image is no longer read
+      red[tid] = csum;
+      __syncthreads();
+      if (tid < PER_ROW) {
+        float4 v = red[tid];
+#pragma unroll
+        for (int k = 1; k < 256 / PER_ROW; ++k) {
+          const float4 a = red[tid + k * PER_ROW];
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        const int m = m0 + 4 * tid;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (m + e < g.M) {
+            atomicAdd(gin.colsum[bz] + m + e, g.alpha * vv[e]);
+            if (gin.colsum2[bz]) atomicAdd(gin.colsum2[bz] + m + e, g.alpha * vv[e]);
+          }
+        }
+      }
+    }
+  }
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -637,6 +699,20 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
     if (g.splitk > 1) SSASR_X6_LAUNCH(A_, B_, false);                                                       \
     else SSASR_X6_LAUNCH(A_, B_, true);                                                                     \
   } while (0)
+    if (g.nseg > 0) {                 // column segments (validated by ssasr_launch_gemm): partial products are
+      int nt = 0;                     // always ADDED (atomics): several K slices and earlier ranges meet in C
+      for (int k = 0; k < g.nseg; ++k) nt += (g.seg[k].N + BN - 1) / BN;
+      grid.x = (unsigned)nt;
+      auto fn = gemm_x6_kernel<BM, BN, true, true, false, true>;
+      static bool once_seg = false;
+      if (!once_seg) {
+        SSASR_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once_seg = true;
+      }
+      hipLaunchKernelGGL(fn, grid, block, lds, st, g, vecA, vecB);
+      SSASR_LAUNCH_CHECK();
+      return SSASR_OK;
+    }
     if (!g.ta && !g.tb) SSASR_X6_PICK(false, false);
     else if (!g.ta && g.tb) SSASR_X6_PICK(false, true);
     else if (g.ta && !g.tb) SSASR_X6_PICK(true, false);
@@ -668,12 +744,41 @@ size_t ssasr_gemm_min_lds_bytes() {
   return sizeof(float) * 2 * (TileGeom<64, false>::FLOATS + TileGeom<64, false>::FLOATS);
 }
 
+// Column segments (GemmDesc::nseg): one launch of the split-bf16 kernel, 64 x 64 tiles (the products are
+// weight gradients of 1,024 rows x a few hundred columns: fine-grained tiles fill the chip; the K slices do the
+// rest), partial products added atomically.
+static int launch_segments(GemmDesc g, hipStream_t st) {
+  if (!ssasr_options().gemm_x6 || g.nseg > 2 || !g.ta || !g.tb || g.batch < 1 || g.batch > 2 || g.M <= 0 || g.ma.inner ||
+      g.kcat > 1 || g.act != 0 || g.bias1 || g.bias2)
+    return SSASR_EARG;
+  if (g.splitk < 1) g.splitk = 1;
+  bool vecA = map_vec_ok(g.ma), vecB = true;
+  int nt = 0;
+  for (int k = 0; k < g.nseg; ++k) {
+    const GemmDesc::Seg& sg = g.seg[k];
+    if (sg.N <= 0 || sg.K <= 0 || sg.ldc < sg.N) return SSASR_EARG;
+    for (int b = 0; b < g.batch; ++b) {
+      if (!sg.A[b] || !sg.B[b] || !sg.C[b]) return SSASR_EARG;
+      vecA = vecA && aligned16(sg.A[b]);
+      vecB = vecB && aligned16(sg.B[b]);
+    }
+    vecB = vecB && map_vec_ok(sg.mb);
+    nt += (sg.N + 63) / 64;
+  }
+  for (int b = g.batch; b < 2; ++b) { g.colsum[b] = nullptr; g.colsum2[b] = nullptr; }
+  if ((int64_t)nt * g.batch * g.splitk > 65535 * 64) return SSASR_EARG;
+  g.N = 64 * nt; g.K = 0;          // (grid geometry only: launch_tiles sizes grid.x / grid.y from N / M)
+  return launch_tiles<64, 64>(g, vecA, vecB, st);
+}
+
 int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   GemmDesc g = gin;
+  if (g.nseg > 0) return launch_segments(g, st);
   if (g.M <= 0 || g.N <= 0 || g.batch <= 0) return SSASR_OK;
   if (g.K < 0 || !g.A || !g.B || !g.C) return SSASR_EARG;
   if (g.splitk < 1) g.splitk = 1;
   if (g.splitk > 1 && g.act != 0) return SSASR_EARG;
+  if (g.act == 3 && (g.bias1 || g.bias2 || g.beta != 0.f || (g.N & 1))) return SSASR_EARG;
   // K segments: split-bf16 kernel only, whole K steps per segment, dense (row-major) K-side layouts
   if (g.kcat > 1 && (g.splitk != 1 || !ssasr_options().gemm_x6 || g.K % 32 != 0 || (g.ta && g.ma.inner) ||
                      (g.tb && g.mb.inner)))

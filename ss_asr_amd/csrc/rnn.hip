@@ -451,6 +451,71 @@ extern "C" int ssasr_events_destroy(void* handle) {
   return SSASR_OK;
 }
 
+// The weight gradients of a step range in ONE launch and ONE pass over the gate derivatives (the
+// two products and the column sums each streamed dG again, ~3 x its bytes on the stream that shares the memory
+// system with the BPTT): dG^T . [X | H_prev] as the two column segments of a split-bf16 GEMM launch
+// (GemmDesc::nseg), the bias gradients as column sums formed by the workgroups of the first column tile from
+// the dG rows they stream anyway.  nb = 1 (one direction: lo / hi / the outputs of index 0) or 2 (both
+// directions as the launch's two batches; ranges of equal length).  Returns SSASR_EARG when the form does not
+// apply (options, alignment): the caller then takes the separate launches.
+static int wgrad_fused(int nb, const int d_of[2], const int64_t lo[2], const int64_t hi[2], const float* dgates,
+                       const float* x, int64_t xs_s, int64_t xs_n, const float* hs, int64_t S, int64_t N, int64_t I,
+                       int64_t H, float* const dwih[2], float* const dwhh[2], float* const db[2], float* const db2[2],
+                       hipStream_t st) {
+  const SsasrOptions& opt = ssasr_options();
+  if (!opt.wgrad_fused || !opt.gemm_x6 || nb < 1 || nb > 2) return SSASR_EARG;
+  const int64_t rows = S * N;
+  if (hi[0] <= lo[0] || (nb == 2 && hi[1] - lo[1] != hi[0] - lo[0])) return SSASR_EARG;
+  // the recurrent product skips the step without a predecessor: s = 0 (forward) / s = S - 1 (reverse)
+  int64_t a0[2], a1[2];
+  for (int b = 0; b < nb; ++b) {
+    a0[b] = d_of[b] ? lo[b] : (lo[b] > 1 ? lo[b] : 1);
+    a1[b] = d_of[b] ? (hi[b] < S - 1 ? hi[b] : S - 1) : hi[b];
+  }
+  if (nb == 2 && a1[1] - a0[1] != a1[0] - a0[0]) return SSASR_EARG;
+  GemmDesc g{};
+  g.ma = rm_dense(4 * H);
+  g.M = (int)(4 * H); g.ta = 1; g.tb = 1; g.alpha = 1.f; g.beta = 1.f; g.batch = nb;
+  int ns = 0;
+  {           // dW_ih[d] += dG_d[range]^T . X[range]
+    GemmDesc::Seg& sg = g.seg[ns++];
+    for (int b = 0; b < nb; ++b) {
+      sg.A[b] = dgates + d_of[b] * rows * 4 * H + lo[b] * N * 4 * H;
+      sg.B[b] = x + lo[b] * xs_s;
+      sg.C[b] = dwih[b];
+    }
+    sg.mb = RowMap{0, N, xs_s, xs_n}; sg.ldc = I; sg.N = (int)I; sg.K = (int)((hi[0] - lo[0]) * N);
+  }
+  if (a1[0] > a0[0]) {           // dW_hh[d] += sum_s dG_d[s]^T . h_d[s_prev]
+    GemmDesc::Seg& sg = g.seg[ns++];
+    for (int b = 0; b < nb; ++b) {
+      sg.A[b] = dgates + d_of[b] * rows * 4 * H + a0[b] * N * 4 * H;
+      sg.B[b] = hs + d_of[b] * rows * H + (d_of[b] ? a0[b] + 1 : a0[b] - 1) * N * H;
+      sg.C[b] = dwhh[b];
+    }
+    sg.mb = rm_dense(H); sg.ldc = H; sg.N = (int)H; sg.K = (int)((a1[0] - a0[0]) * N);
+  }
+  g.nseg = ns;
+  for (int b = 0; b < nb; ++b) { g.colsum[b] = db[b]; g.colsum2[b] = db2[b]; }
+  // K slices.  The products are compute bound and run beside a recurrence that keeps half of the CUs, i.e. on
+  // ~512 workgroup slots (128 CUs x 4 workgroups of 64 x 64 tiles): a launch costs rounds x K steps per
+  // workgroup, rounds = ceil(tiles * sk / slots), plus ~2 steps of prologue / epilogue per round.  The first
+  // version aimed at 640 workgroups whatever the shape and ran two rounds where the separate launches ran one
+  // (5.87 against 5.79 ms per train step); pick the sk with the least cost, the smallest on a tie (fewer atomics).
+  const int64_t tiles = nb * ((4 * H + 63) / 64) * ((I + 63) / 64 + (ns > 1 ? (H + 63) / 64 : 0));
+  const int64_t ksteps = (g.seg[0].K + 31) / 32;
+  int sk = 1;
+  int64_t best = -1;
+  for (int c = 1; c <= 16; ++c) {
+    if (c > 1 && g.seg[ns - 1].K < 64 * c) break;
+    const int64_t rounds = (tiles * c + 511) / 512;
+    const int64_t cost = rounds * ((ksteps + c - 1) / c + 2);
+    if (best < 0 || cost < best) { best = cost; sk = c; }
+  }
+  g.splitk = sk;
+  return ssasr_launch_gemm(g, st);
+}
+
 // Weight / bias gradients of direction d from the time steps [s_lo, s_hi) only, added to the
 // outputs (which the caller zeroed if needed).
 static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgates, const float* x, int64_t xs_s,
@@ -460,6 +525,16 @@ static int wgrad_dir_range(int d, int64_t s_lo, int64_t s_hi, const float* dgate
   const float* dG = dgates + d * rows * 4 * H;
   int rc;
   if (s_hi <= s_lo) return SSASR_OK;
+  {
+    const int d_of[2] = {d, d};
+    const int64_t lo[2] = {s_lo, s_lo}, hi[2] = {s_hi, s_hi};
+    float* const w1[2] = {dwih, nullptr};
+    float* const w2[2] = {dwhh, nullptr};
+    float* const b1[2] = {db, nullptr};
+    float* const b2[2] = {db2, nullptr};
+    rc = wgrad_fused(1, d_of, lo, hi, dgates, x, xs_s, xs_n, hs, S, N, I, H, w1, w2, b1, b2, st);
+    if (rc != SSASR_EARG) return rc;
+  }
   {           // dW_ih += dG[s_lo:s_hi]^T . X[s_lo:s_hi]
     GemmDesc g{};
     g.A = dG + s_lo * N * 4 * H; g.ma = rm_dense(4 * H);
@@ -512,6 +587,12 @@ static int wgrad_pair_range(int64_t lo0, int64_t hi0, int64_t lo1, int64_t hi1, 
     return wgrad_dir_range(1, lo1, hi1, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih[1], dwhh[1], db[1], db2[1], st);
   }
   int rc;
+  {
+    const int d_of[2] = {0, 1};
+    const int64_t lo[2] = {lo0, lo1}, hi[2] = {hi0, hi1};
+    rc = wgrad_fused(2, d_of, lo, hi, dgates, x, xs_s, xs_n, hs, S, N, I, H, dwih, dwhh, db, db2, st);
+    if (rc != SSASR_EARG) return rc;
+  }
   {           // dW_ih[d] += dG_d[range_d]^T . X[range_d]
     GemmDesc g{};
     g.A = dgates + lo0 * N * 4 * H; g.ma = rm_dense(4 * H);

@@ -71,45 +71,59 @@ class GpuResidentLoader:
     @classmethod
     def from_waveforms(cls, waves, sample_rate, texts, batch_size, device, n_mels=None, chars=TOKENS + ALL_CHARS,
                        rank=0, world=1, time_multiple=8):
-        """The corpus built from WAVEFORMS on the GPU: every utterance goes through the log-mel frontend
-        (frontend.log_fbank -> ssasr_logmel; src/preprocess.py:187-208 is what it replaces) and its frames
-        stay on the device -- no .npy round trip, no host copy of the features.  `waves`: 1-D float arrays
+        """The corpus built from WAVEFORMS on the GPU: all utterances go through the log-mel frontend in ONE
+        batched call (frontend.log_fbank_batch -> ssasr_logmel_batch; src/preprocess.py:187-208 is what it
+        replaces) and the frames stay on the device -- no .npy round trip, no host copy of the features.  `waves`: 1-D float arrays
         (or tensors) at `sample_rate`; `texts`: the normalised transcripts WITHOUT the '<' '>' tokens.
         Utterances are ordered by decreasing frame count first (the order the reference's index must
         have inside a batch, conf/README.md:16), then cut into whole batches as everywhere else.
         (The frontend's parity with librosa 0.6.3 is unpinned: DESIGN.md 4.6.)"""
-        from .frontend import log_fbank
+        from . import _lib
+        from .frontend import frontend_constants, log_fbank_batch
         from .preprocess import EOS_TKN, N_DIMS
         n_mels = n_mels or N_DIMS
         char2idx = {c: i for i, c in enumerate(chars)}
-        feats = [log_fbank(w, sample_rate, n_mels) for w in waves]
-        order = sorted(range(len(feats)), key=lambda i: -feats[i].shape[0])
+        # frame counts are known before anything is computed (1 + samples // hop): order and cut first, then ONE
+        # batched frontend call over the kept utterances in that order (frontend.log_fbank_batch: three
+        # launches for the whole corpus); the features stay where the call wrote them -- utterance i's frames
+        # at rows first[i] .., with a few unused rows between utterances -- and the loader's offsets point there
+        n_fft, hop = frontend_constants(sample_rate, n_mels, torch.device(device))[:2]
+        nfr = [int(_lib.load().ssasr_logmel_frames(int(torch.as_tensor(w).numel()), n_fft, hop)) for w in waves]
+        order = sorted(range(len(waves)), key=lambda i: -nfr[i])
         n = len(plan_batches(len(order), batch_size)) * batch_size
         order = order[:n]
+        feats, first, frames = log_fbank_batch([waves[i] for i in order], sample_rate, n_mels, device=device)
         self = cls.__new__(cls)
         self.rows = None
         labels = [[char2idx[SOS_TKN]] + [char2idx[c] for c in texts[i]] + [char2idx[EOS_TKN]] for i in order]
-        self._setup([feats[i] for i in order], labels, batch_size, device, rank, world, time_multiple, char2idx[SOS_TKN])
+        self._setup(None, labels, batch_size, device, rank, world, time_multiple, char2idx[SOS_TKN],
+                    resident=(feats, first, frames))
         return self
 
-    def _setup(self, kept, labels, batch_size, device, rank, world, time_multiple, pad):
+    def _setup(self, kept, labels, batch_size, device, rank, world, time_multiple, pad, resident=None):
+        """kept: the utterances' unpadded [n_i, F] arrays (uploaded back to back), or None with
+        resident = (frames tensor on the device, first row of every utterance, its frame count)."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('GpuResidentLoader keeps the corpus on the GPU (no CPU path)')
         self.batch_size = batch_size
         self.rank, self.world = rank, world
         self.time_multiple = time_multiple
-        self.starts = plan_batches(len(kept), batch_size)
-        lens = [int(a.shape[0]) for a in kept]
-        self.feature_dim = kept[0].shape[1] if kept else 0
-        self.x_lens = lens
-        offs = np.zeros(len(lens) + 1, dtype=np.int64)
-        np.cumsum(lens, out=offs[1:])
-        # one upload each; batches are views of these
-        if kept and torch.is_tensor(kept[0]):       # features that were computed on the device stay there
-            self.frames = torch.cat([a.to(self.device, torch.float32) for a in kept], dim=0)
+        if resident is not None:
+            self.frames, first, lens = resident
+            lens = [int(v) for v in lens]
+            self.starts = plan_batches(len(lens), batch_size)
+            self.feature_dim = int(self.frames.shape[1])
+            offs = np.asarray(list(first) + [0], dtype=np.int64)
         else:
+            self.starts = plan_batches(len(kept), batch_size)
+            lens = [int(a.shape[0]) for a in kept]
+            self.feature_dim = kept[0].shape[1] if kept else 0
+            offs = np.zeros(len(lens) + 1, dtype=np.int64)
+            np.cumsum(lens, out=offs[1:])
+            # one upload; batches are gathered from it
             self.frames = torch.from_numpy(np.concatenate(kept, axis=0)).to(self.device) if kept else None
+        self.x_lens = lens
         self.offsets = torch.from_numpy(offs[:-1].copy()).to(self.device)
         self.lens_dev = torch.tensor(lens, dtype=torch.int32, device=self.device)
         # labels: padded with <sos> like ASRDataset.get_batched_texts

@@ -154,14 +154,30 @@ def test_bilstm_packed_forward_backward(N, T, I, H, lens):
         close(a.grad, b.grad, 2e-4, 'd' + name)
 
 
-@pytest.mark.parametrize('N,S,I,H,segments', [(20, 150, 24, 64, 4), (9, 130, 16, 128, 3), (20, 150, 24, 64, 1)])
-def test_bilstm_segmented_bptt_with_overlapped_weight_gradients(N, S, I, H, segments, monkeypatch):
+@pytest.mark.parametrize('fused', [1, 0])
+@pytest.mark.parametrize('N,S,I,H,segments', [(20, 150, 24, 64, 4), (9, 130, 16, 128, 3), (20, 150, 24, 64, 1),
+                                              (32, 96, 80, 256, 4),        # the first layer's shape: I = 80 (a partly filled column tile)
+                                              (16, 64, 1024, 256, 2)])     # layers 2-3: I = 1024
+def test_bilstm_segmented_bptt_with_overlapped_weight_gradients(N, S, I, H, segments, fused, monkeypatch):
     """The path the train step takes: gradients live in an optimizer-owned flat buffer, so the
     BPTT runs in step-range segments (ring and dc state carried across launches) and the weight
-    gradients are accumulated from a second stream, range by range."""
-    from ss_asr_amd import ops
+    gradients are accumulated from a second stream, range by range -- as ONE launch per range
+    (SSASR_WGRAD_FUSED, default: dG^T . [X | H_prev] as the column segments of one GEMM launch, the
+    bias gradients as column sums of the dG rows its first column tile streams) or as the separate
+    products and column sums."""
+    from ss_asr_amd import _lib, ops
     from ss_asr_amd.optim import FlatParameters
     monkeypatch.setattr(ops, 'bptt_segments', segments)
+    old_fused = _lib.set_option('SSASR_WGRAD_FUSED', fused)
+    try:
+        _segmented_bptt_case(N, S, I, H)
+    finally:
+        _lib.set_option('SSASR_WGRAD_FUSED', old_fused)
+
+
+def _segmented_bptt_case(N, S, I, H):
+    from ss_asr_amd import ops
+    from ss_asr_amd.optim import FlatParameters
     lens = sorted(np.random.default_rng(3).integers(S // 3, S + 1, size=N).tolist(), reverse=True)
     lens[0] = S
     x = rnd(N, S, I, seed=51)
