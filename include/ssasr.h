@@ -81,8 +81,8 @@ int ssasr_gemm_f32(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha,
  * produce zeros in y (pad_packed_sequence, src/asr.py:417).
  * y element (s, n, d * H + u) at y[s * ys_s + n * ys_n + d * H + u].
  * Saved for backward: gates [2][S*N][4H], cs [2][S*N][H], hs [2][S*N][H].
- * Optional workspaces that enable the single-launch persistent recurrence
- * (taken when H % 64 == 0 and N <= 128): hx, ssasr_bilstm_fwd_hx_floats(S, N, H) floats of
+ * Optional workspaces that enable the persistent recurrence (taken when H % 64 == 0: one launch per window of
+ * 128 columns, i.e. a single launch up to N = 128): hx, ssasr_bilstm_fwd_hx_floats(S, N, H) floats of
  * exchange image (layout internal: [2][S][H/4][roundup(N,8)][4] floats), and sync_ws int32[8],
  * ZERO ON ENTRY (sync_ws[4] != 0
  * afterwards reports an exchange timeout); pass NULL for one launch per step.
@@ -108,8 +108,7 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
  * gate pre-activation derivatives).  tsave: what the forward call was given (then cs may be NULL).  dx may be NULL.  db_* is the derivative
  * of b_ih and of b_hh alike.  Workspaces: ws_whhT [2][H][4H], ws_dc [2][2][N][H].
  * dw_ih_f == NULL defers every weight gradient to ssasr_bilstm_wgrad.
- * Optional, enabling the single-launch persistent BPTT (H in {64,128,256},
- * N <= 128): gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats of exchange
+ * Optional, enabling the persistent BPTT (H in {64,128,256}; one launch per window of 128 columns): gx = ssasr_bilstm_bwd_gx_floats(S, N, H) floats of exchange
  * workspace (contents irrelevant on entry), sync_ws int32[8] zero on entry; NULL = one
  * launch per step. */
 int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H);

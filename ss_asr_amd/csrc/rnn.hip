@@ -45,12 +45,45 @@ static bool grid_fits(const void* kernel, int threads, size_t dyn_lds, int64_t w
   return cap <= 0 || workgroups <= cap;
 }
 
-// Floats of the forward recurrence's exchange image [2][S][H/4][Np][4], Np = N rounded up to whole 128-byte
-// lines (0: the shape has no persistent form).
+// Column windows.  The persistent recurrences take at most PERSIST_WINDOW columns per launch (every workgroup of
+// a launch must be resident: 512 forward workgroups = 128 columns at H = 256); a wider layer -- blstm_4 over the
+// 375 encoder frames of BASELINE.json configs[3] -- runs as consecutive launches over column windows of the
+// SAME buffers (EncPersist::nt: the columns are independent recurrences), so that the input projection, the
+// input gradient and the weight gradients stay single products over all columns.
+constexpr int64_t PERSIST_WINDOW = 128;
+static int64_t window_count(int64_t N) { return (N + PERSIST_WINDOW - 1) / PERSIST_WINDOW; }
+static int64_t window_width(int64_t N, int64_t w) { return std::min<int64_t>(PERSIST_WINDOW, N - w * PERSIST_WINDOW); }
+
+// forward kernel instance for k-blocks per wave kpw (H / 64), nb x 16 columns per workgroup, fused first-layer input
+static const void* fwd_fn(int kpw, int nb, bool fuse) {
+#define SSASR_FN(K, NBT) reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, NBT>)
+  if (fuse) return nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 1, 5>)
+                           : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 2, 5>);
+  return nb == 1 ? (kpw == 1 ? SSASR_FN(1, 1) : kpw == 2 ? SSASR_FN(2, 1) : kpw == 4 ? SSASR_FN(4, 1) : SSASR_FN(8, 1))
+                 : (kpw == 1 ? SSASR_FN(1, 2) : kpw == 2 ? SSASR_FN(2, 2) : kpw == 4 ? SSASR_FN(4, 2) : SSASR_FN(8, 2));
+#undef SSASR_FN
+}
+static void fwd_launch(int kpw, int nb, bool fuse, dim3 grid, hipStream_t st, const EncPersist& p) {
+  const dim3 block(FWD_THREADS);
+#define SSASR_L(K, NBT) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<K, NBT>), grid, block, 0, st, p)
+  if (fuse && nb == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, 1, 5>), grid, block, 0, st, p);
+  else if (fuse) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, 2, 5>), grid, block, 0, st, p);
+  else if (nb == 1) { if (kpw == 1) SSASR_L(1, 1); else if (kpw == 2) SSASR_L(2, 1); else if (kpw == 4) SSASR_L(4, 1); else SSASR_L(8, 1); }
+  else { if (kpw == 1) SSASR_L(1, 2); else if (kpw == 2) SSASR_L(2, 2); else if (kpw == 4) SSASR_L(4, 2); else SSASR_L(8, 2); }
+#undef SSASR_L
+}
+// 16 columns per workgroup spreads a window over twice the workgroups (shorter product, half the exchange read
+// per workgroup) when they all fit the chip at one per CU; else 32 columns
+static int fwd_nb(int64_t Nw, int64_t H) { return (H / 4) * 2 * ((Nw + 15) / 16) <= 256 ? 1 : 2; }
+static int64_t fwd_hx_floats_window(int64_t S, int64_t Nw, int64_t H) { return 2 * S * (H / 4) * ((Nw + 7) & ~(int64_t)7) * 4; }
+
+// Floats of the forward recurrence's exchange images, one [2][S][H/4][Np][4] per column window back to back,
+// Np = the window's columns rounded up to whole 128-byte lines (0: the shape has no persistent form).
 extern "C" int64_t ssasr_bilstm_fwd_hx_floats(int64_t S, int64_t N, int64_t H) {
-  if (S <= 0 || N <= 0 || H <= 0 || N > 128 || H % 64 != 0) return 0;
-  const int64_t Np = (N + 7) & ~(int64_t)7;
-  return 2 * S * (H / 4) * Np * 4;
+  if (S <= 0 || N <= 0 || H <= 0 || H % 64 != 0) return 0;
+  int64_t total = 0;
+  for (int64_t w = 0; w < window_count(N); ++w) total += fwd_hx_floats_window(S, window_width(N, w), H);
+  return total;
 }
 
 // ---------------------------------------------------------------------------
@@ -102,18 +135,12 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
   // (2) the recurrence, one launch per step, both directions per launch
   if (ys_s >= (1ll << 31) || ys_n >= (1ll << 31) || rows * 4 * H >= (1ll << 40)) return SSASR_EARG;
   if (!aligned16(w_hh_f) || !aligned16(w_hh_r) || !aligned16(hs)) return SSASR_EARG;   // 16-byte loads
-  // One persistent launch when the whole grid is certain to be resident
+  // One persistent launch per column window when its whole grid is certain to be resident
   // (rnn_kernels.h, "persistent forward recurrence"); else one launch per step.
   {
-    // 16 columns per workgroup spreads a layer over twice the workgroups (shorter
-    // product, half the exchange read per workgroup) when they all fit the chip;
-    // else 32 columns.
     const int kpw = (int)(H / 64);
-    const int64_t Np = (N + 7) & ~(int64_t)7;
-    const int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
-    const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
+    const int64_t nwin = window_count(N);
     bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
-                (H / 4) * 2 * chunks <= 512 && S * Np * H * 4 < (1ll << 31) &&   // <= 2 workgroups per CU
                 aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
                 ys_n % 4 == 0 && !opt.no_persistent;
     // status words are zero on entry (caller's contract)
@@ -122,19 +149,16 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     bool fuse_in = fits && kpw == 4 && I == 80 && bih[0] && bhh[0] && bih[1] && bhh[1] &&
                    aligned16(x) && aligned16(w_ih_f) && aligned16(w_ih_r) && xs_s % 4 == 0 && xs_n % 4 == 0 &&
                    !opt.no_fused_input;
-    // the kernel instance that would run, for the residency check
-    const void* kfn = nullptr;
-#define SSASR_FWD_FN(K, NBT) reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, NBT>)
-#define SSASR_FWD_FN_PICK(NBT) \
-    (kpw == 1 ? SSASR_FWD_FN(1, NBT) : kpw == 2 ? SSASR_FWD_FN(2, NBT) : kpw == 4 ? SSASR_FWD_FN(4, NBT) : SSASR_FWD_FN(8, NBT))
-    if (fits) {
-      if (fuse_in) kfn = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 1, 5>)
-                                 : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 2, 5>);
-      else kfn = nb == 1 ? SSASR_FWD_FN_PICK(1) : SSASR_FWD_FN_PICK(2);
-      if (!grid_fits(kfn, FWD_THREADS, 0, (H / 4) * 2 * chunks)) { fits = false; fuse_in = false; }
+    // every window's kernel instance must have its whole grid resident (<= 2 workgroups per CU)
+    for (int64_t w = 0; w < nwin && fits; ++w) {
+      const int64_t Nw = window_width(N, w), Npw = (Nw + 7) & ~(int64_t)7;
+      const int nb = fwd_nb(Nw, H);
+      const int64_t chunks = (Nw + 16 * nb - 1) / (16 * nb);
+      if ((H / 4) * 2 * chunks > 512 || S * Npw * H * 4 >= (1ll << 31) ||
+          !grid_fits(fwd_fn(kpw, nb, fuse_in), FWD_THREADS, 0, (H / 4) * 2 * chunks)) {
+        fits = false; fuse_in = false;
+      }
     }
-#undef SSASR_FWD_FN_PICK
-#undef SSASR_FWD_FN
     // tile-major saves exist in the persistent form only: a caller that passes the buffer was told
     // by ssasr_bilstm_tsave_floats that this shape takes it
     if (tsave && !fits) return SSASR_EARG;
@@ -143,34 +167,29 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
       if (rc) return rc;
     }
     if (fits) {
-      EncPersist p{};
-      p.tsave = tsave;
-      p.drop_tile = opt.test_drop_tile;
-      p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
-      p.x = x; p.xs_s = xs_s; p.xs_n = xs_n;
-      for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }
-      p.gates = gates; p.cs = cs; p.hs = hs; p.hx = hx; p.y = y; p.lens = lens;
-      p.status = sync_ws + 4;
-      p.delay = persist_delay(opt.delay_fwd, 24);
-      p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
-      dim3 pgrid((unsigned)(H / 4), 2, (unsigned)chunks), pblock(FWD_THREADS);   // 4 recurrence waves + the helper
       if (!armed)
-        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)(2 * S * Np * H), st));
-#define SSASR_FWD_LAUNCH(K, NBT) \
-      hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<K, NBT>), pgrid, pblock, 0, st, p)
-#define SSASR_FWD_PICK(NBT)                                         \
-      do {                                                          \
-        if (kpw == 1) SSASR_FWD_LAUNCH(1, NBT);                     \
-        else if (kpw == 2) SSASR_FWD_LAUNCH(2, NBT);                \
-        else if (kpw == 4) SSASR_FWD_LAUNCH(4, NBT);                \
-        else SSASR_FWD_LAUNCH(8, NBT);                              \
-      } while (0)
-      if (fuse_in && nb == 1) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, 1, 5>), pgrid, pblock, 0, st, p);
-      else if (fuse_in) hipLaunchKernelGGL((lstm_enc_fwd_persistent_kernel<4, 2, 5>), pgrid, pblock, 0, st, p);
-      else if (nb == 1) SSASR_FWD_PICK(1);
-      else SSASR_FWD_PICK(2);
-#undef SSASR_FWD_PICK
-#undef SSASR_FWD_LAUNCH
+        SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)ssasr_bilstm_fwd_hx_floats(S, N, H), st));
+      float* hxw = hx;
+      for (int64_t w = 0; w < nwin; ++w) {
+        const int64_t n0 = w * PERSIST_WINDOW, Nw = window_width(N, w);
+        const int nb = fwd_nb(Nw, H);
+        const int64_t chunks = (Nw + 16 * nb - 1) / (16 * nb);
+        EncPersist p{};
+        // (the pointers of a window start at its first column; nt = the layer's width = their row stride)
+        p.tsave = tsave ? tsave + (n0 / 16) * (H / 16) * 5 * 256 : nullptr;
+        p.drop_tile = opt.test_drop_tile;
+        p.whh[0] = w_hh_f; p.whh[1] = w_hh_r;
+        p.x = x + n0 * xs_n; p.xs_s = xs_s; p.xs_n = xs_n;
+        for (int d = 0; d < 2; ++d) { p.wih[d] = wih[d]; p.bih[d] = bih[d]; p.bhh[d] = bhh[d]; }
+        p.gates = gates + n0 * 4 * H; p.cs = cs ? cs + n0 * H : nullptr; p.hs = hs + n0 * H; p.hx = hxw;
+        p.y = y + n0 * ys_n; p.lens = lens ? lens + n0 : nullptr;
+        p.status = sync_ws + 4;
+        p.delay = persist_delay(opt.delay_fwd, 24);
+        p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)Nw; p.H = (int)H;
+        p.nt = nwin > 1 ? (int)N : 0;
+        fwd_launch(kpw, nb, fuse_in, dim3((unsigned)(H / 4), 2, (unsigned)chunks), st, p);   // 4 recurrence waves + the helper
+        hxw += fwd_hx_floats_window(S, Nw, H);
+      }
       SSASR_LAUNCH_CHECK();
       return SSASR_OK;
     }
@@ -191,29 +210,24 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
 // the caller's: torch allocations are 256-byte aligned), residency of the grid included.
 static bool fwd_persistent_shape_ok(int64_t S, int64_t N, int64_t H) {
   const SsasrOptions& opt = ssasr_options();
-  if (S <= 0 || N <= 0 || N > 128 || H <= 0 || H % 64 != 0 || opt.no_persistent) return false;
+  if (S <= 0 || N <= 0 || H <= 0 || H % 64 != 0 || opt.no_persistent) return false;
   const int kpw = (int)(H / 64);
   if (!(kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8)) return false;
-  const int64_t Np = (N + 7) & ~(int64_t)7;
-  const int nb = (H / 4) * 2 * ((N + 15) / 16) <= 256 ? 1 : 2;
-  const int64_t chunks = (N + 16 * nb - 1) / (16 * nb);
-  if ((H / 4) * 2 * chunks > 512 || S * Np * H * 4 >= (1ll << 31)) return false;
-#define SSASR_FN(K, NBT) reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<K, NBT>)
-  const void* fn = nb == 1 ? (kpw == 1 ? SSASR_FN(1, 1) : kpw == 2 ? SSASR_FN(2, 1) : kpw == 4 ? SSASR_FN(4, 1) : SSASR_FN(8, 1))
-                           : (kpw == 1 ? SSASR_FN(1, 2) : kpw == 2 ? SSASR_FN(2, 2) : kpw == 4 ? SSASR_FN(4, 2) : SSASR_FN(8, 2));
-#undef SSASR_FN
-  if (!grid_fits(fn, FWD_THREADS, 0, (H / 4) * 2 * chunks)) return false;
-  if (kpw == 4) {      // the first layer's variant (fused input projection) is the larger kernel
-    const void* ff = nb == 1 ? reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 1, 5>)
-                             : reinterpret_cast<const void*>(lstm_enc_fwd_persistent_kernel<4, 2, 5>);
-    if (!grid_fits(ff, FWD_THREADS, 0, (H / 4) * 2 * chunks)) return false;
+  for (int64_t w = 0; w < window_count(N); ++w) {
+    const int64_t Nw = window_width(N, w), Npw = (Nw + 7) & ~(int64_t)7;
+    const int nb = fwd_nb(Nw, H);
+    const int64_t chunks = (Nw + 16 * nb - 1) / (16 * nb);
+    if ((H / 4) * 2 * chunks > 512 || S * Npw * H * 4 >= (1ll << 31)) return false;
+    if (!grid_fits(fwd_fn(kpw, nb, false), FWD_THREADS, 0, (H / 4) * 2 * chunks)) return false;
+    // the first layer's variant (fused input projection) is the larger kernel
+    if (kpw == 4 && !grid_fits(fwd_fn(kpw, nb, true), FWD_THREADS, 0, (H / 4) * 2 * chunks)) return false;
   }
   return true;
 }
 
 // Exchange workspace of the persistent BPTT: the K-split form's ring (0: no persistent form for this shape).
 extern "C" int64_t ssasr_bilstm_bwd_gx_floats(int64_t S, int64_t N, int64_t H) {
-  if (S <= 0 || N <= 0 || N > 128 || (H != 64 && H != 128 && H != 256)) return 0;
+  if (S <= 0 || N <= 0 || (H != 64 && H != 128 && H != 256)) return 0;
   const int64_t chunks = (N + 15) / 16;
   return 2 * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;
 }
@@ -257,7 +271,8 @@ extern "C" int64_t ssasr_bilstm_tsave_floats(int64_t S, int64_t N, int64_t H) {
 
 bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
   const SsasrOptions& opt = ssasr_options();
-  const int64_t chunks = (N + 15) / 16;
+  // (per column window: the widest is the first)
+  const int64_t chunks = (std::min<int64_t>(N, PERSIST_WINDOW) + 15) / 16;
   if (!(S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 && !opt.no_persistent))
     return false;
   // every workgroup of the one-per-(tile, chunk) grid must be resident (the two-halves grid is checked at launch)
@@ -265,32 +280,23 @@ bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
   return grid_fits(bptt_rs_fn(kpw, false), 320, (size_t)bptt_reserve_bytes(kpw, false), (H / 16) * dirs * chunks);
 }
 
-int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
-                                 int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
-                                 int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0, int64_t i1,
-                                 float* dc_state, const float* whh_f, const float* whh_r, bool armed,
-                                 const float* tsave, void* stop_event) {
-  const int64_t chunks = (N + 15) / 16, Np = (N + 15) & ~(int64_t)15;
+// One column window [n0, n0 + Nw) of a layer of NT columns (NT = 0: the launch covers the layer, Nw = its width)
+static int launch_bptt_window(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
+                              int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S, int64_t Nw,
+                              int64_t NT, int64_t H, int dirs, hipStream_t st, int64_t i0, int64_t i1, float* dc_state,
+                              const float* whh_f, const float* whh_r, const float* tsave, void* stop_event) {
+  const int64_t chunks = (Nw + 15) / 16;
   const int kpw = (int)(H / 16);
   const SsasrOptions& opt = ssasr_options();
-  if (i1 <= 0) i1 = S;
   const bool ranged = i0 != 0 || i1 != S;
-  if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && !dc_state)) return SSASR_EARG;
-  // every workgroup must be resident: at most one per CU
-  if ((!whhT && !whh_f) || !gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
-      (H / 16) * dirs * chunks > 256 || S * 4 * H * Np * 4 >= (1ll << 31) || !aligned16(gx) || !aligned16(gates) ||
-      (!tsave && !aligned16(cs)) || !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
-    return SSASR_EARG;
   EncPersistBwd p{};
   p.i0 = (int)i0; p.i1 = (int)i1; p.dc_state = dc_state;
   if (whh_f && (dirs == 1 || whh_r)) { p.whh[0] = whh_f; p.whh[1] = whh_r; }
   p.whhT = whhT; p.gates = gates; p.cs = cs; p.dy = dy; p.gx = gx; p.lens = lens; p.tsave = tsave;
   p.status = sync_ws + 4;
   p.delay = persist_delay(opt.delay_bwd_ksplit, 40);
-  p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)N; p.H = (int)H;
+  p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)Nw; p.H = (int)H; p.nt = (int)NT;
   dim3 pgrid((unsigned)(H / 16), (unsigned)dirs, (unsigned)chunks), pblock(320);   // 4 recurrence waves + 1 helper
-  // ring of BWD_RS_RING steps of partial dh tiles (rnn_kernels.h)
-  const size_t ring = (size_t)dirs * chunks * BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
   // two workgroups per (unit tile, chunk) halve the product on the critical path (H >= 128)
   // (not for launches of fewer than three steps: see the note on in-place rows in rnn_kernels.h)
   bool halves = kpw >= 8 && (H / 16) * dirs * chunks * 2 <= 256 && i1 - i0 >= 3 && !opt.bptt_halves_off;
@@ -300,7 +306,6 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
     reserve = bptt_reserve_bytes(kpw, false);
   }
   if (!halves && !grid_fits(bptt_rs_fn(kpw, false), 320, (size_t)reserve, (H / 16) * dirs * chunks)) return SSASR_EARG;
-  if (i0 == 0 && !armed) SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, ring, st));
   if (halves) pgrid.z *= 2;
   // (a range shorter than the hand-off distance between the two halves could rewrite dc_state early)
   if (halves && ranged && i1 < S && i1 - i0 < 4) return SSASR_EARG;
@@ -324,6 +329,40 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
   else SSASR_RS_LAUNCH(4, 1);
 #undef SSASR_RS_LAUNCH
   SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* cs, const float* dy, int64_t ys_s,
+                                 int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
+                                 int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0, int64_t i1,
+                                 float* dc_state, const float* whh_f, const float* whh_r, bool armed,
+                                 const float* tsave, void* stop_event) {
+  const int kpw = (int)(H / 16);
+  if (i1 <= 0) i1 = S;
+  const bool ranged = i0 != 0 || i1 != S;
+  if (i0 < 0 || i0 >= i1 || i1 > S || (ranged && !dc_state)) return SSASR_EARG;
+  const int64_t wchunks = (std::min<int64_t>(N, PERSIST_WINDOW) + 15) / 16;
+  // every workgroup of a window must be resident: at most one per CU
+  if ((!whhT && !whh_f) || !gx || !sync_ws || !(kpw == 4 || kpw == 8 || kpw == 16) || dirs < 1 || dirs > 2 ||
+      (H / 16) * dirs * wchunks > 256 || !aligned16(gx) || !aligned16(gates) ||
+      (!tsave && !aligned16(cs)) || !aligned16(dy) || ys_s % 4 || ys_n % 4 || ys_s >= (1ll << 31) || ys_n >= (1ll << 31))
+    return SSASR_EARG;
+  // ring of BWD_RS_RING steps of partial dh tiles per (direction, 16-column chunk) (rnn_kernels.h); the windows'
+  // rings lie back to back, dirs x chunks of the window each
+  const size_t ring_chunk = (size_t)BWD_RS_RING * (H / 16) * (H / 16) * 256;   // floats
+  if (i0 == 0 && !armed)
+    SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)gx, (int)PERSIST_SENTINEL, (size_t)dirs * ((N + 15) / 16) * ring_chunk, st));
+  const int64_t nwin = window_count(N);
+  for (int64_t w = 0; w < nwin; ++w) {
+    // (the pointers of a window start at its first column; NT = the layer's width = their row stride)
+    const int64_t n0 = w * PERSIST_WINDOW, Nw = window_width(N, w);
+    const int rc = launch_bptt_window(whhT, gates + n0 * 4 * H, cs ? cs + n0 * H : nullptr, dy + n0 * ys_n, ys_s, ys_n,
+                                      lens ? lens + n0 : nullptr, gx + (size_t)dirs * (n0 / 16) * ring_chunk, sync_ws, S, Nw,
+                                      nwin > 1 ? N : 0, H, dirs, st, i0, i1, dc_state ? dc_state + n0 * H : nullptr, whh_f, whh_r,
+                                      tsave ? tsave + (n0 / 16) * (H / 16) * 5 * 256 : nullptr,
+                                      w == nwin - 1 ? stop_event : nullptr);
+    if (rc) return rc;
+  }
   return SSASR_OK;
 }
 

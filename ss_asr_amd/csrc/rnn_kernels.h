@@ -378,6 +378,11 @@ struct EncPersist {
   // step, whole 128-byte lines (tsave_index).  When given, the row-major `gates` / `cs` are NOT
   // written: the pre-activations stay in `gates`, which the BPTT later overwrites with derivatives.
   float* tsave;
+  // Column window of a wider layer (blstm_4 at config 4: 375 columns as three launches of <= 128): nt > 0 = the
+  // layer's TOTAL column count, i.e. the row stride of gates / cs / hs / tsave; N is then the window's width and
+  // every pointer (gates, cs, hs, y, lens, tsave, x) has been advanced to the window's first column by the host.
+  // The exchange image hx is the window's own.  0: the launch covers the whole layer (nt = N).
+  int nt;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -517,7 +522,8 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
   const int S = e.S, N = e.N, H = e.H;
   const int n0 = chunk * 16 * NB;
   const int Np = (N + 7) & ~7;                 // image columns: 128-byte lines never shared by two tiles
-  const int64_t rows = (int64_t)S * N;
+  const int NT = e.nt > 0 ? e.nt : N;          // row stride of the row-major / tile-major arrays (column window: EncPersist::nt)
+  const int64_t rows = (int64_t)S * NT;
   float* gbase = e.gates + (int64_t)d * rows * 4 * H;
   const size_t xbytes = (size_t)S * Np * H * sizeof(float);
   float* xbase = e.hx + (int64_t)d * S * Np * H;
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
 #pragma unroll
           for (int j = 0; j < KIN; ++j) xb[bt][j] = ld4(xp + 16 * j);
         } else {
-          const int64_t g0 = ((int64_t)s * N + (n < N ? n : N - 1)) * 4 * H + u;
+          const int64_t g0 = ((int64_t)s * NT + (n < N ? n : N - 1)) * 4 * H + u;
 #pragma unroll
           for (int g = 0; g < 4; ++g) nadd[bt][g] = gbase[g0 + (int64_t)g * H];
         }
@@ -588,10 +594,10 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
         const int n = n0 + col;
         if (a < 7 && n < N) {
           const float4 v = *reinterpret_cast<const float4*>(&stage[a < 6 ? a : 5][col][0]);
-          const int64_t row = (int64_t)s * N + n;
+          const int64_t row = (int64_t)s * NT + n;
           float* dst;
           if (a < 5 && e.tsave)
-            dst = e.tsave + tsave_index(d, s, n >> 4, tile >> 2, a, S, (N + 15) >> 4, H >> 4) + ((tile & 3) * 16 + (n & 15)) * 4;
+            dst = e.tsave + tsave_index(d, s, n >> 4, tile >> 2, a, S, (NT + 15) >> 4, H >> 4) + ((tile & 3) * 16 + (n & 15)) * 4;
           else
             dst = a < 4 ? gbase + row * 4 * H + (int64_t)a * H + 4 * tile
                 : a == 4 ? cbase + row * H + 4 * tile
@@ -966,6 +972,7 @@ struct EncPersistBwd {
   // tile-major saved gates and cell states written by the forward kernel (EncPersist::tsave)
   // or null (then `gates` / `cs` hold them row-major and `gates` is overwritten in place)
   const float* tsave;
+  int nt;                // column window of a wider layer, as EncPersist::nt (0: nt = N); dc_state rows follow it
 };
 
 // ----------- persistent backward recurrence, K split (reduce-scatter) -----------
@@ -994,7 +1001,7 @@ struct BpttSaved {        // helper-wave state: saved activations of one step ->
   float4 gi, gf, gg, go, cpv, cv, ad;
   __device__ __forceinline__ void fetch(const EncPersistBwd& e, const float* gbase, const float* cbase, int d,
                                         int i, int n, int u0) {
-    const int S = e.S, N = e.N, H = e.H;
+    const int S = e.S, N = e.nt > 0 ? e.nt : e.N, H = e.H;       // N: the row stride (a column window's layer width)
     const int s = d ? i : S - 1 - i;
     const int sp = d ? s + 1 : s - 1;
     const bool has_prev = d ? (s < S - 1) : (s > 0);
@@ -1113,7 +1120,8 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   const int S = e.S, N = e.N, H = e.H;
   const int i0 = e.i0, i1 = e.i1 > 0 ? e.i1 : S;    // this launch's iterations
   const int n0 = chunk * 16;
-  const int64_t rows = (int64_t)S * N;
+  const int NT = e.nt > 0 ? e.nt : N;           // row stride (column window of a wider layer: EncPersistBwd::nt)
+  const int64_t rows = (int64_t)S * NT;
   const int u0 = 16 * tile + 4 * q;             // lane (q, r) of waves 0 and 4: units u0..u0+3 of column n
   const int n = n0 + r;
   const bool col_ok = n < N;
@@ -1164,7 +1172,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       if (epi_rows_ok(col_ok, half, HV, inplace, i, i0)) {
         // row-major copy of this step's gate derivatives for the dX and weight-gradient GEMMs
         const int sr = d ? i : S - 1 - i;
-        float* g0 = gbase + ((int64_t)sr * N + n) * 4 * H + u0;
+        float* g0 = gbase + ((int64_t)sr * NT + n) * 4 * H + u0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[i % NG][g][lane]);
       }
@@ -1185,7 +1193,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int sr = d ? i0 + k : S - 1 - (i0 + k);
-          float* g0 = gbase + ((int64_t)sr * N + n) * 4 * H + u0;
+          float* g0 = gbase + ((int64_t)sr * NT + n) * 4 * H + u0;
 #pragma unroll
           for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[(i0 + k) % NG][g][lane]);
         }
@@ -1230,7 +1238,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
   // lane (q, r) of wave w owns unit 16 tile + 4 w + q of column n0 + r; its cell-state derivative is carried
   // across steps in a register (and across launches of a segmented layer through dc_state)
   float dc1 = 0.f;
-  float* dcs1 = e.dc_state ? e.dc_state + ((int64_t)d * N + n) * H + 16 * tile + 4 * wave + q : nullptr;
+  float* dcs1 = e.dc_state ? e.dc_state + ((int64_t)d * NT + n) * H + 16 * tile + 4 * wave + q : nullptr;
   if (col_ok && i0 > 0 && dcs1) dc1 = *dcs1;
   __syncthreads();              // the helper wave has published the coefficients of the first two steps
 

@@ -256,10 +256,17 @@ def test_bilstm_segmented_bptt_range_options(pct, inline, want_dx, monkeypatch):
         close(a.grad, b.grad, 3e-4, 'd' + name)
 
 
-def test_bilstm_sequence_major_no_lengths():
-    """blstm_4 form: recurrence over dim 0, every column full length."""
-    from ss_asr_amd import ops
-    S, N, I, H = 7, 40, 64, 16
+@pytest.mark.parametrize('S,N,I,H', [(7, 40, 64, 16),
+                                     (12, 150, 64, 64),       # two column windows of the persistent recurrences (128 + 22)
+                                     (32, 375, 96, 256),      # blstm_4 at BASELINE.json configs[3]: 375 encoder frames = 128 + 128 + 119
+                                     (9, 129, 32, 128)])      # a one-column last window
+def test_bilstm_sequence_major_no_lengths(S, N, I, H):
+    """blstm_4 form: recurrence over dim 0, every column full length.  More than 128 columns run as consecutive
+    persistent launches over column windows of the same buffers (csrc/rnn.hip, PERSIST_WINDOW), forward and BPTT,
+    with ONE input projection, input gradient and weight-gradient pass over all columns."""
+    from ss_asr_amd import _lib, ops
+    if N > 128 and H % 64 == 0:
+        assert int(_lib.load().ssasr_bilstm_fwd_hx_floats(S, N, H)) > 0 and int(_lib.load().ssasr_bilstm_tsave_floats(S, N, H)) > 0
     x = rnd(S, N, I, seed=13)
     w = lstm_weights(I, H, 40)
     xr = x.clone().requires_grad_(True)
@@ -272,6 +279,8 @@ def test_bilstm_sequence_major_no_lengths():
     yd = ops.bilstm(xd, None, S, False, wd)
     close(yd, yr, 2e-5, 'y')
     (yd * gy.float().to(dev())).sum().backward()
+    torch.cuda.synchronize()
+    ops.check_persistent_status()
     close(xd.grad, xr.grad, 5e-5, 'dx')
     for a, b in zip(wd, wr):
         close(a.grad, b.grad, 2e-4, 'dw')
