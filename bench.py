@@ -731,7 +731,7 @@ def main():
         red.skip = False
         extras['collective'] = dict(backend=tdist.get_backend(), world_size=tdist.get_world_size(),
                                     bytes_per_step=4 * g.numel(), buckets=red.buckets(), overlap=bool(red.overlap),
-                                    fallback=fallback,
+                                    fallback=fallback, nccl_max_nchannels=os.environ.get('NCCL_MAX_NCHANNELS'),
                                     allreduce_alone_ms=dict(median=round(ar[len(ar) // 2], 4), min=round(ar[0], 4),
                                                             max=round(ar[-1], 4), reps=len(ar),
                                                             bytes=4 * g.numel(),

@@ -46,7 +46,8 @@ int ssasr_abi_version(void);
  * used -- entry points never read the environment -- and may be changed by tools between
  * calls.  Names: SSASR_NO_PERSISTENT, SSASR_NO_FUSED_INPUT, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
  * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
- * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_GEMM_X6, SSASR_GEMM_KCAT, SSASR_LAST_SEG_PCT, SSASR_TAIL_INLINE, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
+ * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_GEMM_X6, SSASR_GEMM_KCAT, SSASR_WGRAD_FUSED, SSASR_NO_WINDOWS,
+ * SSASR_LAST_SEG_PCT, SSASR_TAIL_INLINE, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
  * SSASR_TEST_DROP_TILE / SSASR_TEST_DROP_ATTN_SLICE / SSASR_TEST_DROP_DEC_SLICE (fault injection for the
  * time-out tests, one per kernel family, -1 = off).  Unknown name: -1. */
 int ssasr_set_option(const char* name, int value);

@@ -199,6 +199,7 @@ struct SsasrOptions {
   int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
   int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs (0: on v_mfma_f32_16x16x4_f32)
   int gemm_kcat;                  // SSASR_GEMM_KCAT (1): a layer's input gradient as ONE launch over both directions' K segments
+  int no_windows;                 // SSASR_NO_WINDOWS: layers wider than 128 columns take one launch per step instead of column windows (A/B)
   int wgrad_fused;                // SSASR_WGRAD_FUSED (1): a range's dW_ih, dW_hh and bias gradients as ONE launch, one pass over dG
   int last_seg_pct;               // SSASR_LAST_SEG_PCT (60): length of the LAST recurrence range of a segmented BPTT, in percent of an equal share
   int tail_inline;                // SSASR_TAIL_INLINE (1): the first layer's last range of weight-gradient products on the main stream

@@ -32,6 +32,7 @@ void init_options() {
   g_opt.gemm_x6 = env_int("SSASR_GEMM_X6", 1);
   g_opt.gemm_kcat = env_int("SSASR_GEMM_KCAT", 1);
   g_opt.wgrad_fused = env_int("SSASR_WGRAD_FUSED", 1);
+  g_opt.no_windows = env_flag("SSASR_NO_WINDOWS");
   g_opt.last_seg_pct = env_int("SSASR_LAST_SEG_PCT", 60);
   g_opt.tail_inline = env_int("SSASR_TAIL_INLINE", 1);
   g_opt.no_residency_check = env_flag("SSASR_NO_RESIDENCY_CHECK");
@@ -57,6 +58,7 @@ const Named kNames[] = {
     {"SSASR_GEMM_X6", &SsasrOptions::gemm_x6},
     {"SSASR_GEMM_KCAT", &SsasrOptions::gemm_kcat},
     {"SSASR_WGRAD_FUSED", &SsasrOptions::wgrad_fused},
+    {"SSASR_NO_WINDOWS", &SsasrOptions::no_windows},
     {"SSASR_LAST_SEG_PCT", &SsasrOptions::last_seg_pct},
     {"SSASR_TAIL_INLINE", &SsasrOptions::tail_inline},
     {"SSASR_NO_RESIDENCY_CHECK", &SsasrOptions::no_residency_check},

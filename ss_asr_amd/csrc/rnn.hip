@@ -80,7 +80,7 @@ static int64_t fwd_hx_floats_window(int64_t S, int64_t Nw, int64_t H) { return 2
 // Floats of the forward recurrence's exchange images, one [2][S][H/4][Np][4] per column window back to back,
 // Np = the window's columns rounded up to whole 128-byte lines (0: the shape has no persistent form).
 extern "C" int64_t ssasr_bilstm_fwd_hx_floats(int64_t S, int64_t N, int64_t H) {
-  if (S <= 0 || N <= 0 || H <= 0 || H % 64 != 0) return 0;
+  if (S <= 0 || N <= 0 || H <= 0 || H % 64 != 0 || (ssasr_options().no_windows && N > PERSIST_WINDOW)) return 0;
   int64_t total = 0;
   for (int64_t w = 0; w < window_count(N); ++w) total += fwd_hx_floats_window(S, window_width(N, w), H);
   return total;
@@ -142,7 +142,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
     const int64_t nwin = window_count(N);
     bool fits = hx && sync_ws && H % 64 == 0 && (kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8) &&
                 aligned16(hx) && aligned16(gates) && aligned16(cs) && aligned16(y) && ys_s % 4 == 0 &&
-                ys_n % 4 == 0 && !opt.no_persistent;
+                ys_n % 4 == 0 && !opt.no_persistent && !(opt.no_windows && nwin > 1);
     // status words are zero on entry (caller's contract)
     // narrow input (the 80 mel bins of the first layer): the recurrence waves form the
     // pre-activations themselves; no input projection GEMM (rnn_kernels.h, KI)
@@ -210,7 +210,7 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
 // the caller's: torch allocations are 256-byte aligned), residency of the grid included.
 static bool fwd_persistent_shape_ok(int64_t S, int64_t N, int64_t H) {
   const SsasrOptions& opt = ssasr_options();
-  if (S <= 0 || N <= 0 || H <= 0 || H % 64 != 0 || opt.no_persistent) return false;
+  if (S <= 0 || N <= 0 || H <= 0 || H % 64 != 0 || opt.no_persistent || (opt.no_windows && N > PERSIST_WINDOW)) return false;
   const int kpw = (int)(H / 64);
   if (!(kpw == 1 || kpw == 2 || kpw == 4 || kpw == 8)) return false;
   for (int64_t w = 0; w < window_count(N); ++w) {
@@ -273,7 +273,8 @@ bool ssasr_bptt_ksplit_ok(int64_t S, int64_t N, int64_t H, int dirs) {
   const SsasrOptions& opt = ssasr_options();
   // (per column window: the widest is the first)
   const int64_t chunks = (std::min<int64_t>(N, PERSIST_WINDOW) + 15) / 16;
-  if (!(S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 && !opt.no_persistent))
+  if (!(S > 0 && N > 0 && (H == 64 || H == 128 || H == 256) && (H / 16) * dirs * chunks <= 256 && !opt.no_persistent) ||
+      (opt.no_windows && N > PERSIST_WINDOW))
     return false;
   // every workgroup of the one-per-(tile, chunk) grid must be resident (the two-halves grid is checked at launch)
   const int kpw = (int)(H / 16);

@@ -53,6 +53,16 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            # Co-residency with the persistent BPTT: RCCL runs a collective as ONE
+            # 256-thread workgroup per channel with 19.7 KB of static LDS (rcclGenericKernel in this ROCm's
+            # librccl, read from its gfx950 code object).  The BPTT keeps 128 CUs with ~156 KB of LDS each
+            # (its 118 KB reservation), so channel workgroups cannot land beside it -- they share the other 128
+            # CUs with the weight-gradient GEMMs -- and a BPTT launch that finds channel workgroups already
+            # resident needs 128 CUs free of them.  Capping the channels at 32 keeps both true whatever RCCL's
+            # tuner would pick (a 41 MB all-reduce hidden behind ~1 ms of recurrence does not need more); an
+            # explicit NCCL_MAX_NCHANNELS in the environment wins.
+            os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
