@@ -276,8 +276,16 @@ class ASRTrainer(Solver):
         self.asr_model.eval()
         total_loss, total_acc, total_err, num_batches = 0.0, 0.0, 0.0, 0
         prediction = label = att_map = None
+        # Under torchrun the validation batches are dealt to the ranks round-robin (every rank holds the same
+        # weights: the sums below are all-reduced, the averages are the single-process ones); rank 0 also takes
+        # the LAST batch, whose hypotheses it logs as the reference does (src/trainer.py:505-519).
+        n_valid = len(self.valid_set)
+        mine = lambda b: self.world == 1 or b % self.world == self.rank or (self.rank == 0 and b == n_valid - 1)
+        counted = lambda b: self.world == 1 or b % self.world == self.rank
         with torch.no_grad():
             for b_idx, (x, y) in enumerate(self.valid_set):
+                if not mine(b_idx):
+                    continue
                 self.verbose('Validation step - ( {} / {} )'.format(b_idx, len(self.valid_set)),
                              progress=True)
                 (x, x_lens) = prepare_x(x, device=self.device)
@@ -285,6 +293,8 @@ class ASRTrainer(Solver):
                 ans_len = max(y_lens) - 1
                 _, prediction, att_map = self.asr_model(x, ans_len + 30, state_len=x_lens)
                 label = y[:, 1:ans_len + 1].contiguous()
+                if not counted(b_idx):
+                    continue                       # (rank 0's copy of the last batch: for its log only)
                 loss = self._loss(prediction, y, ans_len)
                 total_loss += float(loss)
                 total_acc += calc_acc(prediction, label)
@@ -294,6 +304,12 @@ class ASRTrainer(Solver):
         # outside a train step's shared row): a hand-off that timed out must not become a "best" model
         # or a best_hyp.txt (float(loss) above has synchronised already)
         ops.check_persistent_status()
+        if sdist.is_active() and self.world > 1:
+            sums = torch.tensor([total_loss, total_acc, total_err, float(num_batches)], dtype=torch.float64,
+                                device=self.device)
+            torch.distributed.all_reduce(sums)
+            total_loss, total_acc, total_err, num_batches = (float(sums[0]), float(sums[1]), float(sums[2]),
+                                                             int(round(float(sums[3]))))
         if num_batches == 0:
             self.asr_model.train()
             return
