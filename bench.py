@@ -454,6 +454,71 @@ def config4_bench(device, steps=4, warmup=2, batch=32):
     return out
 
 
+def config5_bench(device, steps=20, warmup=3, batch=32):
+    """BASELINE.json configs[4]'s legs that are in scope (src/trainer.py:594-758, :1126-1177): the
+    text-autoencoder train step (engine.TAETrainStep: TextAutoEncoder forward through the shared attend-and-spell
+    loop, TAETrainer's loss, backward, clip over the text autoencoder, Adam over it and the ASR model's decoder half)
+    on synthetic label rows of the corpus' lengths with TAETrainer's noise model (characters dropped with
+    probability 0.1), alone and alternating with the supervised ASR step on the SAME ASR object.  rows/s = label
+    rows (utterance transcripts) per second."""
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.engine import ASRTrainStep, TAETrainStep, label_geometry
+    from ss_asr_amd.synthetic import config2_batches
+    from ss_asr_amd.text_autoencoder import TextAutoEncoder
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    asr = ASR(**DIMS).to(device)
+    tae = TextAutoEncoder(DIMS['output_dim'], emb_dim=128, state_size=DIMS['encoder_state_size'], num_layers=2).to(device)
+    asr_step = ASRTrainStep(asr, lr=1.0, eps=1e-8, grad_clip=5.0)
+    tae_step = TAETrainStep(asr, tae, lr=1e-4, eps=1e-8, grad_clip=5.0)
+    rng = np.random.default_rng(5)
+    data = []
+    for x, y, lens in config2_batches(4, batch_size=batch, feat_dim=DIMS['feature_dim'], seed=1):
+        rows = [[int(c) for c in row if c != 0] for row in y.tolist()]           # chars + '>' (the leading '<' is 0)
+        noisy = [[c for c in r[:-1] if rng.random() > 0.1] + [1] for r in rows]
+        def pad(rs):
+            w = max(len(r) for r in rs) + 1
+            out = np.zeros((len(rs), w), dtype=np.int64)
+            for i, r in enumerate(rs):
+                out[i, 1:1 + len(r)] = r
+            return torch.from_numpy(out)
+        yn = pad(noisy)
+        y_lens = [int(v) + 1 for v in (y != 0).sum(-1)]
+        n_lens = [int(v) + 1 for v in (yn != 0).sum(-1)]
+        data.append((x.to(device), y.to(device), lens, label_geometry(y)[1], yn.to(device), y_lens, n_lens))
+
+    def tae_only(i):
+        x, y, lens, ans, yn, yl, nl = data[i % len(data)]
+        return tae_step(y, yn, yl, nl)
+
+    def both(i):
+        x, y, lens, ans, yn, yl, nl = data[i % len(data)]
+        asr_step(x, y, lens, ans)
+        return tae_step(y, yn, yl, nl)
+
+    def timed(fn):
+        for i in range(warmup):
+            fn(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = None
+        for i in range(steps):
+            loss = fn(warmup + i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        tae_step.finish(); asr_step.finish()
+        return dt, float(loss)
+
+    dt_t, loss_t = timed(tae_only)
+    dt_b, loss_b = timed(both)
+    return dict(workload='BASELINE.json configs[4], the legs in scope: TAETrainer step (text autoencoder 128 / 256 x 2 layers + the shared '
+                         'LAS attention / speller, Adam 1e-4) on %d label rows of %d-%d characters, drop rate 0.1; and alternating with the '
+                         'ASRTrainer step on the same ASR object' % (batch, min(min(d[5]) for d in data) - 2, max(max(d[5]) for d in data) - 2),
+                tae_step=dict(ms_per_step=round(dt_t * 1e3, 3), rows_per_sec=round(batch / dt_t, 1), final_loss=round(loss_t, 4)),
+                asr_plus_tae_round=dict(ms_per_round=round(dt_b * 1e3, 3), final_tae_loss=round(loss_b, 4)),
+                steps=steps, warmup=warmup,
+                note='SAETrainer / ADVTrainer (CNN autoencoder, discriminator) are out of scope: SURVEY.md 2 rows 15-16')
+
+
 def cpu_baseline(batches):
     """The oracle (a CPU restatement of the reference, pinned to its golden
     vectors) timed on the host cores for one train step on each of `batches`
@@ -812,6 +877,9 @@ def main():
         torch.cuda.empty_cache()
         out['config4'] = config4_bench(device)
         note('config 4: %s' % out['config4'])
+    if world == 1 and not args.no_config4:
+        out['config5'] = config5_bench(device)
+        note('config 5 (TAE leg): %s' % out['config5'])
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline([host_batches[k] for k in (2, 4, 6)])
     print(json.dumps(out), flush=True)

@@ -53,6 +53,9 @@ SIGNATURES = {
                              I64, I64, I64, I64, I32, P]),
     'ssasr_bilstm_fwd': (I32, [P, I64, I64, I64, I64, I64, I64, P] + [P] * 8 +
                          [P, I64, I64, P, P, P, P, P, I32, P, P]),
+    'ssasr_bilstm_fwd_range': (I32, [P, I64, I64, I64, I64, I64, I64, P] + [P] * 8 +
+                               [P, I64, I64, P, P, P, P, P, I32, P, I64, I64, I32, P]),
+    'ssasr_bilstm_input_projection': (I32, [P, I64, I64, I64, I64, I64, I64] + [P] * 7 + [I32, I64, I64, P]),
     'ssasr_bilstm_tsave_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_fwd_hx_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_bwd': (I32, [P, I64, I64, P, I64, I64, I64, I64, I64, I64, P] + [P] * 4 +
