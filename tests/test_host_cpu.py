@@ -240,6 +240,28 @@ def make_corpus(tmp_path, n=16, t_max=40, feat=80, seed=1):
     return index, lens
 
 
+def test_flat_parameters_are_shared_between_step_objects_and_give_contiguous_runs():
+    """Host logic behind the Seed loop's shared ASR object: a module has ONE flat home (FlatParameters.of finds
+    it again), and the parameters behind the Listener are one contiguous run of it -- what TAETrainStep's Adam
+    steps inside the ASR model's own buffer."""
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.optim import FlatParameters
+    model = ASR(50, 32, 32, 16, 12, 1.0)
+    flat = FlatParameters.of(model)
+    assert FlatParameters.of(model) is flat and flat.clean
+    shared = (list(model.attention.parameters()) + list(model.decoder.parameters()) + list(model.embed.parameters()) +
+              list(model.char_trans.parameters()))
+    lo_, hi_ = flat.range_of(shared)
+    enc = sum((p.numel() + 3) // 4 * 4 for p in model.encoder.parameters())
+    assert (lo_, hi_) == (enc, flat.numel)
+    assert all(lo_ <= o < hi_ for p, o in zip(flat.params, flat.offsets) if any(p is q for q in shared))
+    with pytest.raises(ValueError):
+        flat.range_of([model.embed.weight, model.encoder.blstm_1.layer.weight_hh_l0])      # not a contiguous run
+    # a module whose parameters were re-homed elsewhere gets a fresh flat home
+    model.embed.weight.data = model.embed.weight.data.clone()
+    assert FlatParameters.of(model) is not flat
+
+
 def test_dataset_batches_lengths_and_mapper(tmp_path):
     from ss_asr_amd.ASRDataset import Mapper, load_asr_dataset, prepare_x, prepare_y
     index, lens = make_corpus(str(tmp_path), n=18)
