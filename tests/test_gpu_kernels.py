@@ -122,12 +122,15 @@ def lstm_weights(I, H, seed):
     # what timed out under an exchange ring: DESIGN.md 4.2); the BPTT runs 3 / 4 chunks without halves
     (48, 40, 64, 256, [40] * 10 + [33] * 20 + [9] * 18),
     (64, 24, 64, 256, [24] * 30 + [11] * 34),
-    # H = 256, N <= 32: the XCD-local forward recurrence (csrc/rnn_local.h: 8-column exchange groups, h
-    # exchanged as bf16 planes) -- four full groups per direction with ragged lengths; a last group of
-    # 5 live columns; the fused 80-bin input projection (I = 80) with 13 columns
+    # H = 256, N <= 32: full chunks with ragged lengths; a last chunk of 13 live columns; the fused 80-bin input
+    # projection (I = 80) with 13 columns
     (32, 37, 64, 256, [37 - k for k in range(32)]),
     (29, 21, 48, 256, [21] * 9 + [14] * 12 + [2] * 8),
     (13, 26, 80, 256, [26, 26, 25, 20, 19, 19, 12, 9, 9, 5, 3, 2, 1]),
+    # more utterances than a persistent launch takes: two column windows (128 + 22) WITH lengths, fused 80-bin input;
+    # and a two-column last window at H = 64
+    (150, 40, 80, 256, sorted([40 - (k * 7) % 33 for k in range(150)], reverse=True)),
+    (130, 36, 48, 64, sorted([36 - (k * 5) % 30 for k in range(130)], reverse=True)),
 ])
 def test_bilstm_packed_forward_backward(N, T, I, H, lens):
     from ss_asr_amd import ops
@@ -157,7 +160,8 @@ def test_bilstm_packed_forward_backward(N, T, I, H, lens):
 @pytest.mark.parametrize('fused', [1, 0])
 @pytest.mark.parametrize('N,S,I,H,segments', [(20, 150, 24, 64, 4), (9, 130, 16, 128, 3), (20, 150, 24, 64, 1),
                                               (32, 96, 80, 256, 4),        # the first layer's shape: I = 80 (a partly filled column tile)
-                                              (16, 64, 1024, 256, 2)])     # layers 2-3: I = 1024
+                                              (16, 64, 1024, 256, 2),      # layers 2-3: I = 1024
+                                              (140, 130, 24, 64, 3)])      # two column windows x three step ranges (ring regions and dc_state per window)
 def test_bilstm_segmented_bptt_with_overlapped_weight_gradients(N, S, I, H, segments, fused, monkeypatch):
     """The path the train step takes: gradients live in an optimizer-owned flat buffer, so the
     BPTT runs in step-range segments (ring and dc state carried across launches) and the weight
