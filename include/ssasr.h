@@ -63,7 +63,7 @@ int ssasr_events_destroy(void* handle);
  * MFMA instruction with SSASR_GEMM_X6=0: the same results to fp32 rounding).
  * ta = 0: A is [M][K] (ld = lda); ta = 1: A is [K][M].
  * tb = 0: B is [N][K] (torch Linear weight layout); tb = 1: B is [K][N].
- * act: 0 none, 1 tanh.  splitk > 1 adds partial products atomically into a
+ * act: 0 none, 1 tanh, 4 relu, 5 leaky relu (slope 0.01), 6 sigmoid.  splitk > 1 adds partial products atomically into a
  * caller-initialised C (beta is then ignored).
  * Replaces: torch.nn.Linear / torch.bmm call sites of src/asr.py:381,:385,:389
  * and the dense halves of nn.LSTM (src/asr.py:414,:262). */
@@ -409,6 +409,29 @@ int ssasr_adam_prepare(const float* grad_clip, int64_t n_clip, float grad_scale,
 int ssasr_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const float* ws, int clipped, float grad_scale, float beta1, float beta2, float eps,
                       const float* stats, int zero_grad, void* stream);
+
+/* ---- the Seed loop's other legs (BASELINE.json configs[4]): ADVTrainer, SAETrainer ------------------------
+ * Dense layer with its activation, y = act(x . W^T + b): x [rows][K] (row stride ldx), W [N][K] (nn.Linear),
+ * y [rows][N]; act as for ssasr_gemm_f32 (0, 1, 4, 5, 6).
+ * Replaces: the nn.Sequential cores of src/discriminator.py:38-43 (+ :52 sigmoid) and
+ * src/speech_autoencoder.py:183-188.
+ * ssasr_linear_bwd: dy [rows][N] is the gradient of y and is OVERWRITTEN with dz = dy * act'(y) (y: the saved
+ * output; unused for act 0); dx (optional) = dz . W, row stride lddx; dw (optional) += dz^T . x; db (optional)
+ * += column sums of dz.  Partial products of dw are added atomically (K slices over the rows). */
+int ssasr_linear_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t rows,
+                     int64_t K, int64_t N, int act, void* stream);
+int ssasr_linear_bwd(float* dy, const float* y, const float* x, int64_t ldx, const float* w, float* dx,
+                     int64_t lddx, float* dw, float* db, int64_t rows, int64_t K, int64_t N, int act,
+                     void* stream);
+/* dx[i] = dy[i] * act'(y[i]) through the saved OUTPUT y (dx may alias dy). */
+int ssasr_act_bwd(int act, const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
+/* nn.BCELoss (mean) of n probabilities against ONE target value -- ADVTrainer's three losses
+ * (src/trainer.py:981-984 real labels 1 - label_smoothing, :992-993 fake labels 0, :1012-1028 generator
+ * labels 1), log terms clamped at -100 as torch does.  loss: float[1], written.
+ * ssasr_bce_bwd: dp[i] = upstream * (p - t) / max((1 - p) p, 1e-12) / n; upstream: float[1] or NULL (= 1). */
+int ssasr_bce_fwd(const float* p, int64_t n, float target, float* loss, void* stream);
+int ssasr_bce_bwd(const float* p, int64_t n, float target, const float* upstream, float* dp, void* stream);
 
 /* Frame lengths of zero-padded fbanks, prepare_x (src/ASRDataset.py:314):
  * lens[b] = number of frames whose feature sum is non-zero. */

@@ -355,6 +355,74 @@ def tae_train_step(asr, tae, optim, y, y_noise):
 
 
 # --------------------------------------------------------------------------
+# the Seed loop's other legs (BASELINE.json configs[4]): ADVTrainer, SAETrainer
+# --------------------------------------------------------------------------
+class OracleDiscriminator(nn.Module):
+    """Discriminator, src/discriminator.py:4-54: Linear(in, hid) ReLU Linear(hid, hid) ReLU Linear(hid, 1),
+    then a sigmoid; scores every frame of [batch, seq, in]."""
+
+    def __init__(self, in_dim, hidden_dim=256):
+        super().__init__()
+        self.core = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, hidden_dim),
+                                  nn.ReLU(), nn.Linear(hidden_dim, 1))
+
+    def forward(self, x):
+        return torch.sigmoid(self.core(x))
+
+
+def make_adv_optimizers(asr, disc, g_opt=('Adadelta', 1.0), d_opt=('Adadelta', 1.0)):
+    """ADVTrainer.set_model, src/trainer.py:938-948 with conf/default.yaml:63-68: the generator optimizer holds
+    the Listener's parameters, the discriminator optimizer the discriminator's."""
+    G = getattr(torch.optim, g_opt[0])(asr.encoder.parameters(), lr=g_opt[1], eps=1e-8)
+    D = getattr(torch.optim, d_opt[0])(disc.parameters(), lr=d_opt[1], eps=1e-8)
+    return G, D
+
+
+def adv_train_step(asr, text_encoder, disc, G_optim, D_optim, x, y, label_smoothing=0.1):
+    """One iteration of ADVTrainer.exec, src/trainer.py:968-1032, with the loss the reference names but never
+    defines (`self.loss_metric`, :984) taken as nn.BCELoss (src/discriminator.py:17-19).  Returns
+    (D_realloss, D_fakeloss, G_loss, D norm, G norm)."""
+    bce = nn.BCELoss()
+    lens = frame_lengths(x)
+    batch = x.shape[0]
+    disc.zero_grad()
+    real = text_encoder(y)                                                  # :978
+    d_out = disc(real)
+    d_real = bce(d_out.squeeze(dim=2), torch.ones(batch, real.shape[1]) - label_smoothing)
+    d_real.backward()
+    fake, _ = asr.encoder(x, lens)                                          # :988
+    d_out = disc(fake.detach())
+    d_fake = bce(d_out.squeeze(dim=2), torch.zeros(batch, fake.shape[1]))
+    d_fake.backward()
+    d_norm, _ = solver_step(list(disc.parameters()), D_optim)               # :999
+    asr.encoder.zero_grad()                                                 # :1005
+    d_out = disc(fake)                                                      # the UPDATED discriminator
+    g_loss = bce(d_out.squeeze(dim=2), torch.ones(batch, fake.shape[1]))
+    g_loss.backward()
+    g_norm, _ = solver_step(list(asr.encoder.parameters()), G_optim)        # :1029
+    return float(d_real.detach()), float(d_fake.detach()), float(g_loss.detach()), d_norm, g_norm
+
+
+def seeded_generic_weights(module, seed):
+    """numpy-PCG64 parameters for the Seed loop's extra modules (Discriminator, SpeechAutoEncoder; reference
+    or oracle: same names and order): matrices and convolution kernels N(0, 1/sqrt(fan_in)) with fan_in =
+    everything but the leading axis; batch-norm scales 1 + N(0, 0.1); every other vector N(0, 0.1)."""
+    rng = np.random.default_rng(seed)
+    bn_scales = {id(m.weight) for m in module.modules() if isinstance(m, nn.BatchNorm2d)}
+    with torch.no_grad():
+        for _, p in module.named_parameters():
+            draw = rng.standard_normal(tuple(p.shape))
+            if p.dim() > 1:
+                draw *= 1.0 / math.sqrt(int(np.prod(p.shape[1:])))
+            elif id(p) in bn_scales:
+                draw = 1.0 + 0.1 * draw
+            else:
+                draw *= 0.1
+            p.copy_(torch.from_numpy(draw.astype(np.float32)))
+    return module
+
+
+# --------------------------------------------------------------------------
 # explicit arithmetic (kernel-level oracle)
 # --------------------------------------------------------------------------
 def lstm_gates_explicit(pre, c_prev):

@@ -297,6 +297,89 @@ def capture_tae_traj(asr_mod, tae_mod, name, dims, tae_dims, batches_y_lens, tf_
                                                   os.path.getsize(path) / 1024))
 
 
+def ref_adv_step(disc, asr, text_encoder, D_optim, G_optim, x, x_lens, y, label_smoothing):
+    """The body of the reference's ADVTrainer.exec (src/trainer.py:968-1032) around the reference's own
+    Discriminator / ASR / TextAutoEncoder classes.  ADVTrainer itself cannot be constructed (tensorboardX, an
+    index on disk, config keys the yaml lacks) and reads an attribute it never sets: `self.loss_metric`
+    (:984) is nn.BCELoss here, the loss src/discriminator.py:17-19 names -- the ONE departure from the
+    reference's text, recorded in the fixture."""
+    loss_metric = nn.BCELoss()
+    batch_size = x.shape[0]
+    disc.zero_grad()
+    real_data = text_encoder(y)
+    D_out = disc(real_data)
+    real_labels = torch.ones(batch_size, real_data.shape[1]) - label_smoothing
+    D_realloss = loss_metric(D_out.squeeze(dim=2), real_labels)
+    D_realloss.backward()
+    fake_data, _ = asr.encoder(x, x_lens)
+    D_out = disc(fake_data.detach())
+    fake_labels = torch.zeros(batch_size, fake_data.shape[1])
+    D_fakeloss = loss_metric(D_out.squeeze(dim=2), fake_labels)
+    D_fakeloss.backward()
+    d_norm = float(nn.utils.clip_grad_norm_(disc.parameters(), 5))          # Solver.step(discriminator.parameters(), D_optim)
+    D_optim.step()
+    asr.encoder.zero_grad()
+    fake_labels = torch.ones(batch_size, fake_data.shape[1])
+    D_out = disc(fake_data)
+    G_loss = loss_metric(D_out.squeeze(dim=2), fake_labels)
+    G_loss.backward()
+    g_norm = float(nn.utils.clip_grad_norm_(asr.encoder.parameters(), 5))   # Solver.step(asr_model.encoder.parameters(), G_optim)
+    G_optim.step()
+    return float(D_realloss.item()), float(D_fakeloss.item()), float(G_loss.item()), d_norm, g_norm
+
+
+def _weights_record(out, w0, w1, keep_all):
+    names = sorted(w1)
+    out['param_names'] = np.array(names)
+    out['update_norms'] = np.array([(w1[k].double() - w0[k].double()).norm().item() for k in names])
+    for k in names:
+        if keep_all:
+            out['w1/' + k] = w1[k].numpy()
+        else:
+            out['w1_head/' + k] = w1[k].reshape(-1)[:256].numpy()
+            out['dw_head/' + k] = (w1[k] - w0[k]).reshape(-1)[:256].numpy()
+
+
+def capture_adv_traj(asr_mod, tae_mod, disc_mod, name, dims, tae_dims, hidden, batches, seed, g_opt, d_opt,
+                     label_smoothing=0.1):
+    """A trajectory of ADVTrainer iterations on the real reference's classes (config 5's second leg,
+    src/trainer.py:909-1124): per entry of `batches` (frame lengths, label lengths) one iteration -- the
+    discriminator's two passes and step, then the generator's pass and step.  The batch itself is a recipe:
+    ss_asr_amd.synthetic.make_batch(lens, ylens, feat, batch_seed)."""
+    from las_oracle import seeded_generic_weights
+    from ss_asr_amd.synthetic import make_batch
+    seed_all(seed)
+    asr = asr_mod.ASR(*dims, 1.0)
+    seeded_weights(asr, seed + 100)
+    tae = tae_mod.TextAutoEncoder(dims[0], *tae_dims)
+    seeded_tae_weights(tae, seed + 200)
+    disc = disc_mod.Discriminator(asr.encoder.get_outdim(), hidden_dim=hidden)
+    seeded_generic_weights(disc, seed + 300)
+    G_optim = getattr(torch.optim, g_opt[0])(asr.encoder.parameters(), lr=g_opt[1], eps=1e-8)     # trainer.py:938-943
+    D_optim = getattr(torch.optim, d_opt[0])(disc.parameters(), lr=d_opt[1], eps=1e-8)            # :945-948
+    w0 = {('disc.' + k): v.clone() for k, v in disc.state_dict().items()}
+    w0.update({('asr.' + k): v.clone() for k, v in asr.state_dict().items()})
+    out = dict(dims=np.array(dims), tae_dims=np.array(tae_dims), hidden=np.int64(hidden), seed=np.int64(seed),
+               asr_weights_seed=np.int64(seed + 100), tae_weights_seed=np.int64(seed + 200),
+               disc_weights_seed=np.int64(seed + 300), rounds=np.int64(len(batches)),
+               g_opt=np.array([g_opt[0], repr(g_opt[1])]), d_opt=np.array([d_opt[0], repr(d_opt[1])]),
+               label_smoothing=np.float64(label_smoothing), loss_metric=np.array('BCELoss'))
+    rows = []
+    for r, (lens, ylens) in enumerate(batches):
+        x, y, _ = make_batch(np.array(lens), np.array(ylens), dims[4], seed + 1000 + r)
+        rows.append(ref_adv_step(disc, asr, tae.encoder, D_optim, G_optim, x, list(lens), y, label_smoothing))
+        out['lens%d' % r], out['ylens%d' % r], out['batch_seed%d' % r] = np.array(lens), np.array(ylens), np.int64(seed + 1000 + r)
+    rows = np.array(rows)
+    out['d_real'], out['d_fake'], out['g_loss'], out['d_norm'], out['g_norm'] = rows.T
+    w1 = {('disc.' + k): v for k, v in disc.state_dict().items()}
+    w1.update({('asr.' + k): v for k, v in asr.state_dict().items()})
+    _weights_record(out, w0, w1, sum(v.numel() for v in w1.values()) < 400000)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-18s D real %s fake %s G %s  %.1f KB' % (name, np.round(out['d_real'], 5), np.round(out['d_fake'], 5),
+                                                     np.round(out['g_loss'], 5), os.path.getsize(path) / 1024))
+
+
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)
     asr_mod = import_reference()
@@ -351,6 +434,19 @@ def main(only=None):
                          [[10, 7, 5, 3, 3], [9, 8, 4, 4, 2], [8, 8, 6, 3, 2]], 1.0, 42,
                          asr_batches=[([64, 56, 48, 40], [10, 7, 5, 3]), ([72, 50, 33, 17], [9, 6, 4, 2]),
                                       ([56, 56, 41, 24], [8, 8, 3, 5])])
+    # config 5's second leg (ADVTrainer, src/trainer.py:909-1124): three iterations at full layer sizes with the
+    # yaml's optimizers (Adadelta / Adadelta), and a small model with Adam on both sides
+    import discriminator as disc_mod                            # reference module
+    if not only or 'adv_traj_full_b8' in only:
+        capture_adv_traj(asr_mod, tae_mod, disc_mod, 'adv_traj_full_b8', full, (128, 256, 2), 256,
+                         [([200, 184, 160, 152, 120, 96, 80, 64], [20, 18, 15, 15, 12, 9, 8, 6]),
+                          ([192, 176, 168, 144, 128, 104, 72, 40], [19, 17, 16, 14, 12, 10, 7, 4]),
+                          ([208, 200, 136, 128, 112, 88, 56, 48], [21, 20, 13, 12, 11, 8, 5, 4])],
+                         51, ('Adadelta', 1.0), ('Adadelta', 1.0))
+    if not only or 'adv_traj_small_adam' in only:
+        capture_adv_traj(asr_mod, tae_mod, disc_mod, 'adv_traj_small_adam', small, (8, 32, 2), 24,
+                         [([64, 56, 48, 40], [10, 7, 5, 3]), ([72, 50, 33, 17], [9, 6, 4, 2]), ([56, 56, 41, 24], [8, 8, 3, 5])],
+                         52, ('Adam', 1e-3), ('Adam', 1e-3))
     for name, pick, seed, wseed in (('bench_b32_t800', 0, 8, 14), ('bench_b32_median', 4, 9, 15)):
         x, y, lens = config2_batches(8, batch_size=32, feat_dim=80, seed=1)[pick]
         ylens = [int(v) - 1 for v in (y != 0).sum(-1)]

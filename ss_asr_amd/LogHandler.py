@@ -43,3 +43,18 @@ class LogHandler:
             self.log.add_image(self._key(key), val, step)
         else:
             self._write('image', key, list(val.shape), step)
+
+    def figure(self, key, val, step):
+        """src/LogHandler.py:26-27 (SAETrainer.valid's spectrogram comparisons); without tensorboardX the
+        record is the pair of array shapes handed over."""
+        if self.log is not None:
+            self.log.add_figure(self._key(key), val, step)
+        else:
+            self._write('figure', key, [list(getattr(v, 'shape', ())) for v in (val if isinstance(val, (list, tuple)) else [val])], step)
+
+    def embedding(self, key, val, meta, step):
+        """src/LogHandler.py:29-30 (ADVTrainer.valid's real / fake frames)."""
+        if self.log is not None:
+            self.log.add_embedding(val, metadata=meta, tag=self._key(key), global_step=step)
+        else:
+            self._write('embedding', key, {'shape': list(val.shape), 'meta': {m: meta.count(m) for m in set(meta)}}, step)

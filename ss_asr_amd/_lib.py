@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -85,6 +85,11 @@ SIGNATURES = {
     'ssasr_adam_ws': (I64, [I64]),
     'ssasr_adam_prepare': (I32, [P, I64, F32, F32, F32, F32, F32, P, P, P, P]),
     'ssasr_adam_update': (I32, [P, P, P, P, I64, P, I32, F32, F32, F32, F32, P, I32, P]),
+    'ssasr_linear_fwd': (I32, [P, I64, P, P, P, I64, I64, I64, I32, P]),
+    'ssasr_linear_bwd': (I32, [P, P, P, I64, P, P, I64, P, P, I64, I64, I64, I32, P]),
+    'ssasr_act_bwd': (I32, [I32, P, P, P, I64, P]),
+    'ssasr_bce_fwd': (I32, [P, I64, F32, P, P]),
+    'ssasr_bce_bwd': (I32, [P, I64, F32, P, P, P]),
     'ssasr_bilstm_bwd_gx_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_bwd_ring_floats': (I64, [I64, I64, I64, I64]),
     'ssasr_decoder_bwd_chain_floats': (I64, [I64] * 6),

@@ -140,7 +140,8 @@ struct GemmDesc {
   int tb;              // 0: B stored [N][K]   1: B stored [K][N]
   const float* bias1;  // per output column, optional
   const float* bias2;  // per output column, optional
-  int act;             // 0 none, 1 tanh, 2 log(x + 2.22e-16), 3 pairs of columns -> C[m][n / 2] = c0^2 + c1^2 (splitk == 1)
+  int act;             // 0 none, 1 tanh, 2 log(x + 2.22e-16), 3 pairs of columns -> C[m][n / 2] = c0^2 + c1^2 (splitk == 1),
+                       // 4 relu, 5 leaky relu (slope 0.01), 6 sigmoid
   float alpha, beta;   // C = act(alpha * A.B + bias) + beta * C
   int splitk;          // >1: partial products are atomically added into C
   int batch;

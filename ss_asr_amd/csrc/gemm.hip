@@ -191,6 +191,18 @@ __device__ __forceinline__ void gemm_tile_of_block(int& bx, int& by, int& bzz) {
 
 // Epilogue of both GEMM kernels: acc holds the wave's TM x TN fragments of 16 x 16 (D layout of
 // v_mfma_f32_16x16x4_f32 and of v_mfma_f32_16x16x32_bf16 alike).
+// GemmDesc::act on one output value (code 3, the pair power, is handled where the columns are in hand)
+__device__ __forceinline__ float gemm_act(int act, float v) {
+  switch (act) {
+    case 1: return tanhf(v);
+    case 2: return logf(fmaxf(v, 0.f) + 2.220446049250313e-16f);   // np.log(x + eps)
+    case 4: return fmaxf(v, 0.f);                                   // nn.ReLU
+    case 5: return v > 0.f ? v : 0.01f * v;                         // nn.LeakyReLU() (negative_slope 0.01)
+    case 6: return 1.0f / (1.0f + expf(-v));                        // torch.sigmoid
+    default: return v;
+  }
+}
+
 template <int TM, int TN, int WM, int WN, bool TR>
 __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x4 (&acc)[TM][TN], int m0, int n0,
                                               int wm, int wn, int r, int q, int bz, int kz) {
@@ -219,8 +231,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x4 (&a
           if (g.splitk > 1) {
             atomicAdd(C + rowoff + n, v);
           } else {
-            if (g.act == 1) v = tanhf(v);
-            else if (g.act == 2) v = logf(fmaxf(v, 0.f) + 2.220446049250313e-16f);   // np.log(x + eps)
+            v = gemm_act(g.act, v);
             if (g.beta != 0.f) v += g.beta * C[rowoff + n];
             C[rowoff + n] = v;
           }
@@ -274,8 +285,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x4 (&a
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (g.act == 1) v[e] = tanhf(v[e]);
-        else if (g.act == 2) v[e] = logf(fmaxf(v[e], 0.f) + 2.220446049250313e-16f);   // np.log(x + eps)
+        v[e] = gemm_act(g.act, v[e]);
       }
       if (vecC && nb + 3 < g.N) {
         float4* dst = reinterpret_cast<float4*>(C + rowoff + nb);

@@ -135,3 +135,104 @@ def label_geometry(y_cpu):
     (y_lens, ans_len)."""
     y_lens = [int(v) + 1 for v in (y_cpu != 0).sum(-1)]
     return y_lens, max(y_lens) - 1
+
+
+def _fused_optimizer(kind, flat, span, lr, eps=1e-8):
+    """The fused form of torch.optim.<kind>(params, lr=lr, eps=eps) over one run of a flat buffer, with
+    Solver.step's clip over that same run; None for a kind this build has no kernel for."""
+    lo, hi = span if span is not None else (0, flat.numel)
+    if kind == 'Adadelta':
+        return FusedAdadelta(flat, lr=lr, eps=eps, span=(lo, hi))
+    if kind == 'Adam':
+        return FusedAdam([(flat.data[lo:hi], flat.grad[lo:hi], True)], lr=lr, eps=eps)
+    return None
+
+
+class ADVTrainStep:
+    """One ADVTrainer iteration (src/trainer.py:968-1032) as a reusable object: the discriminator is trained to
+    score the text encoder's frames high (labels 1 - label_smoothing) and the Listener's low (labels 0), then
+    the Listener -- the generator -- to be scored high (labels 1) by the UPDATED discriminator; Solver.step
+    over the discriminator's parameters with D_opt, then over the Listener's with G_opt.  The reference leaves
+    `self.loss_metric` undefined (:984): it is nn.BCELoss here, what
+    src/discriminator.py:17-19 describes.
+
+    The Listener runs ONCE per iteration (as in the reference, which reuses `fake_data`'s graph for the
+    generator pass); gradients the reference computes and never uses -- the text encoder's from the real
+    pass, the discriminator's from the generator pass (zeroed at :975 before anything reads them) -- are not
+    computed.  The Listener's parameters stay where the ASR model's flat buffer has them: the other legs of
+    the Seed loop train the same storage."""
+
+    def __init__(self, asr_model, tae_model, discriminator, g_opt=('Adadelta', 1.0), d_opt=('Adadelta', 1.0),
+                 label_smoothing=0.1, grad_clip=5.0):
+        for m in (asr_model, tae_model, discriminator):
+            if not next(m.parameters()).is_cuda:
+                raise RuntimeError('ADVTrainStep needs every model on the GPU (no CPU path)')
+        self.asr, self.tae, self.disc = asr_model, tae_model, discriminator
+        self.asr_flat = FlatParameters.of(asr_model)
+        self.d_flat = FlatParameters.of(discriminator)
+        self.span = self.asr_flat.range_of(list(asr_model.encoder.parameters()))
+        sdist.broadcast_flat(self.asr_flat.data)
+        sdist.broadcast_flat(self.d_flat.data)
+        self.G_optim = _fused_optimizer(g_opt[0], self.asr_flat, self.span, g_opt[1])
+        self.D_optim = _fused_optimizer(d_opt[0], self.d_flat, None, d_opt[1])
+        if self.G_optim is None or self.D_optim is None:
+            raise NotImplementedError('ADVTrainStep: optimizer types %r / %r (Adadelta and Adam have kernels)'
+                                      % (g_opt[0], d_opt[0]))
+        self.label_smoothing = float(label_smoothing)
+        self.grad_clip = grad_clip
+        self._one = torch.ones((), device=self.d_flat.data.device)
+        self.last_done = None          # (generator grad norm, skipped) of the last finished iteration
+        self.last_done_d = None
+        self.skipped_steps = 0
+
+    def frames(self, x, x_lens, y):
+        """The two encoders' frames: (real [B, seq, 512] from the text encoder, no graph; fake [B, T', 512] from
+        the Listener, with its graph)."""
+        with torch.no_grad():
+            real = self.tae.encoder(y)                               # the data distribution, [B, seq, 512]
+        fake, _ = self.asr.encoder(x, x_lens)
+        return real, fake
+
+    def __call__(self, x, x_lens, y):
+        """x [B, T, F] padded fbanks, x_lens host list (descending), y [B, L] label rows (int64), all on
+        the GPU.  Returns (D_realloss, D_fakeloss, G_loss) device tensors."""
+        from .seed_ops import bce_loss
+        done = self.D_optim.poll()
+        if done is not None:
+            self.last_done_d = done
+            self.skipped_steps += int(done[1])
+        self._note(self.G_optim.poll())
+        ops.set_wgrad_listener(None)
+        for flat in (self.d_flat, self.asr_flat):
+            if not flat.clean:
+                flat.zero_grad()
+        self.d_flat.clean = self.asr_flat.clean = False
+        lo, hi = self.span
+        with ops.shared_status_row(self.G_optim.status_row):
+            # --- discriminator: maximise log D(real) + log(1 - D(G(x)))
+            real, fake = self.frames(x, x_lens, y)
+            d_real = bce_loss(self.disc(real), 1.0 - self.label_smoothing)
+            d_real.backward(self._one)
+            d_fake = bce_loss(self.disc(fake.detach()), 0.0)
+            d_fake.backward(self._one)
+            scale = sdist.allreduce_grad(self.d_flat.grad)
+            self.D_optim.clip_and_step(self.grad_clip, grad_scale=scale, zero_grad=True)
+            self.d_flat.clean = True
+            # --- generator: maximise log D(G(x)), through the discriminator just updated
+            g_loss = bce_loss(self.disc(fake, frozen=True), 1.0)
+            g_loss.backward(self._one)
+        scale = sdist.allreduce_grad(self.asr_flat.grad[lo:hi])
+        self.G_optim.clip_and_step(self.grad_clip, grad_scale=scale, zero_grad=True)
+        self.asr_flat.clean = True         # (nothing behind the Listener was touched by this pass)
+        return d_real, d_fake, g_loss
+
+    _note = ASRTrainStep._note
+
+    def finish(self):
+        """Waits for the last iteration's words of BOTH optimizers; raises on a persistent time-out."""
+        done = self.D_optim.poll(wait=True)
+        if done is not None:
+            self.last_done_d = done
+            self.skipped_steps += int(done[1])
+        self._note(self.G_optim.poll(wait=True))
+        return self.last_done

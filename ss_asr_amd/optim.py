@@ -79,13 +79,19 @@ class FusedAdadelta(torch.optim.Optimizer):
     """torch.optim.Adadelta(lr, rho, eps, weight_decay=0) over FlatParameters,
     fused with clip_grad_norm_ and the NaN guard of Solver.step."""
 
-    def __init__(self, flat, lr=1.0, rho=0.9, eps=1e-6):
+    def __init__(self, flat, lr=1.0, rho=0.9, eps=1e-6, span=None):
+        """span (begin, end): the optimizer owns only that run of the flat buffer (FlatParameters.range_of) --
+        ADVTrainer's generator optimizer holds the Listener alone (src/trainer.py:940-943), a run of the ASR
+        model's buffer; norm, NaN guard, clip and update then cover that run."""
         self.flat = flat
-        super().__init__(flat.params, dict(lr=lr, rho=rho, eps=eps))
+        lo, hi = span if span is not None else (0, flat.numel)
+        self._data, self._grad = flat.data[lo:hi], flat.grad[lo:hi]
+        owned = [p for p, o in zip(flat.params, flat.offsets) if lo <= o < hi]
+        super().__init__(owned, dict(lr=lr, rho=rho, eps=eps))
         dev = flat.data.device
-        self.square_avg = torch.zeros_like(flat.data)
-        self.acc_delta = torch.zeros_like(flat.data)
-        self._ws = ops.clip_adadelta_ws(flat.numel, dev)
+        self.square_avg = torch.zeros_like(self._data)
+        self.acc_delta = torch.zeros_like(self._data)
+        self._ws = ops.clip_adadelta_ws(hi - lo, dev)
         # per-step words that reach the host in ONE asynchronous copy: [grad_norm, skipped] written
         # by the update kernel, then the int32[8] status row of the step's persistent launches
         # (ops.shared_status_row; words 4 / 5 turn non-zero when a launch timed out)
@@ -103,7 +109,7 @@ class FusedAdadelta(torch.optim.Optimizer):
         folded into the update kernel)."""
         ops.join_side_stream()       # weight gradients enqueued on the side stream
         g = self.param_groups[0]
-        ops.clip_adadelta_(self.flat.data, self.flat.grad, self.square_avg, self.acc_delta,
+        ops.clip_adadelta_(self._data, self._grad, self.square_avg, self.acc_delta,
                            self._ws, self.stats, grad_scale=grad_scale, max_norm=max_norm,
                            lr=g['lr'], rho=g['rho'], eps=g['eps'], zero_grad=zero_grad)
         # the norm / NaN flag / status row reach the host asynchronously; see poll()

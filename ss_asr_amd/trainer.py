@@ -106,7 +106,7 @@ class Solver:
             done = optim.poll()
             if done is not None and done[1]:
                 self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
-            scale = sdist.allreduce_grad(optim.flat.grad)
+            scale = sdist.allreduce_grad(optim._grad)
             optim.clip_and_step(max_norm=float(grad_clip), grad_scale=scale)
             return
         params = list(params)
@@ -491,6 +491,135 @@ class TAETrainer(Solver):
             self.train_step.finish()
         if self.rank == 0:
             torch.save(self.text_autoenc.state_dict(), self.ckppath)
+            torch.save(self.asr_model.state_dict(), self.asrpath_out)
+
+
+class ADVTrainer(Solver):
+    """Adversarial training of the Listener against the text encoder's frames (src/trainer.py:909-1124;
+    config 5's second leg).  Generator: the ASR model's Listener; data distribution: the text autoencoder's
+    encoder; discriminator: discriminator.Discriminator.  One iteration of exec() is ONE engine.ADVTrainStep
+    call (Adadelta or Adam for G_opt / D_opt; anything else raises).
+
+    The reference's ADVTrainer cannot run as shipped; what is fixed here, and
+    nothing else: `self.loss_metric` (used at :984, never set) is nn.BCELoss -- on the ssasr_bce kernels; the
+    validation index is `adv.eval_index` when the config has it (:918) and `adv.valid_index` (the key
+    conf/default.yaml:74 carries) otherwise; the character-LM dataset of :922-924 (`chunk_size`,
+    `lm_train_index`: absent from the yaml, and never read by exec or valid) is not loaded."""
+
+    def __init__(self, config, paras):
+        super().__init__(config, paras, 'adv')
+
+    def load_data(self):
+        n_jobs = self.set_if_exists('loader_jobs', 8)
+        (self.mapper, self.dataset, self.train_set) = load_asr_dataset(
+            self.config['adv']['train_index'], batch_size=self.train_batch_size, use_gpu=self.paras.gpu,
+            n_jobs=n_jobs)
+        eval_index = self.config['adv'].get('eval_index', self.config['adv'].get('valid_index'))
+        (_, _, self.valid_set) = load_asr_dataset(eval_index, batch_size=self.valid_batch_size,
+                                                  use_gpu=self.paras.gpu, n_jobs=n_jobs)
+
+    def set_model(self, asrpath=None, taepath=None, asr_model=None, text_autoenc=None):
+        """src/trainer.py:926-948.  asr_model / text_autoenc (this build): objects already in memory."""
+        from .discriminator import Discriminator
+        from .engine import ADVTrainStep
+        from .text_autoencoder import TextAutoEncoder
+        (self.asrpath_in, self.asrpath_out) = self.genpath(asrpath, 'asr')
+        (taepath_in, _) = self.genpath(taepath, 'tae')
+        self.asr_model = asr_model if asr_model is not None else self.setup_module(
+            ASR, self.asrpath_in, self.mapper.get_dim(), **self.config['asr']['mdl'])
+        self.text_autoenc = text_autoenc if text_autoenc is not None else self.setup_module(
+            TextAutoEncoder, taepath_in, self.mapper.get_dim(), **self.config['tae']['mdl'])
+        self.discriminator = self.setup_module(Discriminator, self.ckppath, self.asr_model.encoder.get_outdim(),
+                                               **self.config['adv']['mdl'])
+        self.data_distribution = self.text_autoenc.encoder
+        g, d = self.config['adv']['G_opt'], self.config['adv']['D_opt']
+        self.train_step = ADVTrainStep(self.asr_model, self.text_autoenc, self.discriminator,
+                                       g_opt=(g['type'], g['learning_rate']), d_opt=(d['type'], d['learning_rate']),
+                                       label_smoothing=self.config['adv']['label_smoothing'], grad_clip=5.0)
+        self.G_optim, self.D_optim = self.train_step.G_optim, self.train_step.D_optim
+
+    def _rank_batches(self):
+        from .gpu_loader import rank_batches
+        mine = set(rank_batches(len(self.train_set), self.rank, self.world))
+        for b_idx, (x, y) in enumerate(self.train_set):
+            if b_idx in mine:
+                yield b_idx, x, y
+
+    def exec(self):
+        self.verbose('Training set total {} batches'.format(len(self.train_set)))
+        nan_reported = self.train_step.skipped_steps
+        epoch = 0
+        while epoch < self.n_epochs:
+            self.verbose("Starting epoch {} out of {}".format(epoch + 1, self.n_epochs))
+            for b_idx, x, y in self._rank_batches():
+                self.verbose('Global step - {} ( {} / {} )'.format(self.tr.step, b_idx, len(self.train_set)),
+                             progress=True)
+                x, x_lens = prepare_x(x, device=self.device)
+                y, _ = prepare_y(y, device=self.device)
+                D_realloss, D_fakeloss, G_loss = self.train_step(x, x_lens, y)
+                if self.train_step.skipped_steps > nan_reported:
+                    nan_reported = self.train_step.skipped_steps
+                    self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+                if self.rank == 0 and self.tr.step % self.logging_step == 0:
+                    self.lg.scalar('discrim_real_loss_train', D_realloss.item(), self.tr.step)
+                    self.lg.scalar('discrim_fake_loss_train', D_fakeloss.item(), self.tr.step)
+                    self.lg.scalar('discrim_loss_train', (D_realloss + D_fakeloss).item(), self.tr.step)
+                    self.lg.scalar('gen_loss_train', G_loss.item(), self.tr.step)
+                if self.tr.step % self.valid_step == 0:
+                    self.valid()
+                if self.rank == 0 and self.tr.step % self.save_step == 0:
+                    self.train_step.finish()           # never checkpoint after a time-out
+                    self.verbose("Model saved at step {}".format(self.tr.step))
+                    torch.save(self.discriminator.state_dict(), self.ckppath)
+                    torch.save(self.asr_model.state_dict(), self.asrpath_out)
+                self.tr.do_step()
+            epoch += 1
+        self.train_step.finish()
+
+    def valid(self):
+        """src/trainer.py:1038-1113: the discriminator's two losses (real labels unsmoothed here, :1059) averaged
+        over the validation batches; the last batch's first utterance goes to the embedding log."""
+        from .seed_ops import bce_loss
+        self.asr_model.eval()
+        self.discriminator.eval()
+        real_sum = fake_sum = 0.0
+        n_batches = 0
+        real_data = fake_data = None
+        with torch.no_grad():
+            for b_idx, (x, y) in enumerate(self.valid_set):
+                self.verbose('Validation step - {} ( {} / {} )'.format(self.tr.step, b_idx, len(self.valid_set)),
+                             progress=True)
+                x, x_lens = prepare_x(x, device=self.device)
+                y, _ = prepare_y(y, device=self.device)
+                real_data, fake_data = self.train_step.frames(x, x_lens, y)
+                real_sum += float(bce_loss(self.discriminator(real_data), 1.0))
+                fake_sum += float(bce_loss(self.discriminator(fake_data), 0.0))
+                n_batches += 1
+        ops.check_persistent_status()
+        self.asr_model.train()
+        self.discriminator.train()
+        if n_batches == 0 or self.rank != 0:
+            return
+        avg_real, avg_fake = real_sum / n_batches, fake_sum / n_batches
+        real_emb, fake_emb = real_data[0], fake_data[0]
+        self.lg.embedding('validation_emb', torch.cat((real_emb, fake_emb)).cpu(),
+                          ['real'] * real_emb.shape[0] + ['fake'] * fake_emb.shape[0], self.tr.step)
+        avg_loss = avg_real + avg_fake
+        self.lg.scalar('discrim_real_loss_eval', avg_real, self.tr.step)
+        self.lg.scalar('discrim_fake_loss_eval', avg_fake, self.tr.step)
+        self.lg.scalar('discrim_loss_eval', avg_loss, self.tr.step)
+        if avg_loss < self.tr.get_best():
+            self.tr.set_best(avg_loss)
+            self.verbose('Best validation loss : {:.4f} @ global step {}'.format(self.tr.get_best(), self.tr.step))
+            torch.save(self.discriminator.state_dict(), self.best_ckppath)
+            self.verbose("Both the discriminator and ASR have been saved")
+
+    def close(self):
+        self.verbose("Finished training! The most recent model will" +
+                     "be saved at step {} as well as the ASR model".format(self.tr.step))
+        self.train_step.finish()
+        if self.rank == 0:
+            torch.save(self.discriminator.state_dict(), self.ckppath)
             torch.save(self.asr_model.state_dict(), self.asrpath_out)
 
 

@@ -381,3 +381,68 @@ def test_tae_trainer_end_to_end(tmp_path):
     asr1 = torch.load(os.path.join(ckpdir, 'asr.cpt'), map_location='cpu')
     assert all(torch.equal(asr1[k], asr0[k]) for k in asr0 if k.startswith('encoder.'))
     assert not torch.equal(asr1['decoder.layer_1.weight_ih'], asr0['decoder.layer_1.weight_ih'])
+
+
+# ------------------------------------------------- config 5: the ADV leg ----
+def _final_weights_check(fx, w0, w1, atol):
+    names = [str(n) for n in fx['param_names']]
+    assert sorted(w1) == names
+    upd = np.array([(w1[k].double() - w0[k].double()).norm().item() for k in names])
+    rel = np.abs(upd - fx['update_norms']) / np.maximum(fx['update_norms'], 1e-9)
+    print('max rel update-norm error: %.3g (%s)' % (rel.max(), names[int(rel.argmax())]))
+    np.testing.assert_allclose(upd, fx['update_norms'], rtol=2e-4, atol=1e-8)
+    worst = 0.0
+    for k in fx.files:
+        if k.startswith('w1/'):
+            got, want = w1[k[3:]].numpy(), fx[k]
+        elif k.startswith('w1_head/'):
+            got, want = w1[k[8:]].reshape(-1)[:256].numpy(), fx[k]
+        else:
+            continue
+        worst = max(worst, float(np.abs(got - want).max()))
+        np.testing.assert_allclose(got, want, atol=atol, rtol=0, err_msg=k)
+    print('max abs final-weight error: %.3g' % worst)
+
+
+@pytest.mark.parametrize('name', ['adv_traj_full_b8', 'adv_traj_small_adam'])
+def test_adv_train_steps_follow_the_reference_trajectory(golden, name):
+    """Config 5's second leg (ADVTrainer, src/trainer.py:909-1124): three engine.ADVTrainStep iterations against
+    the trajectory captured from the reference's Discriminator / Listener / text-encoder classes (with the
+    undefined `loss_metric` as nn.BCELoss): the three losses and both clipped norms of every iteration, the
+    per-tensor norms of the total update, final weights -- the yaml's Adadelta pair at full layer sizes, Adam on
+    a small model.  Everything behind the Listener must come out untouched."""
+    from ss_asr_amd.discriminator import Discriminator
+    from ss_asr_amd.engine import ADVTrainStep
+    from ss_asr_amd.synthetic import make_batch
+    fx = golden(name)
+    fx_t = dict(dims=fx['dims'], tf_rate=1.0, asr_weights_seed=fx['asr_weights_seed'], tae_dims=fx['tae_dims'],
+                tae_weights_seed=fx['tae_weights_seed'])
+    asr, tae = _tae_pair(fx_t)
+    dims = [int(v) for v in fx['dims']]
+    disc = Discriminator(2 * dims[1], int(fx['hidden']))
+    lo.seeded_generic_weights(disc, int(fx['disc_weights_seed']))
+    disc = disc.to('cuda:0')
+    state = lambda: {**{('disc.' + k): v.detach().cpu().clone() for k, v in disc.state_dict().items()},
+                     **{('asr.' + k): v.detach().cpu().clone() for k, v in asr.state_dict().items()}}
+    w0 = state()
+    opt = lambda a: (str(a[0]), float(a[1]))
+    step = ADVTrainStep(asr, tae, disc, g_opt=opt(fx['g_opt']), d_opt=opt(fx['d_opt']),
+                        label_smoothing=float(fx['label_smoothing']))
+    for r in range(int(fx['rounds'])):
+        x, y, lens = make_batch(fx['lens%d' % r], fx['ylens%d' % r], dims[4], int(fx['batch_seed%d' % r]))
+        d_real, d_fake, g_loss = [float(v) for v in step(x.cuda(), lens, y.cuda())]
+        g_norm, skipped = step.finish()
+        d_norm, d_skipped = step.last_done_d
+        assert not skipped and not d_skipped
+        got = [d_real, d_fake, g_loss, d_norm, g_norm]
+        want = [float(fx[k][r]) for k in ('d_real', 'd_fake', 'g_loss', 'd_norm', 'g_norm')]
+        print('adv iteration %d: %s (reference %s)' % (r, np.round(got, 6), np.round(want, 6)))
+        np.testing.assert_allclose(got[:3], want[:3], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(got[3:], want[3:], rtol=5e-5, atol=1e-7)
+    w1 = state()
+    for k in w1:
+        if k.startswith('asr.') and not k.startswith('asr.encoder.'):
+            assert torch.equal(w1[k], w0[k]), k
+    # (Adam at lr 1e-3 moves a weight by ~3e-3 over the three iterations, and where a gradient is of the order of
+    # Adam's eps the step is as sensitive as m / sqrt(v): measured 2.9e-6; Adadelta: 1.7e-8)
+    _final_weights_check(fx, w0, w1, atol=1e-5 if 'adam' in name else 1e-6)

@@ -193,3 +193,45 @@ def test_tae_trainer_trajectory_oracle_matches_reference(golden, name):
             np.testing.assert_allclose(w1[k[3:]].numpy(), fx[k], atol=2e-6, rtol=0, err_msg=k)
         if k.startswith('w1_head/'):
             np.testing.assert_allclose(w1[k[8:]].reshape(-1)[:256].numpy(), fx[k], atol=2e-6, rtol=0, err_msg=k)
+
+
+def _check_final_weights(fx, w0, w1, atol=2e-6):
+    names = [str(n) for n in fx['param_names']]
+    assert sorted(w1) == names
+    upd = np.array([(w1[k].double() - w0[k].double()).norm().item() for k in names])
+    np.testing.assert_allclose(upd, fx['update_norms'], rtol=1e-4, atol=1e-9)
+    for k in fx.files:
+        if k.startswith('w1/'):
+            np.testing.assert_allclose(w1[k[3:]].numpy(), fx[k], atol=atol, rtol=0, err_msg=k)
+        if k.startswith('w1_head/'):
+            np.testing.assert_allclose(w1[k[8:]].reshape(-1)[:256].numpy(), fx[k], atol=atol, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize('name', ['adv_traj_full_b8', 'adv_traj_small_adam'])
+def test_adv_trainer_trajectory_oracle_matches_reference(golden, name):
+    """Config 5's second leg: the oracle's adv_train_step (src/trainer.py:968-1032 with the undefined
+    `loss_metric` as nn.BCELoss) against three iterations captured from the reference's Discriminator / Listener /
+    text encoder classes -- the yaml's Adadelta pair at full layer sizes, Adam on a small model."""
+    from ss_asr_amd.synthetic import make_batch
+    fx = golden(name)
+    assert str(fx['loss_metric']) == 'BCELoss'
+    dims = [int(v) for v in fx['dims']]
+    torch.manual_seed(0)
+    asr = lo.OracleASR(*dims, 1.0)
+    lo.seeded_weights(asr, int(fx['asr_weights_seed']))
+    tae = lo.OracleTextAutoEncoder(dims[0], *[int(v) for v in fx['tae_dims']])
+    lo.seeded_tae_weights(tae, int(fx['tae_weights_seed']))
+    disc = lo.OracleDiscriminator(2 * dims[1], int(fx['hidden']))
+    lo.seeded_generic_weights(disc, int(fx['disc_weights_seed']))
+    opt = lambda a: (str(a[0]), float(a[1]))
+    G, D = lo.make_adv_optimizers(asr, disc, opt(fx['g_opt']), opt(fx['d_opt']))
+    w0 = {('disc.' + k): v.clone() for k, v in disc.state_dict().items()}
+    w0.update({('asr.' + k): v.clone() for k, v in asr.state_dict().items()})
+    for r in range(int(fx['rounds'])):
+        x, y, _ = make_batch(fx['lens%d' % r], fx['ylens%d' % r], dims[4], int(fx['batch_seed%d' % r]))
+        got = lo.adv_train_step(asr, tae.encoder, disc, G, D, x, y, float(fx['label_smoothing']))
+        want = [float(fx[k][r]) for k in ('d_real', 'd_fake', 'g_loss', 'd_norm', 'g_norm')]
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6, err_msg='round %d' % r)
+    w1 = {('disc.' + k): v for k, v in disc.state_dict().items()}
+    w1.update({('asr.' + k): v for k, v in asr.state_dict().items()})
+    _check_final_weights(fx, w0, w1)
