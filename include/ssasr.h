@@ -433,6 +433,65 @@ int ssasr_act_bwd(int act, const float* dy, const float* y, float* dx, int64_t n
 int ssasr_bce_fwd(const float* p, int64_t n, float target, float* loss, void* stream);
 int ssasr_bce_bwd(const float* p, int64_t n, float target, const float* upstream, float* dp, void* stream);
 
+/* SAETrainer's SpeechAutoEncoder (src/speech_autoencoder.py; src/trainer.py:760-907).  Activations are
+ * CHANNELS-LAST: [B][T][W][C] (time, mel, channel) -- the fbank batch [B][T][F] is the first layer's input as it
+ * stands (W = F, C = 1), the global encoder's output [B][1][1][256] is [B][256].
+ *
+ * ssasr_conv2d_fwd: nn.Conv2d(C, F, [kh, kw], padding 0, bias False) (:118-147): x [B][T][W][C], w in torch's
+ *   layout [F][C][kh][kw], y [B][T - kh + 1][W - kw + 1][F].  The product reads its overlapping input windows in
+ *   place through the GEMM's row maps when a kernel row's kw * C values are a multiple of 32 or kh == 1;
+ *   other shapes go through an im2col copy in ws.  ws: float[ssasr_conv2d_ws_floats(...)], scratch.
+ * ssasr_conv2d_bwd: dw (optional, torch layout) += the weight gradient (needs x); dx (optional) [B][T][W][C] = the
+ *   input gradient (needs w).  dy_bordered != 0: dy is stored inside a zero border of kh - 1 rows and kw - 1
+ *   columns, [B][To + 2 (kh - 1)][Wo + 2 (kw - 1)][F] (what ssasr_bn_relu_pool_bwd writes with border_t = kh - 1,
+ *   border_w = kw - 1) -- required for dx, whose full correlation reads the border in place; 0: dense
+ *   [B][To][Wo][F]. */
+int64_t ssasr_conv2d_ws_floats(int64_t B, int64_t T, int64_t W, int64_t C, int64_t F, int64_t kh, int64_t kw);
+int ssasr_conv2d_fwd(const float* x, const float* w, float* y, int64_t B, int64_t T, int64_t W, int64_t C,
+                     int64_t F, int64_t kh, int64_t kw, float* ws, void* stream);
+int ssasr_conv2d_bwd(const float* dy, int dy_bordered, const float* x, const float* w, float* dx, float* dw,
+                     int64_t B, int64_t T, int64_t W, int64_t C, int64_t F, int64_t kh, int64_t kw, float* ws,
+                     void* stream);
+
+/* nn.BatchNorm2d + nn.ReLU + nn.MaxPool2d([ph, pw]) of one encoder block (:123-125), channels-last.
+ * ssasr_bn_stats: per-channel statistics of y [rows][C] (rows = B * T * W), two passes, sums in double.
+ *   training != 0: batch mean / biased variance; running_mean / running_var are updated in place with
+ *   `momentum` (the variance unbiased), as torch does.  0: the running statistics are used.
+ *   save: float[4 * C] = mean, 1 / sqrt(var + eps), scale = gamma * invstd, shift = beta - mean * scale.
+ *   ws: float[ssasr_bn_ws_floats(C)] scratch (shared with ssasr_bn_relu_pool_bwd).
+ * ssasr_bn_relu_pool_fwd: p [B][T / ph][W / pw][C] = max over each window of relu(y * scale + shift) (floor
+ *   mode: remainder rows / columns dropped); idx: offset i * pw + j of the FIRST maximum inside its window.
+ * ssasr_bn_relu_pool_bwd (training-mode batch norm): from dp, the gradient of p, writes the gradient of the
+ *   convolution output y, dy [B][T + 2 border_t][W + 2 border_w][C] (the border zeroed here), and adds
+ *   dgamma / dbeta (optional).  Windows whose maximum is 0 pass nothing (ReLU). */
+int64_t ssasr_bn_ws_floats(int64_t C);
+int ssasr_bn_stats(const float* y, int64_t rows, int64_t C, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, int training, float* ws,
+                   float* save, void* stream);
+int ssasr_bn_relu_pool_fwd(const float* y, const float* save, int64_t B, int64_t T, int64_t W, int64_t C,
+                           int64_t ph, int64_t pw, float* p, int32_t* idx, void* stream);
+int ssasr_bn_relu_pool_bwd(const float* dp, const float* p, const int32_t* idx, const float* y, const float* save,
+                           const float* gamma, int64_t B, int64_t T, int64_t W, int64_t C, int64_t ph, int64_t pw,
+                           int64_t border_t, int64_t border_w, float* dy, float* dgamma, float* dbeta, float* ws,
+                           void* stream);
+
+/* The frame decoder's input (:62-75): din[(b, i)] = [listener[b][i][0 .. L) | enc[b][0 .. G)] for the Tq Listener
+ * frames of every utterance, as ONE [B * Tq][L + G] matrix (the reference runs its decoder once per frame).
+ * _bwd: dlistener [B][Tq][L] = the first L columns; denc [B][G] = the last G summed over an utterance's frames. */
+int ssasr_sae_concat_fwd(const float* listener, const float* enc, int64_t B, int64_t Tq, int64_t L, int64_t G,
+                         float* din, void* stream);
+int ssasr_sae_concat_bwd(const float* ddin, int64_t B, int64_t Tq, int64_t L, int64_t G, float* dlistener, float* denc,
+                         void* stream);
+
+/* SAETrainer's loss (src/trainer.py:811-818): nn.SmoothL1Loss() (mean) between the prediction pred [B][R][F]
+ * padded with zero rows up to bt frames and x[:, :bt] (x [B][Tx][F], Tx >= bt >= R).
+ * ws: float[ssasr_smooth_l1_ws_floats()]; loss: float[1].  _bwd: dpred [B][R][F]; upstream float[1] or NULL. */
+int64_t ssasr_smooth_l1_ws_floats(void);
+int ssasr_smooth_l1_fwd(const float* pred, const float* x, int64_t B, int64_t bt, int64_t R, int64_t Tx, int64_t F,
+                        float* ws, float* loss, void* stream);
+int ssasr_smooth_l1_bwd(const float* pred, const float* x, int64_t B, int64_t bt, int64_t R, int64_t Tx, int64_t F,
+                        const float* upstream, float* dpred, void* stream);
+
 /* Frame lengths of zero-padded fbanks, prepare_x (src/ASRDataset.py:314):
  * lens[b] = number of frames whose feature sum is non-zero. */
 int ssasr_frame_lengths(const float* x, int64_t B, int64_t T, int64_t F, int32_t* lens,

@@ -403,6 +403,70 @@ def adv_train_step(asr, text_encoder, disc, G_optim, D_optim, x, y, label_smooth
     return float(d_real.detach()), float(d_fake.detach()), float(g_loss.detach()), d_norm, g_norm
 
 
+class OracleSpeechAutoEncoder(nn.Module):
+    """SpeechAutoEncoder, src/speech_autoencoder.py:5-203: a global encoder of three Conv2d(bias False) /
+    BatchNorm2d / ReLU / MaxPool2d blocks over [batch, 1, seq, feat] (:118-160) and a decoder
+    Linear LeakyReLU Linear LeakyReLU Linear (:183-188) applied to [listener frame | global encoding] once per
+    Listener frame, each call predicting the 8 input frames under that Listener frame (:62-94)."""
+
+    def __init__(self, listener_out_dim, feature_dim, kernel_sizes, num_filters, pool_kernel_sizes):
+        super().__init__()
+        self.feature_dim = feature_dim
+        enc = nn.Module()
+        chans = [1] + list(num_filters)
+        for k in range(3):
+            setattr(enc, 'conv_%d' % (k + 1), nn.Sequential(
+                nn.Conv2d(chans[k], chans[k + 1], kernel_size=tuple(kernel_sizes[k]), padding=0, bias=False),
+                nn.BatchNorm2d(chans[k + 1]), nn.ReLU(), nn.MaxPool2d(tuple(pool_kernel_sizes[k]))))
+        self.encoder = enc
+        dec = nn.Module()
+        in_dim = num_filters[-1] + listener_out_dim
+        dec.core = nn.Sequential(nn.Linear(in_dim, in_dim), nn.LeakyReLU(), nn.Linear(in_dim, in_dim), nn.LeakyReLU(),
+                                 nn.Linear(in_dim, 8 * feature_dim))
+        self.decoder = dec
+
+    def encode(self, x):
+        h = x.unsqueeze(1)
+        for k in (1, 2, 3):
+            h = getattr(self.encoder, 'conv_%d' % k)(h)
+        return h.squeeze(2).squeeze(2)
+
+    def forward(self, x, listener_out, just_first=False):
+        g = self.encode(x)
+        frames = []
+        for i in range(1 if just_first else listener_out.shape[1]):
+            out = self.decoder.core(torch.cat((listener_out[:, i, :], g), dim=1))
+            frames.append(out.view(out.shape[0], 8, self.feature_dim))
+        return torch.cat(frames, dim=1)
+
+
+def make_sae_optimizer(sae, asr, lr=1e-4, kind='Adam'):
+    """SAETrainer.set_model, src/trainer.py:789-794 with conf/default.yaml:24-26: ONE optimizer over the whole
+    speech autoencoder and the ASR model's Listener."""
+    return getattr(torch.optim, kind)(list(sae.parameters()) + list(asr.encoder.parameters()), lr=lr, eps=1e-8)
+
+
+def sae_loss(pred, x, batch_t):
+    """src/trainer.py:811-818: the prediction padded with zero frames up to batch_t against x[:, :batch_t]."""
+    full = torch.zeros(pred.shape[0], batch_t, pred.shape[2])
+    full[:, :pred.shape[1], :] = pred
+    return F.smooth_l1_loss(full, x[:, :batch_t, :])
+
+
+def sae_train_step(asr, sae, optim, x):
+    """One iteration of SAETrainer.exec, src/trainer.py:803-820: Listener, speech autoencoder, smooth-L1 against
+    the input frames, backward, then Solver.step on the SPEECH AUTOENCODER's parameters (the clipped norm is
+    theirs alone; the optimizer steps the Listener too).  Returns (loss, clipped norm)."""
+    lens = frame_lengths(x)
+    optim.zero_grad()
+    listener_out, _ = asr.encoder(x, lens)
+    pred = sae(x, listener_out)
+    loss = sae_loss(pred, x, max(lens))
+    loss.backward()
+    norm, _ = solver_step(list(sae.parameters()), optim)
+    return float(loss.detach()), norm
+
+
 def seeded_generic_weights(module, seed):
     """numpy-PCG64 parameters for the Seed loop's extra modules (Discriminator, SpeechAutoEncoder; reference
     or oracle: same names and order): matrices and convolution kernels N(0, 1/sqrt(fan_in)) with fan_in =

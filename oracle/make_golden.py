@@ -380,6 +380,67 @@ def capture_adv_traj(asr_mod, tae_mod, disc_mod, name, dims, tae_dims, hidden, b
                                                      np.round(out['g_loss'], 5), os.path.getsize(path) / 1024))
 
 
+def ref_sae_step(sae, asr, optim, x, x_lens):
+    """The body of the reference's SAETrainer.exec (src/trainer.py:803-820) around the reference's own
+    SpeechAutoEncoder / ASR classes."""
+    optim.zero_grad()
+    listener_out, _ = asr.encoder(x, x_lens)
+    autoenc_out = sae(x, listener_out)
+    batch_t = max(x_lens)
+    xt = x[:, :batch_t, :]
+    enc_final = torch.zeros([autoenc_out.shape[0], batch_t, autoenc_out.shape[2]])
+    enc_final[:, :autoenc_out.shape[1], :] = autoenc_out
+    loss = nn.SmoothL1Loss()(enc_final, xt)                                 # trainer.py:796
+    loss.backward()
+    norm = float(nn.utils.clip_grad_norm_(sae.parameters(), 5))             # Solver.step(speech_autoenc.parameters(), optim)
+    optim.step()
+    return float(loss.item()), norm
+
+
+def capture_sae_traj(asr_mod, sae_mod, name, dims, sae_cfg, batches, pad_to, seed, opt=('Adam', 1e-4)):
+    """A trajectory of SAETrainer iterations on the real reference's classes (config 5's third leg,
+    src/trainer.py:760-907): one optimizer over the speech autoencoder and the Listener (:789-794), the norm
+    clipped over the speech autoencoder alone (:820).  Every batch is padded to `pad_to` frames, as the
+    reference's dataset pads every utterance to the corpus maximum (src/ASRDataset.py:131-151): the global
+    encoder convolves the padding too, the loss stops at the batch's longest utterance.  Afterwards the eval-
+    mode loss of the first batch (running batch-norm statistics, SAETrainer.valid :853-868)."""
+    from las_oracle import seeded_generic_weights
+    from ss_asr_amd.synthetic import make_batch
+    seed_all(seed)
+    asr = asr_mod.ASR(*dims, 1.0)
+    seeded_weights(asr, seed + 100)
+    sae = sae_mod.SpeechAutoEncoder(asr.encoder.out_dim, dims[4], **sae_cfg)
+    seeded_generic_weights(sae, seed + 300)
+    optim = getattr(torch.optim, opt[0])(list(sae.parameters()) + list(asr.encoder.parameters()), lr=opt[1], eps=1e-8)
+    w0 = {('sae.' + k): v.clone() for k, v in sae.state_dict().items()}
+    w0.update({('asr.' + k): v.clone() for k, v in asr.state_dict().items()})
+    out = dict(dims=np.array(dims), seed=np.int64(seed), asr_weights_seed=np.int64(seed + 100),
+               sae_weights_seed=np.int64(seed + 300), rounds=np.int64(len(batches)), pad_to=np.int64(pad_to),
+               opt=np.array([opt[0], repr(opt[1])]), kernel_sizes=np.array(sae_cfg['kernel_sizes']),
+               num_filters=np.array(sae_cfg['num_filters']), pool_kernel_sizes=np.array(sae_cfg['pool_kernel_sizes']))
+    rows = []
+    for r, lens in enumerate(batches):
+        x, _, _ = make_batch(np.array(lens), np.full(len(lens), 3), dims[4], seed + 1000 + r, pad_to=pad_to)
+        rows.append(ref_sae_step(sae, asr, optim, x, list(lens)))
+        out['lens%d' % r], out['batch_seed%d' % r] = np.array(lens), np.int64(seed + 1000 + r)
+        if r == 0:
+            with torch.no_grad():
+                sae.eval()                                  # (a forward in eval mode moves no buffer)
+                lis, _ = asr.encoder(x, list(lens))
+                out['eval_pred_head'] = sae(x, lis).reshape(-1)[:512].numpy()
+                sae.train()
+    out['loss'], out['norm'] = np.array(rows).T
+    w1 = {('sae.' + k): v for k, v in sae.state_dict().items()}
+    w1.update({('asr.' + k): v for k, v in asr.state_dict().items()})
+    w0f = {k: v.to(torch.float32) for k, v in w0.items()}
+    w1f = {k: v.to(torch.float32) for k, v in w1.items()}
+    _weights_record(out, w0f, w1f, sum(v.numel() for v in w1.values()) < 400000)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-18s loss %s  norm %s  %.1f KB' % (name, np.round(out['loss'], 6), np.round(out['norm'], 6),
+                                               os.path.getsize(path) / 1024))
+
+
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)
     asr_mod = import_reference()
@@ -447,6 +508,23 @@ def main(only=None):
         capture_adv_traj(asr_mod, tae_mod, disc_mod, 'adv_traj_small_adam', small, (8, 32, 2), 24,
                          [([64, 56, 48, 40], [10, 7, 5, 3]), ([72, 50, 33, 17], [9, 6, 4, 2]), ([56, 56, 41, 24], [8, 8, 3, 5])],
                          52, ('Adam', 1e-3), ('Adam', 1e-3))
+    # config 5's third leg (SAETrainer, src/trainer.py:760-907): three iterations at full layer sizes with the
+    # yaml's kernels and filters (conf/default.yaml:27-30; its last pooling window, [2000, 40], needs utterances
+    # of 30,000 frames: the window here is what a 208-frame corpus leaves, [11, 40]), batches whose longest
+    # utterance is shorter than the padding and not a multiple of 8; and a small model with the kernel
+    # orientation of the class docstring (src/speech_autoencoder.py:108-110: time first), odd filter counts, Adam 1e-3
+    import speech_autoencoder as sae_mod                        # reference module
+    if not only or 'sae_traj_full_b8' in only:
+        capture_sae_traj(asr_mod, sae_mod, 'sae_traj_full_b8', full,
+                         dict(kernel_sizes=[[1, 36], [5, 1], [3, 1]], num_filters=[32, 64, 256],
+                              pool_kernel_sizes=[[3, 1], [5, 1], [11, 40]]),
+                         [[208, 184, 160, 152, 120, 96, 80, 64], [203, 176, 168, 144, 128, 104, 72, 40],
+                          [192, 190, 136, 128, 112, 88, 56, 48]], 208, 61)
+    if not only or 'sae_traj_small' in only:
+        capture_sae_traj(asr_mod, sae_mod, 'sae_traj_small', small,
+                         dict(kernel_sizes=[[7, 1], [1, 3], [2, 2]], num_filters=[6, 12, 20],
+                              pool_kernel_sizes=[[2, 1], [1, 2], [28, 3]]),
+                         [[64, 56, 48, 40], [61, 50, 33, 17], [56, 56, 41, 24]], 64, 62, opt=('Adam', 1e-3))
     for name, pick, seed, wseed in (('bench_b32_t800', 0, 8, 14), ('bench_b32_median', 4, 9, 15)):
         x, y, lens = config2_batches(8, batch_size=32, feat_dim=80, seed=1)[pick]
         ylens = [int(v) - 1 for v in (y != 0).sum(-1)]

@@ -90,6 +90,18 @@ SIGNATURES = {
     'ssasr_act_bwd': (I32, [I32, P, P, P, I64, P]),
     'ssasr_bce_fwd': (I32, [P, I64, F32, P, P]),
     'ssasr_bce_bwd': (I32, [P, I64, F32, P, P, P]),
+    'ssasr_conv2d_ws_floats': (I64, [I64] * 7),
+    'ssasr_conv2d_fwd': (I32, [P, P, P] + [I64] * 7 + [P, P]),
+    'ssasr_conv2d_bwd': (I32, [P, I32, P, P, P, P] + [I64] * 7 + [P, P]),
+    'ssasr_bn_ws_floats': (I64, [I64]),
+    'ssasr_bn_stats': (I32, [P, I64, I64, P, P, P, P, F32, F32, I32, P, P, P]),
+    'ssasr_bn_relu_pool_fwd': (I32, [P, P] + [I64] * 6 + [P, P, P]),
+    'ssasr_bn_relu_pool_bwd': (I32, [P, P, P, P, P, P] + [I64] * 8 + [P, P, P, P, P]),
+    'ssasr_sae_concat_fwd': (I32, [P, P, I64, I64, I64, I64, P, P]),
+    'ssasr_sae_concat_bwd': (I32, [P, I64, I64, I64, I64, P, P, P]),
+    'ssasr_smooth_l1_ws_floats': (I64, []),
+    'ssasr_smooth_l1_fwd': (I32, [P, P] + [I64] * 5 + [P, P, P]),
+    'ssasr_smooth_l1_bwd': (I32, [P, P] + [I64] * 5 + [P, P, P]),
     'ssasr_bilstm_bwd_gx_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_bwd_ring_floats': (I64, [I64, I64, I64, I64]),
     'ssasr_decoder_bwd_chain_floats': (I64, [I64] * 6),

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libssasr_hip.so')
-SOURCES = ['gemm.hip', 'rnn.hip', 'decoder.hip', 'loss_opt.hip', 'ctc.hip', 'frontend.hip', 'seed.hip', 'options.hip']
+SOURCES = ['gemm.hip', 'rnn.hip', 'decoder.hip', 'loss_opt.hip', 'ctc.hip', 'frontend.hip', 'seed.hip', 'sae.hip', 'options.hip']
 HEADERS = ['common.h', 'rnn_kernels.h', 'attn_kernels.h', 'decoder_persistent.h', 'decoder_long.h',
            'decoder_bwd_persistent.h',
            os.path.join('..', '..', 'include', 'ssasr.h')]

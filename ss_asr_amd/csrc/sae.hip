@@ -1,0 +1,567 @@
+// SAETrainer's SpeechAutoEncoder around the shared Listener (src/speech_autoencoder.py, src/trainer.py:760-907;
+// BASELINE.json configs[4]'s third leg): the global speech encoder -- three times convolution, batch norm,
+// ReLU, max pooling (:118-147) -- and the pieces of the frame decoder and its smooth-L1 loss that are not dense
+// layers (those are seed.hip's ssasr_linear_*).
+//
+// Activations are CHANNELS-LAST, [B][T][W][C] (time, mel, channel): the fbank batch [B][T][F] is the first
+// layer's input as it stands (C = 1), a pixel's channels are one contiguous run, and a convolution is a GEMM
+// whose A rows are overlapping windows of the input read IN PLACE through a row map (common.h RowMap) --
+// the kw * C values under a kernel row are contiguous, kernel rows are K segments (GemmDesc::kcat) -- so no
+// im2col copy is made where the shape allows it (a kernel row of kw * C values a multiple of 32, or a single
+// kernel row); other shapes take an im2col copy and a dense GEMM.  Weight and input gradients are the same
+// two products turned round.  Batch norm and pooling are HBM-bound passes over those tensors.
+#include "../../include/ssasr.h"
+#include "common.h"
+
+namespace {
+
+inline int stream_grid(int64_t n, int per_thread = 4) {
+  int64_t g = (n + 256 * (int64_t)per_thread - 1) / (256 * (int64_t)per_thread);
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// ------------------------------------------------------------------ convolution ----
+// torch's [F][C][kh][kw] kernel in the layouts the products read:
+//   mode 0  rows : out[i][f][j * C + c] = w[f][c][i][j]                      (forward, fast path)
+//   mode 1  flip : out[i][c][j * F + f] = w[f][c][kh - 1 - i][kw - 1 - j]    (input gradient: full correlation)
+//   mode 2  col  : out[f][(i * kw + j) * C + c] = w[f][c][i][j]              (forward, im2col path)
+//   mode 3  fcol : out[c][(i * kw + j) * F + f] = w[f][c][kh - 1 - i][kw - 1 - j]
+__global__ void conv_w_layout_kernel(const float* w, float* out, int F, int C, int kh, int kw, int mode) {
+  const int n = F * C * kh * kw;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int j = e % kw, i = (e / kw) % kh, c = (e / (kw * kh)) % C, f = e / (kw * kh * C);
+    int64_t o;
+    if (mode == 0) o = ((int64_t)i * F + f) * (kw * C) + j * C + c;
+    else if (mode == 1) o = ((int64_t)(kh - 1 - i) * C + c) * (kw * F) + (kw - 1 - j) * F + f;
+    else if (mode == 2) o = (int64_t)f * (kh * kw * C) + (i * kw + j) * C + c;
+    else o = (int64_t)c * (kh * kw * F) + ((kh - 1 - i) * kw + (kw - 1 - j)) * F + f;
+    out[o] = w[e];
+  }
+}
+
+// dw[f][c][i][j] += the product's result in the rows (mode 0) or col (mode 2) layout
+__global__ void conv_dw_fold_kernel(const float* src, float* dw, int F, int C, int kh, int kw, int mode) {
+  const int n = F * C * kh * kw;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int j = e % kw, i = (e / kw) % kh, c = (e / (kw * kh)) % C, f = e / (kw * kh * C);
+    const int64_t o = mode == 0 ? ((int64_t)i * F + f) * (kw * C) + j * C + c
+                                : (int64_t)f * (kh * kw * C) + (i * kw + j) * C + c;
+    dw[e] += src[o];
+  }
+}
+
+// col[(b, t, m)][(i, j, c)] = x[b][t + i][m + j][c]
+__global__ void im2col_kernel(const float* x, float* col, int64_t B, int64_t T, int64_t W, int C, int kh, int kw) {
+  const int64_t To = T - kh + 1, Wo = W - kw + 1;
+  const int K = kh * kw * C;
+  const int64_t n = B * To * Wo * K, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const int k = (int)(e % K);
+    const int64_t row = e / K;
+    const int c = k % C, j = (k / C) % kw, i = k / (C * kw);
+    const int64_t m = row % Wo, t = (row / Wo) % To, b = row / (Wo * To);
+    col[e] = x[((b * T + t + i) * W + m + j) * C + c];
+  }
+}
+
+// (kernel rows as K segments need the split-bf16 GEMM; SSASR_GEMM_X6=0 sends those shapes through im2col)
+inline bool conv_in_place(int64_t C, int kh, int kw) { return kh == 1 || ((kw * C) % 32 == 0 && ssasr_options().gemm_x6); }
+
+// y[b][t][m][f] = sum_{i, j, c} x[b][t + i][m + j][c] * K[f][c][i][j], t < T - kh + 1, m < W - kw + 1, with the
+// kernel already in `wl`: rows layout (in-place path) or col layout (im2col path, `col` = the scratch for it)
+int conv_product(const float* x, int64_t B, int64_t T, int64_t W, int64_t C, const float* wl, int64_t F, int kh, int kw,
+                 float* y, float* col, hipStream_t st) {
+  const int64_t To = T - kh + 1, Wo = W - kw + 1;
+  GemmDesc g{};
+  g.alpha = 1.f; g.beta = 0.f; g.splitk = 1;
+  g.B = wl; g.C = y; g.N = (int)F;
+  if (conv_in_place(C, kh, kw)) {
+    g.A = x;
+    g.ma = RowMap{0, Wo, W * C, C};            // row (t, m) of one utterance
+    g.K = (int)(kw * C); g.mb = rm_dense(kw * C); g.mc = rm_dense(F);
+    g.M = (int)(To * Wo);
+    g.batch = (int)B; g.sa = T * W * C; g.sb = 0; g.sc = To * Wo * F;
+    if (kh > 1) { g.kcat = kh; g.ska = W * C; g.skb = F * kw * C; }
+    return ssasr_launch_gemm(g, st);
+  }
+  const int64_t K = (int64_t)kh * kw * C, rows = B * To * Wo;
+  if (rows * K > (int64_t)1 << 40 || rows > 0x7fffffff) return SSASR_EARG;
+  hipLaunchKernelGGL(im2col_kernel, dim3(stream_grid(rows * K)), dim3(256), 0, st, x, col, B, T, W, (int)C, kh, kw);
+  SSASR_LAUNCH_CHECK();
+  g.A = col; g.ma = rm_dense(K); g.mb = rm_dense(K); g.mc = rm_dense(F);
+  g.M = (int)rows; g.K = (int)K; g.batch = 1;
+  return ssasr_launch_gemm(g, st);
+}
+
+inline int64_t conv_col_floats(int64_t B, int64_t T, int64_t W, int64_t C, int kh, int kw) {
+  return conv_in_place(C, kh, kw) ? 0 : B * (T - kh + 1) * (W - kw + 1) * kh * kw * C;
+}
+
+// ------------------------------------------------------------------ batch norm ----
+// per-channel sums over the rows of a channels-last [rows][C] tensor, in double:
+//   CENTERED = false: acc[c] += sum_r y[r][c];  true: acc[C + c] += sum_r (y[r][c] - acc[c] / rows)^2
+template <bool CENTERED>
+__global__ __launch_bounds__(256) void bn_sum_kernel(const float* y, int64_t rows, int C, int CT, double* acc) {
+  __shared__ double sm[256];
+  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT, RL = 256 / CT;
+  const int c = blockIdx.y * CT + cl;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  const float mean = (CENTERED && c < C) ? (float)(acc[c] / (double)rows) : 0.f;
+  double tot = 0.0;
+  if (c < C) {
+    int64_t r = r0 + rl;
+    while (r < r1) {
+      float part = 0.f;                                    // fp32 over a short run, double across runs
+      for (int k = 0; k < 64 && r < r1; ++k, r += RL) {
+        const float v = y[r * C + c] - mean;
+        part += CENTERED ? v * v : v;
+      }
+      tot += (double)part;
+    }
+  }
+  sm[threadIdx.x] = tot;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double s = 0.0;
+    for (int k = 0; k < RL; ++k) s += sm[k * CT + cl];
+    atomicAdd(acc + (CENTERED ? C : 0) + c, s);
+  }
+}
+
+// save[0][c] mean, [1] 1 / sqrt(var + eps), [2] scale = gamma * invstd, [3] shift = beta - mean * scale;
+// training: batch statistics (biased variance), running statistics updated with the unbiased one
+// (nn.BatchNorm2d, momentum 0.1); eval: the running statistics.
+__global__ void bn_finalize_kernel(const double* acc, int64_t rows, int C, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, int training,
+                                   float* save) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    float mean, var;
+    if (training) {
+      mean = (float)(acc[c] / (double)rows);
+      var = (float)(acc[C + c] / (double)rows);
+      const float unbiased = rows > 1 ? (float)(acc[C + c] / (double)(rows - 1)) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float scale = gamma[c] * invstd;
+    save[c] = mean; save[C + c] = invstd; save[2 * C + c] = scale; save[3 * C + c] = beta[c] - mean * scale;
+  }
+}
+
+// ------------------------------------------------------------------ normalise + ReLU + max pool ----
+// p[b][to][wo][c] = max over the ph x pw window of relu(y * scale + shift); idx = offset (i * pw + j) of the FIRST
+// maximum inside the window (torch's rule).  Remainder rows / columns are dropped (floor mode).
+// Small windows: one thread per output value.
+__global__ void pool_fwd_small_kernel(const float* y, const float* save, int64_t B, int64_t T, int64_t W, int C, int ph,
+                                      int pw, float* p, int32_t* idx) {
+  const int64_t To = T / ph, Wo = W / pw, n = B * To * Wo * C, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const int c = (int)(e % C);
+    const int64_t pos = e / C, wo = pos % Wo, to = (pos / Wo) % To, b = pos / (Wo * To);
+    const float sc = save[2 * C + c], sh = save[3 * C + c];
+    const float* base = y + ((b * T + to * ph) * W + wo * pw) * C + c;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int i = 0; i < ph; ++i)
+      for (int j = 0; j < pw; ++j) {
+        const float v = fmaxf(fmaf(base[((int64_t)i * W + j) * C], sc, sh), 0.f);
+        if (v > best) { best = v; bi = i * pw + j; }
+      }
+    p[e] = best;
+    idx[e] = bi;
+  }
+}
+
+// Large windows (the last layer pools a whole utterance, [2000, 40] in conf/default.yaml:30): one workgroup per
+// output pixel and tile of CT channels, the window split over 256 / CT thread rows, combined through LDS.
+__global__ __launch_bounds__(256) void pool_fwd_large_kernel(const float* y, const float* save, int64_t T, int64_t W, int C,
+                                                            int CT, int ph, int pw, int64_t To, int64_t Wo, float* p,
+                                                            int32_t* idx) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int cl = threadIdx.x % CT, wl = threadIdx.x / CT, WL = 256 / CT;
+  const int c = blockIdx.y * CT + cl;
+  const int64_t pos = blockIdx.x, wo = pos % Wo, to = (pos / Wo) % To, b = pos / (Wo * To);
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (c < C) {
+    const float sc = save[2 * C + c], sh = save[3 * C + c];
+    const float* base = y + ((b * T + to * ph) * W + wo * pw) * C + c;
+    const int win = ph * pw;
+    for (int e = wl; e < win; e += WL) {
+      const int i = e / pw, j = e % pw;
+      const float v = fmaxf(fmaf(base[((int64_t)i * W + j) * C], sc, sh), 0.f);
+      if (v > best) { best = v; bi = e; }
+    }
+  }
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  __syncthreads();
+  if (wl == 0 && c < C) {
+    for (int k = 1; k < WL; ++k) {
+      const float v = sv[k * CT + cl];
+      const int vi = si[k * CT + cl];
+      if (v > best || (v == best && vi < bi)) { best = v; bi = vi; }
+    }
+    p[pos * C + c] = best;
+    idx[pos * C + c] = bi;
+  }
+}
+
+// Backward, first pass: per channel s1 = sum dz, s2 = sum dz * xhat over the pooled outputs, dz = dp * (p > 0)
+// landing on the window's arg-max (every other position of the layer has dz = 0).
+__global__ __launch_bounds__(256) void pool_bwd_sums_kernel(const float* dp, const float* p, const int32_t* idx, const float* y,
+                                                           const float* save, int64_t B, int64_t T, int64_t W, int C, int CT,
+                                                           int ph, int pw, double* acc) {
+  __shared__ double s1[256], s2[256];
+  const int cl = threadIdx.x % CT, rl = threadIdx.x / CT, RL = 256 / CT;
+  const int c = blockIdx.y * CT + cl;
+  const int64_t To = T / ph, Wo = W / pw, npos = B * To * Wo;
+  const int64_t per = (npos + gridDim.x - 1) / gridDim.x, q0 = blockIdx.x * per, q1 = min(npos, q0 + per);
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    const float mean = save[c], invstd = save[C + c];
+    for (int64_t q = q0 + rl; q < q1; q += RL) {
+      const float pv = p[q * C + c];
+      if (pv > 0.f) {
+        const float dz = dp[q * C + c];
+        const int k = idx[q * C + c];
+        const int64_t wo = q % Wo, to = (q / Wo) % To, b = q / (Wo * To);
+        const float yv = y[((b * T + to * ph + k / pw) * W + wo * pw + k % pw) * C + c];
+        a1 += (double)dz;
+        a2 += (double)(dz * ((yv - mean) * invstd));
+      }
+    }
+  }
+  s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < RL; ++k) { t1 += s1[k * CT + cl]; t2 += s2[k * CT + cl]; }
+    atomicAdd(acc + c, t1);
+    atomicAdd(acc + C + c, t2);
+  }
+}
+
+// Backward, second pass, every position of the layer: dy = gamma * invstd * (dz - s1 / n - xhat * s2 / n)
+// (batch norm in training mode), written inside a zero border of (bt, bw) pixels when the convolution's input
+// gradient is wanted next (its full correlation then reads the border in place).  Block 0 also adds the two
+// parameter gradients: dgamma += s2, dbeta += s1.
+__global__ void bn_pool_bwd_apply_kernel(const float* dp, const float* p, const int32_t* idx, const float* y,
+                                         const float* save, const float* gamma, const double* acc, int64_t B, int64_t T,
+                                         int64_t W, int C, int ph, int pw, int bt, int bw, float* dy, float* dgamma,
+                                         float* dbeta) {
+  const int64_t To = T / ph, Wo = W / pw, n = B * T * W * C, stride = (int64_t)gridDim.x * blockDim.x;
+  const double count = (double)(B * T * W);
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      if (dgamma) dgamma[c] += (float)acc[C + c];
+      if (dbeta) dbeta[c] += (float)acc[c];
+    }
+  const int64_t Tp = T + 2 * bt, Wp = W + 2 * bw;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const int c = (int)(e % C);
+    const int64_t pos = e / C, m = pos % W, t = (pos / W) % T, b = pos / (W * T);
+    const float mean = save[c], invstd = save[C + c];
+    const float xhat = (y[e] - mean) * invstd;
+    const int64_t to = t / ph, wo = m / pw;
+    float dz = 0.f;
+    if (to < To && wo < Wo) {
+      const int64_t q = ((b * To + to) * Wo + wo) * C + c;
+      if (p[q] > 0.f && idx[q] == (int)((t % ph) * pw + (m % pw))) dz = dp[q];
+    }
+    const float m1 = (float)(acc[c] / count), m2 = (float)(acc[C + c] / count);
+    dy[((b * Tp + t + bt) * Wp + m + bw) * C + c] = gamma[c] * invstd * (dz - m1 - xhat * m2);
+  }
+}
+
+// ------------------------------------------------------------------ the frame decoder's input ----
+// din[(b, i)][0 .. L) = listener[b][i][:], din[(b, i)][L .. L + G) = enc[b][:]   (src/speech_autoencoder.py:72-75)
+__global__ void sae_concat_fwd_kernel(const float* listener, const float* enc, int64_t B, int64_t Tq, int L, int G,
+                                      float* din) {
+  const int D = L + G;
+  const int64_t n = B * Tq * D, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const int k = (int)(e % D);
+    const int64_t row = e / D;
+    din[e] = k < L ? listener[row * L + k] : enc[(row / Tq) * G + (k - L)];
+  }
+}
+// dlistener[b][i][:] = ddin[(b, i)][0 .. L);  denc[b][g] = sum_i ddin[(b, i)][L + g]
+__global__ void sae_concat_bwd_kernel(const float* ddin, int64_t B, int64_t Tq, int L, int G, float* dlistener, float* denc) {
+  const int D = L + G;
+  const int64_t nl = B * Tq * L, ne = B * G, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nl + ne; e += stride) {
+    if (e < nl) {
+      dlistener[e] = ddin[(e / L) * D + e % L];
+    } else {
+      const int64_t q = e - nl, b = q / G;
+      const int g = (int)(q % G);
+      float s = 0.f;
+      for (int64_t i = 0; i < Tq; ++i) s += ddin[(b * Tq + i) * D + L + g];
+      denc[q] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ smooth L1 ----
+// nn.SmoothL1Loss() between the prediction padded with zero rows up to `bt` frames and x[:, :bt]
+// (src/trainer.py:811-818): mean over B * bt * F of 0.5 d^2 (|d| < 1) or |d| - 0.5, d = pred - x.
+__device__ __forceinline__ float sl1_diff(const float* pred, const float* x, int64_t e, int64_t bt, int64_t R, int64_t Tx, int F) {
+  const int f = (int)(e % F);
+  const int64_t r = (e / F) % bt, b = e / (F * bt);
+  const float xv = x[(b * Tx + r) * F + f];
+  return (r < R ? pred[(b * R + r) * F + f] : 0.f) - xv;
+}
+__global__ __launch_bounds__(256) void sl1_fwd_kernel(const float* pred, const float* x, int64_t B, int64_t bt, int64_t R,
+                                                     int64_t Tx, int F, double* partial) {
+  __shared__ double sm[256];
+  const int64_t n = B * bt * F, stride = (int64_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const float d = sl1_diff(pred, x, e, bt, R, Tx, F), a = fabsf(d);
+    acc += (double)(a < 1.f ? 0.5f * d * d : a - 0.5f);
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+__global__ void sl1_mean_kernel(const double* partial, int nblocks, double count, float* loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < nblocks; ++k) s += partial[k];       // fixed order: deterministic
+    *loss = (float)(s / count);
+  }
+}
+// dpred[b][r][f] = upstream * clamp(d, -1, 1) / (B * bt * F), rows r < R only (the zero rows are constants)
+__global__ void sl1_bwd_kernel(const float* pred, const float* x, int64_t B, int64_t bt, int64_t R, int64_t Tx, int F,
+                               const float* upstream, float* dpred) {
+  const float g = (upstream ? *upstream : 1.0f) / (float)(B * bt * F);
+  const int64_t n = B * R * F, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const int f = (int)(e % F);
+    const int64_t r = (e / F) % R, b = e / (F * R);
+    float d = 0.f;
+    if (r < bt) d = pred[e] - x[(b * Tx + r) * F + f];
+    dpred[e] = r < bt ? g * fminf(fmaxf(d, -1.f), 1.f) : 0.f;
+  }
+}
+
+inline int chan_tile(int64_t C) { return C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256)); }
+
+}  // namespace
+
+// =============================================================================================================
+extern "C" int64_t ssasr_conv2d_ws_floats(int64_t B, int64_t T, int64_t W, int64_t C, int64_t F, int64_t kh, int64_t kw) {
+  if (B <= 0 || C <= 0 || F <= 0 || kh <= 0 || kw <= 0 || T < kh || W < kw) return 0;
+  const int64_t wsz = (F * C * kh * kw + 3) / 4 * 4;
+  const int64_t To = T - kh + 1, Wo = W - kw + 1;
+  // the input gradient convolves the zero-bordered output gradient [B][To + 2 (kh - 1)][Wo + 2 (kw - 1)][F]
+  const int64_t colx = conv_col_floats(B, T, W, C, (int)kh, (int)kw);
+  const int64_t coly = conv_col_floats(B, To + 2 * (kh - 1), Wo + 2 * (kw - 1), F, (int)kh, (int)kw);
+  return 2 * wsz + (colx > coly ? colx : coly);
+}
+
+extern "C" int ssasr_conv2d_fwd(const float* x, const float* w, float* y, int64_t B, int64_t T, int64_t W, int64_t C,
+                                int64_t F, int64_t kh, int64_t kw, float* ws, void* stream) {
+  if (!x || !w || !y || !ws || B <= 0 || C <= 0 || F <= 0 || kh <= 0 || kw <= 0 || T < kh || W < kw) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t wsz = (F * C * kh * kw + 3) / 4 * 4;
+  const bool inplace = conv_in_place(C, (int)kh, (int)kw);
+  hipLaunchKernelGGL(conv_w_layout_kernel, dim3(stream_grid(F * C * kh * kw, 1)), dim3(256), 0, st, w, ws, (int)F, (int)C,
+                     (int)kh, (int)kw, inplace ? 0 : 2);
+  SSASR_LAUNCH_CHECK();
+  return conv_product(x, B, T, W, C, ws, F, (int)kh, (int)kw, y, ws + 2 * wsz, st);
+}
+
+extern "C" int ssasr_conv2d_bwd(const float* dy, int dy_bordered, const float* x, const float* w, float* dx, float* dw,
+                                int64_t B, int64_t T, int64_t W, int64_t C, int64_t F, int64_t kh, int64_t kw, float* ws,
+                                void* stream) {
+  if (!dy || !ws || B <= 0 || C <= 0 || F <= 0 || kh <= 0 || kw <= 0 || T < kh || W < kw || (dx && (!w || !dy_bordered)) ||
+      (dw && !x))
+    return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int ikh = (int)kh, ikw = (int)kw;
+  const int64_t n_w = F * C * kh * kw, wsz = (n_w + 3) / 4 * 4;
+  const int64_t To = T - kh + 1, Wo = W - kw + 1;
+  const int64_t bt = dy_bordered ? kh - 1 : 0, bw = dy_bordered ? kw - 1 : 0;
+  const int64_t Tp = To + 2 * bt, Wp = Wo + 2 * bw;                    // geometry of dy as stored
+  const float* dy_in = dy + (bt * Wp + bw) * F;                        // its first interior pixel
+  float* wl = ws;
+  float* dwl = ws + wsz;
+  float* col = ws + 2 * wsz;
+  int rc;
+  if (dw) {
+    SSASR_HIP(hipMemsetAsync(dwl, 0, sizeof(float) * n_w, st));
+    if (conv_in_place(C, ikh, ikw)) {
+      // per kernel row i: dK_i[f][(j, c)] += sum_{b, t, m} dy[b][t][m][f] * x[b][t + i][m + j][c], utterances as the
+      // batch axis and K slices on top so that the few output tiles still fill the chip; partial products are added
+      const int64_t tiles = ((F + 63) / 64) * ((kw * C + 63) / 64);
+      int64_t s = (512 + tiles * B - 1) / (tiles * B), smax = (To * Wo) / 256;
+      if (s > smax) s = smax;
+      if (s < 2) s = 2;                                                // (>= 2: the batch entries share C)
+      for (int i = 0; i < ikh; ++i) {
+        GemmDesc g{};
+        g.A = dy_in; g.ta = 1;
+        g.ma = RowMap{0, Wo, Wp * F, F};                              // k = (t, m) -> the pixel's F gradients
+        g.B = x + (int64_t)i * W * C; g.tb = 1;
+        g.mb = RowMap{0, Wo, W * C, C};                               // k -> the kw * C inputs under kernel row i
+        g.C = dwl + (int64_t)i * F * kw * C; g.mc = rm_dense(kw * C);
+        g.M = (int)F; g.N = (int)(kw * C); g.K = (int)(To * Wo);
+        g.alpha = 1.f; g.beta = 1.f; g.splitk = (int)s;
+        g.batch = (int)B; g.sa = Tp * Wp * F; g.sb = T * W * C; g.sc = 0;
+        if ((rc = ssasr_launch_gemm(g, st))) return rc;
+      }
+      hipLaunchKernelGGL(conv_dw_fold_kernel, dim3(stream_grid(n_w, 1)), dim3(256), 0, st, dwl, dw, (int)F, (int)C, ikh, ikw, 0);
+    } else {
+      if (dy_bordered) return SSASR_EARG;          // (the im2col form reads dy as one dense [rows][F] matrix)
+      const int64_t K = kh * kw * C, rows = B * To * Wo;
+      if (rows > 0x7fffffff) return SSASR_EARG;
+      hipLaunchKernelGGL(im2col_kernel, dim3(stream_grid(rows * K)), dim3(256), 0, st, x, col, B, T, W, (int)C, ikh, ikw);
+      SSASR_LAUNCH_CHECK();
+      GemmDesc g{};
+      g.A = dy; g.ta = 1; g.ma = rm_dense(F);
+      g.B = col; g.tb = 1; g.mb = rm_dense(K);
+      g.C = dwl; g.mc = rm_dense(K);
+      g.M = (int)F; g.N = (int)K; g.K = (int)rows;
+      g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
+      const int64_t tiles = ((F + 63) / 64) * ((K + 63) / 64);
+      int64_t s = (512 + tiles - 1) / tiles, smax = rows / 256;
+      if (s > smax) s = smax;
+      g.splitk = (int)(s < 1 ? 1 : s);
+      if ((rc = ssasr_launch_gemm(g, st))) return rc;
+      hipLaunchKernelGGL(conv_dw_fold_kernel, dim3(stream_grid(n_w, 1)), dim3(256), 0, st, dwl, dw, (int)F, (int)C, ikh, ikw, 2);
+    }
+    SSASR_LAUNCH_CHECK();
+  }
+  if (dx) {
+    // full correlation: dx[b][t][m][c] = sum_{i, j, f} dyb[b][t + i][m + j][f] * K[f][c][kh - 1 - i][kw - 1 - j] over the
+    // zero-bordered gradient -- the forward product with channels and kernel turned round
+    const bool inplace = conv_in_place(F, ikh, ikw);
+    hipLaunchKernelGGL(conv_w_layout_kernel, dim3(stream_grid(n_w, 1)), dim3(256), 0, st, w, wl, (int)F, (int)C, ikh, ikw,
+                       inplace ? 1 : 3);
+    SSASR_LAUNCH_CHECK();
+    if ((rc = conv_product(dy, B, Tp, Wp, F, wl, C, ikh, ikw, dx, col, st))) return rc;
+  }
+  return SSASR_OK;
+}
+
+extern "C" int64_t ssasr_bn_ws_floats(int64_t C) { return 4 * C + 8; }        // 2 C doubles (+ alignment slack)
+
+static double* bn_acc(float* ws) { return reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7); }
+
+extern "C" int ssasr_bn_stats(const float* y, int64_t rows, int64_t C, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int training, float* ws,
+                              float* save, void* stream) {
+  if (!y || !gamma || !beta || !running_mean || !running_var || !ws || !save || rows <= 0 || C <= 0) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  double* acc = bn_acc(ws);
+  if (training) {
+    SSASR_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st));
+    const int CT = chan_tile(C);
+    int64_t gx = (rows + (256 / CT) * 64 - 1) / ((256 / CT) * 64);
+    gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
+    dim3 grid((unsigned)gx, (unsigned)((C + CT - 1) / CT));
+    hipLaunchKernelGGL((bn_sum_kernel<false>), grid, dim3(256), 0, st, y, rows, (int)C, CT, acc);
+    hipLaunchKernelGGL((bn_sum_kernel<true>), grid, dim3(256), 0, st, y, rows, (int)C, CT, acc);
+    SSASR_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, acc, rows, (int)C, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, save);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_bn_relu_pool_fwd(const float* y, const float* save, int64_t B, int64_t T, int64_t W, int64_t C,
+                                      int64_t ph, int64_t pw, float* p, int32_t* idx, void* stream) {
+  if (!y || !save || !p || !idx || B <= 0 || C <= 0 || ph <= 0 || pw <= 0 || T < ph || W < pw || ph * pw > 0x7ffffff)
+    return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t To = T / ph, Wo = W / pw;
+  if (ph * pw < 64) {
+    hipLaunchKernelGGL(pool_fwd_small_kernel, dim3(stream_grid(B * To * Wo * C, 1)), dim3(256), 0, st, y, save, B, T, W, (int)C,
+                       (int)ph, (int)pw, p, idx);
+  } else {
+    const int CT = chan_tile(C);
+    if (B * To * Wo > 0x7fffffff) return SSASR_EARG;
+    dim3 grid((unsigned)(B * To * Wo), (unsigned)((C + CT - 1) / CT));
+    hipLaunchKernelGGL(pool_fwd_large_kernel, grid, dim3(256), 0, st, y, save, T, W, (int)C, CT, (int)ph, (int)pw, To, Wo, p, idx);
+  }
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_bn_relu_pool_bwd(const float* dp, const float* p, const int32_t* idx, const float* y, const float* save,
+                                      const float* gamma, int64_t B, int64_t T, int64_t W, int64_t C, int64_t ph, int64_t pw,
+                                      int64_t border_t, int64_t border_w, float* dy, float* dgamma, float* dbeta, float* ws,
+                                      void* stream) {
+  if (!dp || !p || !idx || !y || !save || !gamma || !dy || !ws || B <= 0 || C <= 0 || ph <= 0 || pw <= 0 || T < ph || W < pw ||
+      border_t < 0 || border_w < 0)
+    return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  double* acc = bn_acc(ws);
+  SSASR_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st));
+  if (border_t || border_w)
+    SSASR_HIP(hipMemsetAsync(dy, 0, sizeof(float) * B * (T + 2 * border_t) * (W + 2 * border_w) * C, st));
+  const int CT = chan_tile(C);
+  const int64_t npos = B * (T / ph) * (W / pw);
+  int64_t gx = (npos + (256 / CT) * 16 - 1) / ((256 / CT) * 16);
+  gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
+  hipLaunchKernelGGL(pool_bwd_sums_kernel, dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
+                     B, T, W, (int)C, CT, (int)ph, (int)pw, acc);
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(stream_grid(B * T * W * C)), dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
+                     B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_sae_concat_fwd(const float* listener, const float* enc, int64_t B, int64_t Tq, int64_t L, int64_t G,
+                                    float* din, void* stream) {
+  if (!listener || !enc || !din || B <= 0 || Tq <= 0 || L <= 0 || G <= 0) return SSASR_EARG;
+  hipLaunchKernelGGL(sae_concat_fwd_kernel, dim3(stream_grid(B * Tq * (L + G))), dim3(256), 0, (hipStream_t)stream, listener, enc, B,
+                     Tq, (int)L, (int)G, din);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_sae_concat_bwd(const float* ddin, int64_t B, int64_t Tq, int64_t L, int64_t G, float* dlistener, float* denc,
+                                    void* stream) {
+  if (!ddin || !dlistener || !denc || B <= 0 || Tq <= 0 || L <= 0 || G <= 0) return SSASR_EARG;
+  hipLaunchKernelGGL(sae_concat_bwd_kernel, dim3(stream_grid(B * Tq * L + B * G, 1)), dim3(256), 0, (hipStream_t)stream, ddin, B, Tq,
+                     (int)L, (int)G, dlistener, denc);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+constexpr int SL1_BLOCKS = 512;
+extern "C" int64_t ssasr_smooth_l1_ws_floats(void) { return 2 * SL1_BLOCKS + 2; }
+
+extern "C" int ssasr_smooth_l1_fwd(const float* pred, const float* x, int64_t B, int64_t bt, int64_t R, int64_t Tx, int64_t F,
+                                   float* ws, float* loss, void* stream) {
+  if (!pred || !x || !ws || !loss || B <= 0 || bt <= 0 || R < 0 || Tx < bt || F <= 0) return SSASR_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = bn_acc(ws);
+  int g = stream_grid(B * bt * F);
+  if (g > SL1_BLOCKS) g = SL1_BLOCKS;
+  hipLaunchKernelGGL(sl1_fwd_kernel, dim3(g), dim3(256), 0, st, pred, x, B, bt, R, Tx, (int)F, partial);
+  hipLaunchKernelGGL(sl1_mean_kernel, dim3(1), dim3(64), 0, st, partial, g, (double)(B * bt * F), loss);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+extern "C" int ssasr_smooth_l1_bwd(const float* pred, const float* x, int64_t B, int64_t bt, int64_t R, int64_t Tx, int64_t F,
+                                   const float* upstream, float* dpred, void* stream) {
+  if (!pred || !x || !dpred || B <= 0 || bt <= 0 || R <= 0 || Tx < bt || F <= 0) return SSASR_EARG;
+  hipLaunchKernelGGL(sl1_bwd_kernel, dim3(stream_grid(B * R * F)), dim3(256), 0, (hipStream_t)stream, pred, x, B, bt, R, Tx, (int)F,
+                     upstream, dpred);
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}

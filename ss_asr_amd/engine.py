@@ -236,3 +236,61 @@ class ADVTrainStep:
             self.skipped_steps += int(done[1])
         self._note(self.G_optim.poll(wait=True))
         return self.last_done
+
+
+class SAETrainStep:
+    """One SAETrainer iteration (src/trainer.py:803-820) as a reusable object: the shared Listener, the speech
+    autoencoder over its output and the raw frames, smooth-L1 against the input frames (:811-818), backward,
+    gradient all-reduce, then Solver.step as the reference calls it -- norm, NaN guard and clip over the SPEECH
+    AUTOENCODER's parameters only (:820), Adam (:789-794, conf/default.yaml:24-26) over them AND the Listener.
+    The Listener's parameters stay where the ASR model's flat buffer has them (its first run): the other legs of
+    the Seed loop train the same storage.  Batch-norm running statistics are per rank (the reference is
+    single-device; they do not enter the training arithmetic)."""
+
+    def __init__(self, asr_model, sae_model, opt=('Adam', 1e-4), grad_clip=5.0):
+        if not next(sae_model.parameters()).is_cuda or not next(asr_model.parameters()).is_cuda:
+            raise RuntimeError('SAETrainStep needs both models on the GPU (no CPU path)')
+        if opt[0] != 'Adam':
+            raise NotImplementedError('SAETrainStep: optimizer type %r (Adam has the kernel whose clipped range may '
+                                      'differ from its update range)' % (opt[0],))
+        self.asr, self.sae = asr_model, sae_model
+        self.asr_flat = FlatParameters.of(asr_model)
+        self.sae_flat = FlatParameters.of(sae_model)
+        self.lo, self.hi = self.asr_flat.range_of(list(asr_model.encoder.parameters()))
+        sdist.broadcast_flat(self.sae_flat.data)
+        sdist.broadcast_flat(self.asr_flat.data)
+        self.optim = FusedAdam([(self.sae_flat.data, self.sae_flat.grad, True),
+                                (self.asr_flat.data[self.lo:self.hi], self.asr_flat.grad[self.lo:self.hi], False)],
+                               lr=opt[1], eps=1e-8)
+        self.grad_clip = grad_clip
+        self._one = torch.ones((), device=self.sae_flat.data.device)
+        self.last_pred = None          # [B, 8 T', F] of the most recent step (for the trainer's figures)
+        self.last_done = None
+        self.skipped_steps = 0
+
+    def forward_loss(self, x, x_lens):
+        from .seed_ops import sae_loss
+        listener_out, _ = self.asr.encoder(x, x_lens)
+        pred = self.sae(x, listener_out)
+        return sae_loss(pred, x, max(x_lens)), pred
+
+    def __call__(self, x, x_lens):
+        """x [B, T, F] padded fbanks on the GPU (T: the corpus' padding, >= max(x_lens)), x_lens host list
+        (descending).  Returns the loss tensor."""
+        self._note(self.optim.poll())
+        ops.set_wgrad_listener(None)
+        for flat in (self.sae_flat, self.asr_flat):
+            if not flat.clean:
+                flat.zero_grad()
+        self.sae_flat.clean = self.asr_flat.clean = False
+        with ops.shared_status_row(self.optim.status_row):
+            loss, self.last_pred = self.forward_loss(x, x_lens)
+            loss.backward(self._one)
+        scale = sdist.allreduce_grad(self.sae_flat.grad)
+        sdist.allreduce_grad(self.asr_flat.grad[self.lo:self.hi])
+        self.optim.clip_and_step(self.grad_clip, grad_scale=scale, zero_grad=True)
+        self.sae_flat.clean = self.asr_flat.clean = True      # (nothing behind the Listener was touched)
+        return loss
+
+    _note = ASRTrainStep._note
+    finish = ASRTrainStep.finish

@@ -623,6 +623,115 @@ class ADVTrainer(Solver):
             torch.save(self.asr_model.state_dict(), self.asrpath_out)
 
 
+class SAETrainer(Solver):
+    """Trains the speech autoencoder and, through it, the ASR model's Listener on audio alone
+    (src/trainer.py:760-907; config 5's third leg).  With Adam (conf/default.yaml:24-26) one iteration of
+    exec() is ONE engine.SAETrainStep call; other optimizer types raise.  The spectrogram figures of valid()
+    (:871-887, matplotlib + librosa's specshow) are logged as the pair of arrays they would draw."""
+
+    def __init__(self, config, paras):
+        super().__init__(config, paras, 'sae')
+
+    def load_data(self):
+        n_jobs = self.set_if_exists('loader_jobs', 8)
+        (self.mapper, _, self.train_set) = load_asr_dataset(
+            self.config['sae']['train_index'], batch_size=self.train_batch_size, use_gpu=self.paras.gpu, n_jobs=n_jobs)
+        (_, _, self.valid_set) = load_asr_dataset(
+            self.config['sae']['valid_index'], batch_size=self.valid_batch_size, use_gpu=self.paras.gpu, n_jobs=n_jobs)
+
+    def set_model(self, asrpath=None, asr_model=None):
+        """src/trainer.py:774-796.  asr_model (this build): an ASR object already in memory."""
+        from .engine import SAETrainStep
+        from .speech_autoencoder import SpeechAutoEncoder
+        (self.asrpath_in, self.asrpath_out) = self.genpath(asrpath, 'asr')
+        self.asr_model = asr_model if asr_model is not None else self.setup_module(
+            ASR, self.asrpath_in, self.mapper.get_dim(), **self.config['asr']['mdl'])
+        self.speech_autoenc = self.setup_module(SpeechAutoEncoder, self.ckppath, self.asr_model.encoder.out_dim,
+                                                self.config['asr']['mdl']['feature_dim'], **self.config['sae']['mdl'])
+        opt = self.config['sae']['opt']
+        self.train_step = SAETrainStep(self.asr_model, self.speech_autoenc, opt=(opt['type'], opt['learning_rate']),
+                                       grad_clip=5.0)
+        self.optim = self.train_step.optim
+
+    def _rank_batches(self):
+        from .gpu_loader import rank_batches
+        mine = set(rank_batches(len(self.train_set), self.rank, self.world))
+        for b_ind, (x, y) in enumerate(self.train_set):
+            if b_ind in mine:
+                yield b_ind, x
+
+    def exec(self):
+        self.verbose('Training set total {} batches.'.format(len(self.train_set)))
+        nan_reported = self.train_step.skipped_steps
+        epoch = 0
+        while epoch < self.n_epochs:
+            self.verbose("Starting epoch {} out of {}".format(epoch + 1, self.n_epochs))
+            for b_ind, x in self._rank_batches():
+                self.verbose('Batch: {}/{}, global step: {}'.format(b_ind, len(self.train_set), self.tr.step),
+                             progress=True)
+                x, x_lens = prepare_x(x, device=self.device)
+                loss = self.train_step(x, x_lens)
+                if self.train_step.skipped_steps > nan_reported:
+                    nan_reported = self.train_step.skipped_steps
+                    self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+                if self.rank == 0 and self.tr.step % self.logging_step == 0:
+                    self.lg.scalar('train_loss', loss.item(), self.tr.step)
+                if self.tr.step % self.valid_step == 0:
+                    self.valid()
+                if self.rank == 0 and self.tr.step % self.save_step == 0:
+                    self.train_step.finish()           # never checkpoint after a time-out
+                    self.verbose("Model saved at step {}".format(self.tr.step))
+                    torch.save(self.speech_autoenc.state_dict(), self.ckppath)
+                    torch.save(self.asr_model.state_dict(), self.asrpath_out)
+                self.tr.do_step()
+            epoch += 1
+        self.train_step.finish()
+
+    def valid(self):
+        """src/trainer.py:840-897: the eval-mode loss (running batch-norm statistics) averaged over the
+        validation batches; the last batch's utterances against their reconstructions go to the figure log."""
+        self.speech_autoenc.eval()
+        self.asr_model.eval()
+        total, n_batches = 0.0, 0
+        x = x_lens = pred = None
+        with torch.no_grad():
+            for b_idx, (x, y) in enumerate(self.valid_set):
+                self.verbose('Validation step - {} ( {} / {} )'.format(self.tr.step, b_idx, len(self.valid_set)),
+                             progress=True)
+                x, x_lens = prepare_x(x, device=self.device)
+                loss, pred = self.train_step.forward_loss(x, x_lens)
+                total += float(loss)
+                n_batches += 1
+        ops.check_persistent_status()
+        self.speech_autoenc.train()
+        self.asr_model.train()
+        if n_batches == 0 or self.rank != 0:
+            return
+        batch_t = max(x_lens)
+        enc_final = torch.zeros(pred.shape[0], batch_t, pred.shape[2])
+        enc_final[:, :pred.shape[1], :] = pred.cpu()
+        for i in range(min(self.valid_batch_size, x.shape[0])):
+            label_img = x[i, :x_lens[i], :].cpu().permute(1, 0)
+            predict_img = enc_final[i, :x_lens[i], :].permute(1, 0)
+            self.lg.figure('encode_compare_' + str(i), [label_img.numpy(), predict_img.numpy()], self.tr.step)
+        avg_loss = total / n_batches
+        self.lg.scalar('eval_loss', avg_loss, self.tr.step)
+        if avg_loss < self.tr.get_best():
+            self.tr.set_best(avg_loss)
+            self.verbose('Best validation loss : {:.4f} @ global step {}'.format(self.tr.get_best(), self.tr.step))
+            torch.save(self.speech_autoenc.state_dict(), self.best_ckppath)
+        else:
+            self.verbose("Validation metric worse : ({:.4f} vs. {:.4f})".format(avg_loss, self.tr.get_best()))
+
+    def close(self):
+        self.verbose("Finished training! The most recent model will" +
+                     "be saved at step {} as well as the ASR model".format(self.tr.step))
+        self.train_step.finish()
+        if self.rank == 0:
+            torch.save(self.speech_autoenc.state_dict(), self.ckppath)
+            torch.save(self.asr_model.state_dict(), self.asrpath_out)
+
+
 def asr_seed_train(config, paras):
     """The Seed loop, src/trainer.py:1126-1177 (`train.py Seed`): `seed_train.its` super-iterations in which
     several trainers take turns on ONE ASR model, handed from leg to leg through the checkpoint chain

@@ -55,3 +55,157 @@ def test_bce_matches_torch(n, target):
     got.backward()
     assert abs(float(got) - float(want)) < 1e-5 * max(1.0, abs(float(want)))
     np.testing.assert_allclose(pg.grad.cpu().numpy(), pr.grad.numpy(), rtol=2e-5, atol=1e-9)
+
+
+# ------------------------------------------------------------------ SAE: the speech autoencoder's kernels ----
+def _lib_call():
+    import ctypes as C
+    from ss_asr_amd import _lib
+    lib = _lib.load()
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return lib, p, st
+
+
+@pytest.mark.parametrize('B,T,W,C,F,kh,kw', [
+    (3, 40, 20, 1, 8, 1, 7),        # one kernel row over mel, C = 1: in place, unaligned windows (conv_1 of the yaml)
+    (2, 30, 9, 32, 16, 5, 1),       # kernel rows as K segments, kw * C = 32 (conv_2)
+    (2, 12, 9, 64, 24, 3, 1),       # kw * C = 64 (conv_3)
+    (2, 25, 11, 1, 6, 7, 1),        # kernel over time with C = 1: im2col path (the class docstring's conv_1)
+    (2, 14, 12, 6, 10, 1, 3),       # one kernel row, K = 18
+    (2, 10, 8, 12, 20, 2, 2),       # both axes, kw * C = 24: im2col path
+    (2, 16, 10, 16, 8, 3, 2),       # both axes, kw * C = 32: in place
+])
+def test_conv2d_matches_torch(B, T, W, C, F, kh, kw):
+    """ssasr_conv2d_fwd / _bwd (channels-last; the overlapping windows read in place or through im2col) against
+    torch.nn.functional.conv2d in float64: output, weight gradient (accumulated into a non-zero buffer), input
+    gradient from the zero-bordered output gradient."""
+    lib, p, st = _lib_call()
+    g = torch.Generator().manual_seed(B * T + C * kh)
+    x = torch.randn(B, T, W, C, generator=g)
+    w = torch.randn(F, C, kh, kw, generator=g) / (C * kh * kw) ** 0.5
+    To, Wo = T - kh + 1, W - kw + 1
+    dy = torch.randn(B, To, Wo, F, generator=g)
+    xr, wr = x.permute(0, 3, 1, 2).double().requires_grad_(), w.double().requires_grad_()
+    yr = F_conv(xr, wr)
+    yr.backward(dy.permute(0, 3, 1, 2).double())
+    xg, wg = x.cuda(), w.cuda()
+    ws = torch.empty(max(int(lib.ssasr_conv2d_ws_floats(B, T, W, C, F, kh, kw)), 4), device='cuda')
+    y = torch.empty(B, To, Wo, F, device='cuda')
+    assert lib.ssasr_conv2d_fwd(p(xg), p(wg), p(y), B, T, W, C, F, kh, kw, p(ws), st()) == 0
+    want = yr.detach().permute(0, 2, 3, 1)
+    assert float((y.cpu().double() - want).abs().max()) < 3e-6 * max(1.0, float(want.abs().max()))
+    # backward: dense dy for the weight gradient alone, bordered dy for both
+    dw0 = torch.randn(F, C, kh, kw, generator=g)
+    dw = dw0.cuda()
+    assert lib.ssasr_conv2d_bwd(p(dy.cuda()), 0, p(xg), p(wg), None, p(dw), B, T, W, C, F, kh, kw, p(ws), st()) == 0
+    tol_w = 3e-6 * max(1.0, float(wr.grad.abs().max())) * max(1.0, (B * To * Wo) ** 0.5 / 8)
+    assert float((dw.cpu().double() - dw0.double() - wr.grad).abs().max()) < tol_w
+    dyb = torch.zeros(B, To + 2 * (kh - 1), Wo + 2 * (kw - 1), F)
+    dyb[:, kh - 1:kh - 1 + To, kw - 1:kw - 1 + Wo] = dy
+    dx = torch.empty(B, T, W, C, device='cuda')
+    dw2 = torch.zeros(F, C, kh, kw, device='cuda')
+    rc = lib.ssasr_conv2d_bwd(p(dyb.cuda()), 1, p(xg), p(wg), p(dx), p(dw2), B, T, W, C, F, kh, kw, p(ws), st())
+    in_place = kh == 1 or (kw * C) % 32 == 0
+    if not in_place:
+        assert rc != 0          # (documented: the im2col weight gradient reads a dense dy)
+        assert lib.ssasr_conv2d_bwd(p(dyb.cuda()), 1, p(xg), p(wg), p(dx), None, B, T, W, C, F, kh, kw, p(ws), st()) == 0
+    else:
+        assert rc == 0
+        assert float((dw2.cpu().double() - wr.grad).abs().max()) < tol_w
+    want_dx = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx.cpu().double() - want_dx).abs().max()) < 3e-6 * max(1.0, float(want_dx.abs().max()))
+
+
+def F_conv(x, w):
+    return F.conv2d(x, w)
+
+
+@pytest.mark.parametrize('B,T,W,C,ph,pw,border', [(3, 21, 9, 32, 3, 1, (4, 0)), (2, 13, 8, 64, 5, 1, (2, 0)),
+                                                  (4, 50, 45, 16, 50, 40, (0, 0)), (2, 9, 11, 20, 2, 3, (1, 2)),
+                                                  (2, 70, 40, 256, 64, 33, (2, 0)), (3, 7, 5, 6, 1, 1, (0, 0))])
+def test_batch_norm_relu_pool_matches_torch(B, T, W, C, ph, pw, border):
+    """ssasr_bn_stats + ssasr_bn_relu_pool_fwd / _bwd against BatchNorm2d (training mode) -> ReLU -> MaxPool2d in
+    float64: pooled output, running statistics, gradient of the convolution output (inside a zero border),
+    dgamma / dbeta (accumulated); then eval mode against the running statistics."""
+    lib, p, st = _lib_call()
+    g = torch.Generator().manual_seed(T * W + C)
+    y = torch.randn(B, T, W, C, generator=g) * 1.5 + 0.3
+    gamma, beta = 1.0 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    rm0, rv0 = 0.1 * torch.randn(C, generator=g), 1.0 + 0.1 * torch.rand(C, generator=g)
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+    yr = y.permute(0, 3, 1, 2).double().requires_grad_()
+    pr = F.max_pool2d(torch.relu(bn(yr)), (ph, pw))
+    dp = torch.randn(B, T // ph, W // pw, C, generator=g)
+    pr.backward(dp.permute(0, 3, 1, 2).double())
+    yg, gam, bet, rm, rv = (t.cuda() for t in (y, gamma, beta, rm0.clone(), rv0.clone()))
+    ws = torch.empty(int(lib.ssasr_bn_ws_floats(C)), device='cuda')
+    save = torch.empty(4 * C, device='cuda')
+    assert lib.ssasr_bn_stats(p(yg), B * T * W, C, p(gam), p(bet), p(rm), p(rv), 0.1, 1e-5, 1, p(ws), p(save), st()) == 0
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), atol=2e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=3e-6)
+    To, Wo = T // ph, W // pw
+    pg = torch.empty(B, To, Wo, C, device='cuda')
+    idx = torch.empty(B, To, Wo, C, device='cuda', dtype=torch.int32)
+    assert lib.ssasr_bn_relu_pool_fwd(p(yg), p(save), B, T, W, C, ph, pw, p(pg), p(idx), st()) == 0
+    want = pr.detach().permute(0, 2, 3, 1)
+    assert float((pg.cpu().double() - want).abs().max()) < 3e-6 * max(1.0, float(want.abs().max()))
+    bt, bw = border
+    dy = torch.full((B, T + 2 * bt, W + 2 * bw, C), float('nan'), device='cuda')
+    dg0, db0 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dg, db = dg0.cuda(), db0.cuda()
+    assert lib.ssasr_bn_relu_pool_bwd(p(dp.cuda()), p(pg), p(idx), p(yg), p(save), p(gam), B, T, W, C, ph, pw, bt, bw, p(dy),
+                                      p(dg), p(db), p(ws), st()) == 0
+    dy = dy.cpu()
+    want_dy = yr.grad.permute(0, 2, 3, 1)
+    scale = max(1.0, float(want_dy.abs().max()))
+    assert float((dy[:, bt:bt + T, bw:bw + W].double() - want_dy).abs().max()) < 5e-6 * scale
+    inner = torch.zeros_like(dy, dtype=torch.bool)
+    inner[:, bt:bt + T, bw:bw + W] = True
+    assert float(dy[~inner].abs().sum()) == 0.0 if (bt or bw) else True
+    n_terms = max(1.0, (B * To * Wo) ** 0.5 / 8)
+    assert float((dg.cpu().double() - dg0.double() - bn.weight.grad).abs().max()) < 5e-6 * n_terms * max(1.0, float(bn.weight.grad.abs().max()))
+    assert float((db.cpu().double() - db0.double() - bn.bias.grad).abs().max()) < 5e-6 * n_terms * max(1.0, float(bn.bias.grad.abs().max()))
+    # eval mode: the running statistics (left untouched)
+    bn.eval()
+    pe = F.max_pool2d(torch.relu(bn(y.permute(0, 3, 1, 2).double())), (ph, pw)).permute(0, 2, 3, 1)
+    rm1, rv1 = rm.clone(), rv.clone()
+    assert lib.ssasr_bn_stats(p(yg), B * T * W, C, p(gam), p(bet), p(rm), p(rv), 0.1, 1e-5, 0, p(ws), p(save), st()) == 0
+    assert lib.ssasr_bn_relu_pool_fwd(p(yg), p(save), B, T, W, C, ph, pw, p(pg), p(idx), st()) == 0
+    assert torch.equal(rm, rm1) and torch.equal(rv, rv1)
+    assert float((pg.cpu().double() - pe.detach()).abs().max()) < 3e-6 * max(1.0, float(pe.abs().max()))
+
+
+def test_frame_decoder_input_and_smooth_l1_match_torch():
+    """ssasr_sae_concat_* and ssasr_smooth_l1_* against torch: [listener frame | global encoding] rows with the
+    broadcast's sum in backward; the loss of src/trainer.py:811-818 with its zero padding up to batch_t (R < bt:
+    the padded rows count in the mean and pass no gradient), both branches of the Huber law."""
+    from ss_asr_amd import seed_ops
+    g = torch.Generator().manual_seed(5)
+    B, Tq, L, G, Fd = 3, 7, 24, 10, 6
+    lis, enc = torch.randn(B, Tq, L, generator=g), torch.randn(B, G, generator=g)
+    lr, er = lis.double().requires_grad_(), enc.double().requires_grad_()
+    dr = torch.cat((lr, er.unsqueeze(1).expand(-1, Tq, -1)), dim=2)
+    up = torch.randn(B, Tq, L + G, generator=g)
+    dr.backward(up.double())
+    lg, eg = lis.cuda().requires_grad_(), enc.cuda().requires_grad_()
+    dg = seed_ops.sae_concat(lg, eg)
+    dg.backward(up.cuda())
+    assert torch.equal(dg.detach().cpu(), dr.detach().float())
+    assert torch.equal(lg.grad.cpu(), lr.grad.float())
+    np.testing.assert_allclose(eg.grad.cpu().numpy(), er.grad.numpy(), atol=2e-6)
+    R, bt, Tx = 8 * Tq, 8 * Tq + 5, 8 * Tq + 9
+    pred = 2.0 * torch.randn(B, R, Fd, generator=g)
+    x = torch.randn(B, Tx, Fd, generator=g)
+    prr = pred.double().requires_grad_()
+    full = torch.zeros(B, bt, Fd, dtype=torch.float64)
+    full[:, :R] = prr
+    want = F.smooth_l1_loss(full, x[:, :bt].double())
+    (3.0 * want).backward()
+    pg = pred.cuda().requires_grad_()
+    got = seed_ops.sae_loss(pg, x.cuda(), bt)
+    (3.0 * got).backward()
+    assert abs(float(got) - float(want)) < 2e-6 * max(1.0, float(want))
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), prr.grad.numpy(), rtol=1e-5, atol=1e-9)

@@ -446,3 +446,57 @@ def test_adv_train_steps_follow_the_reference_trajectory(golden, name):
     # (Adam at lr 1e-3 moves a weight by ~3e-3 over the three iterations, and where a gradient is of the order of
     # Adam's eps the step is as sensitive as m / sqrt(v): measured 2.9e-6; Adadelta: 1.7e-8)
     _final_weights_check(fx, w0, w1, atol=1e-5 if 'adam' in name else 1e-6)
+
+
+# ------------------------------------------------- config 5: the SAE leg ----
+def _sae_models(fx):
+    from ss_asr_amd.asr import ASR
+    from ss_asr_amd.speech_autoencoder import SpeechAutoEncoder
+    dims = [int(v) for v in fx['dims']]
+    torch.manual_seed(0)
+    asr = ASR(*dims, 1.0)
+    lo.seeded_weights(asr, int(fx['asr_weights_seed']))
+    sae = SpeechAutoEncoder(2 * dims[1], dims[4], [list(map(int, k)) for k in fx['kernel_sizes']],
+                            [int(v) for v in fx['num_filters']], [list(map(int, k)) for k in fx['pool_kernel_sizes']])
+    lo.seeded_generic_weights(sae, int(fx['sae_weights_seed']))
+    return asr.to('cuda:0'), sae.to('cuda:0'), dims
+
+
+@pytest.mark.parametrize('name', ['sae_traj_full_b8', 'sae_traj_small'])
+def test_sae_train_steps_follow_the_reference_trajectory(golden, name):
+    """Config 5's third leg (SAETrainer, src/trainer.py:760-907): three engine.SAETrainStep iterations against the
+    trajectory captured from the reference's SpeechAutoEncoder + Listener classes: loss and clipped norm (the
+    speech autoencoder's alone) of every iteration, per-tensor norms of the total update, final weights AND
+    batch-norm buffers of both models, an eval-mode prediction (running statistics); the full-size case with the
+    yaml's kernels and filters (windows read in place), the small one with the docstring's orientation
+    (im2col path, odd filter counts).  Everything behind the Listener must come out untouched."""
+    from ss_asr_amd.engine import SAETrainStep
+    from ss_asr_amd.synthetic import make_batch
+    fx = golden(name)
+    asr, sae, dims = _sae_models(fx)
+    state = lambda: {**{('sae.' + k): v.detach().cpu().clone().float() for k, v in sae.state_dict().items()},
+                     **{('asr.' + k): v.detach().cpu().clone() for k, v in asr.state_dict().items()}}
+    w0 = state()
+    step = SAETrainStep(asr, sae, opt=(str(fx['opt'][0]), float(fx['opt'][1])))
+    for r in range(int(fx['rounds'])):
+        lens = [int(v) for v in fx['lens%d' % r]]
+        x, _, _ = make_batch(fx['lens%d' % r], np.full(len(lens), 3), dims[4], int(fx['batch_seed%d' % r]), pad_to=int(fx['pad_to']))
+        x = x.cuda()
+        loss = float(step(x, lens))
+        norm, skipped = step.finish()
+        assert not skipped
+        print('sae step %d: loss %.6f (reference %.6f), norm %.6f (%.6f)' % (r, loss, fx['loss'][r], norm, fx['norm'][r]))
+        assert abs(loss - float(fx['loss'][r])) < 1e-5
+        assert abs(norm - float(fx['norm'][r])) < 5e-5 * max(1.0, norm)
+        if r == 0:
+            with torch.no_grad():
+                sae.eval()
+                _, pred = step.forward_loss(x, lens)
+                sae.train()
+            np.testing.assert_allclose(pred.reshape(-1)[:512].cpu().numpy(), fx['eval_pred_head'], atol=2e-5, rtol=0)
+    w1 = state()
+    for k in w1:
+        if k.startswith('asr.') and not k.startswith('asr.encoder.'):
+            assert torch.equal(w1[k], w0[k]), k
+    assert int(sae.encoder.conv_1[1].num_batches_tracked) == int(fx['rounds'])
+    _final_weights_check(fx, w0, w1, atol=1e-5 if float(fx['opt'][1]) > 5e-4 else 1e-6)
