@@ -422,21 +422,22 @@ extern "C" int ssasr_conv2d_bwd(const float* dy, int dy_bordered, const float* x
       }
       hipLaunchKernelGGL(conv_dw_fold_kernel, dim3(stream_grid(n_w, 1)), dim3(256), 0, st, dwl, dw, (int)F, (int)C, ikh, ikw, 0);
     } else {
-      if (dy_bordered) return SSASR_EARG;          // (the im2col form reads dy as one dense [rows][F] matrix)
+      // im2col form: dK[f][(i, j, c)] += sum over an utterance's pixels of dy[f] * col[(i, j, c)], utterances as the batch axis
       const int64_t K = kh * kw * C, rows = B * To * Wo;
       if (rows > 0x7fffffff) return SSASR_EARG;
       hipLaunchKernelGGL(im2col_kernel, dim3(stream_grid(rows * K)), dim3(256), 0, st, x, col, B, T, W, (int)C, ikh, ikw);
       SSASR_LAUNCH_CHECK();
       GemmDesc g{};
-      g.A = dy; g.ta = 1; g.ma = rm_dense(F);
+      g.A = dy_in; g.ta = 1; g.ma = RowMap{0, Wo, Wp * F, F};
       g.B = col; g.tb = 1; g.mb = rm_dense(K);
       g.C = dwl; g.mc = rm_dense(K);
-      g.M = (int)F; g.N = (int)K; g.K = (int)rows;
-      g.alpha = 1.f; g.beta = 1.f; g.batch = 1;
+      g.M = (int)F; g.N = (int)K; g.K = (int)(To * Wo);
+      g.alpha = 1.f; g.beta = 1.f;
+      g.batch = (int)B; g.sa = Tp * Wp * F; g.sb = To * Wo * K; g.sc = 0;
       const int64_t tiles = ((F + 63) / 64) * ((K + 63) / 64);
-      int64_t s = (512 + tiles - 1) / tiles, smax = rows / 256;
+      int64_t s = (512 + tiles * B - 1) / (tiles * B), smax = (To * Wo) / 256;
       if (s > smax) s = smax;
-      g.splitk = (int)(s < 1 ? 1 : s);
+      g.splitk = (int)(s < 2 ? 2 : s);                                 // (>= 2: the batch entries share C)
       if ((rc = ssasr_launch_gemm(g, st))) return rc;
       hipLaunchKernelGGL(conv_dw_fold_kernel, dim3(stream_grid(n_w, 1)), dim3(256), 0, st, dwl, dw, (int)F, (int)C, ikh, ikw, 2);
     }

@@ -106,13 +106,8 @@ def test_conv2d_matches_torch(B, T, W, C, F, kh, kw):
     dx = torch.empty(B, T, W, C, device='cuda')
     dw2 = torch.zeros(F, C, kh, kw, device='cuda')
     rc = lib.ssasr_conv2d_bwd(p(dyb.cuda()), 1, p(xg), p(wg), p(dx), p(dw2), B, T, W, C, F, kh, kw, p(ws), st())
-    in_place = kh == 1 or (kw * C) % 32 == 0
-    if not in_place:
-        assert rc != 0          # (documented: the im2col weight gradient reads a dense dy)
-        assert lib.ssasr_conv2d_bwd(p(dyb.cuda()), 1, p(xg), p(wg), p(dx), None, B, T, W, C, F, kh, kw, p(ws), st()) == 0
-    else:
-        assert rc == 0
-        assert float((dw2.cpu().double() - wr.grad).abs().max()) < tol_w
+    assert rc == 0
+    assert float((dw2.cpu().double() - wr.grad).abs().max()) < tol_w
     want_dx = xr.grad.permute(0, 2, 3, 1)
     assert float((dx.cpu().double() - want_dx).abs().max()) < 3e-6 * max(1.0, float(want_dx.abs().max()))
 
