@@ -500,3 +500,44 @@ def test_sae_train_steps_follow_the_reference_trajectory(golden, name):
             assert torch.equal(w1[k], w0[k]), k
     assert int(sae.encoder.conv_1[1].num_batches_tracked) == int(fx['rounds'])
     _final_weights_check(fx, w0, w1, atol=1e-5 if float(fx['opt'][1]) > 5e-4 else 1e-6)
+
+
+@pytest.mark.parametrize('name', ['sae_traj_full_b8', 'sae_traj_small'])
+def test_sae_gradients_match_the_oracle_tensor_by_tensor(golden, name):
+    """One forward / backward of the SAE leg on the fixture's first batch: EVERY gradient tensor of the speech
+    autoencoder and of the Listener against the CPU oracle's (float64 of the same modules), by norm of the
+    difference relative to the tensor's norm."""
+    from ss_asr_amd import seed_ops
+    from ss_asr_amd.synthetic import make_batch
+    fx = golden(name)
+    asr, sae, dims = _sae_models(fx)
+    ref_asr = lo.OracleASR(*dims, 1.0)
+    lo.seeded_weights(ref_asr, int(fx['asr_weights_seed']))
+    ref_sae = lo.OracleSpeechAutoEncoder(2 * dims[1], dims[4], [list(map(int, k)) for k in fx['kernel_sizes']],
+                                         [int(v) for v in fx['num_filters']], [list(map(int, k)) for k in fx['pool_kernel_sizes']])
+    lo.seeded_generic_weights(ref_sae, int(fx['sae_weights_seed']))
+    ref_asr, ref_sae = ref_asr.double(), ref_sae.double()
+    lens = [int(v) for v in fx['lens0']]
+    x, _, _ = make_batch(fx['lens0'], np.full(len(lens), 3), dims[4], int(fx['batch_seed0']), pad_to=int(fx['pad_to']))
+    lis, _ = ref_asr.encoder(x.double(), lens)
+    pred = ref_sae(x.double(), lis)
+    full = torch.zeros(pred.shape[0], max(lens), pred.shape[2], dtype=torch.float64)
+    full[:, :pred.shape[1]] = pred
+    torch.nn.functional.smooth_l1_loss(full, x[:, :max(lens)].double()).backward()
+    xg = x.cuda()
+    lis_g, _ = asr.encoder(xg, lens)
+    seed_ops.sae_loss(sae(xg, lis_g), xg, max(lens)).backward()
+    torch.cuda.synchronize()
+    worst = []
+    for tag, got_m, ref_m in (('sae.', sae, ref_sae), ('asr.', asr, ref_asr)):
+        ref_g = dict(ref_m.named_parameters())
+        for k, p in got_m.named_parameters():
+            if tag == 'asr.' and not k.startswith('encoder.'):
+                continue
+            want = ref_g[k].grad
+            err = float((p.grad.detach().cpu().double() - want).norm()) / max(float(want.norm()), 1e-30)
+            worst.append((err, tag + k, float(want.norm())))
+    worst.sort(reverse=True)
+    for err, k, nrm in worst[:8]:
+        print('%-48s rel err %.3g (norm %.3g)' % (k, err, nrm))
+    assert worst[0][0] < 2e-5, worst[:3]
