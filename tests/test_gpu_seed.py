@@ -170,7 +170,7 @@ def test_batch_norm_relu_pool_matches_torch(B, T, W, C, ph, pw, border):
     assert lib.ssasr_bn_stats(p(yg), B * T * W, C, p(gam), p(bet), p(rm), p(rv), 0.1, 1e-5, 0, p(ws), p(save), st()) == 0
     assert lib.ssasr_bn_relu_pool_fwd(p(yg), p(save), B, T, W, C, ph, pw, p(pg), p(idx), st()) == 0
     assert torch.equal(rm, rm1) and torch.equal(rv, rv1)
-    assert float((pg.cpu().double() - pe.detach()).abs().max()) < 3e-6 * max(1.0, float(pe.abs().max()))
+    assert float((pg.cpu().double() - pe.detach()).abs().max()) < 3e-6 * max(1.0, float(pe.detach().abs().max()))
 
 
 def test_frame_decoder_input_and_smooth_l1_match_torch():

@@ -499,7 +499,10 @@ def test_sae_train_steps_follow_the_reference_trajectory(golden, name):
         if k.startswith('asr.') and not k.startswith('asr.encoder.'):
             assert torch.equal(w1[k], w0[k]), k
     assert int(sae.encoder.conv_1[1].num_batches_tracked) == int(fx['rounds'])
-    _final_weights_check(fx, w0, w1, atol=1e-5 if float(fx['opt'][1]) > 5e-4 else 1e-6)
+    # (Adam: a weight moves by ~lr per step; measured 1.3e-6 at lr 1e-4 and 1.7e-6 at lr 1e-3.  The norms above sit
+    # 2.2e-5 from the fixture at full size because the reference's float32 run does: against the float64 oracle this
+    # build's gradients agree to 4.5e-6 per tensor, test_sae_gradients_match_the_oracle_tensor_by_tensor)
+    _final_weights_check(fx, w0, w1, atol=1e-5 if float(fx['opt'][1]) > 5e-4 else 3e-6)
 
 
 @pytest.mark.parametrize('name', ['sae_traj_full_b8', 'sae_traj_small'])
@@ -541,3 +544,9 @@ def test_sae_gradients_match_the_oracle_tensor_by_tensor(golden, name):
     for err, k, nrm in worst[:8]:
         print('%-48s rel err %.3g (norm %.3g)' % (k, err, nrm))
     assert worst[0][0] < 2e-5, worst[:3]
+    # the norm Solver.step clips (the speech autoencoder's): this build against the float64 oracle, and the
+    # reference's own float32 run (the fixture) against it -- at full size the latter is the larger distance
+    n64 = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in ref_sae.parameters())))
+    ngpu = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in sae.parameters())))
+    print('clipped norm: float64 oracle %.7f, this build %.7f, reference float32 %.7f' % (n64, ngpu, float(fx['norm'][0])))
+    assert abs(ngpu - n64) < 3e-6 * n64
