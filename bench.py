@@ -455,21 +455,33 @@ def config4_bench(device, steps=4, warmup=2, batch=32):
 
 
 def config5_bench(device, steps=20, warmup=3, batch=32):
-    """BASELINE.json configs[4]'s legs that are in scope (src/trainer.py:594-758, :1126-1177): the
-    text-autoencoder train step (engine.TAETrainStep: TextAutoEncoder forward through the shared attend-and-spell
-    loop, TAETrainer's loss, backward, clip over the text autoencoder, Adam over it and the ASR model's decoder half)
-    on synthetic label rows of the corpus' lengths with TAETrainer's noise model (characters dropped with
-    probability 0.1), alone and alternating with the supervised ASR step on the SAME ASR object.  rows/s = label
-    rows (utterance transcripts) per second."""
+    """BASELINE.json configs[4], the Seed loop's three legs on ONE ASR object (src/trainer.py:594-1177),
+    each as the step object its trainer runs, on the corpus' batches (32 utterances, <= 800 frames, padded to 800 as
+    the reference's dataset pads to the corpus maximum):
+      tae  engine.TAETrainStep: text autoencoder through the shared attend-and-spell loop, TAETrainer's noise model
+           (characters dropped with probability 0.1), Adam over it and the ASR decoder half;
+      adv  engine.ADVTrainStep: discriminator on text-encoder frames (labels 0.9) and Listener frames (0), Adadelta;
+           then the Listener as generator through the updated discriminator, Adadelta (conf/default.yaml:62-71);
+      sae  engine.SAETrainStep: Listener, global speech encoder (conv / batch norm / pool x 3, conf/default.yaml:27-30
+           with the last pooling window fitted to 800 frames, [50, 40]), frame decoder, smooth L1, Adam over both;
+    then one super-iteration's worth in the reference's order (tae, adv, sae), and the supervised ASR step + tae round
+    of earlier rounds.  rows/s = label rows (transcripts) or utterances per second."""
     from ss_asr_amd.asr import ASR
-    from ss_asr_amd.engine import ASRTrainStep, TAETrainStep, label_geometry
+    from ss_asr_amd.discriminator import Discriminator
+    from ss_asr_amd.engine import ADVTrainStep, ASRTrainStep, SAETrainStep, TAETrainStep, label_geometry
+    from ss_asr_amd.speech_autoencoder import SpeechAutoEncoder
     from ss_asr_amd.synthetic import config2_batches
     from ss_asr_amd.text_autoencoder import TextAutoEncoder
     random.seed(5); np.random.seed(5); torch.manual_seed(5)
     asr = ASR(**DIMS).to(device)
     tae = TextAutoEncoder(DIMS['output_dim'], emb_dim=128, state_size=DIMS['encoder_state_size'], num_layers=2).to(device)
+    disc = Discriminator(asr.encoder.get_outdim(), hidden_dim=256).to(device)
+    sae = SpeechAutoEncoder(asr.encoder.out_dim, DIMS['feature_dim'], [[1, 36], [5, 1], [3, 1]], [32, 64, 256],
+                            [[3, 1], [5, 1], [50, 40]]).to(device)
     asr_step = ASRTrainStep(asr, lr=1.0, eps=1e-8, grad_clip=5.0)
     tae_step = TAETrainStep(asr, tae, lr=1e-4, eps=1e-8, grad_clip=5.0)
+    adv_step = ADVTrainStep(asr, tae, disc, g_opt=('Adadelta', 1.0), d_opt=('Adadelta', 1.0), label_smoothing=0.1)
+    sae_step = SAETrainStep(asr, sae, opt=('Adam', 1e-4))
     rng = np.random.default_rng(5)
     data = []
     for x, y, lens in config2_batches(4, batch_size=batch, feat_dim=DIMS['feature_dim'], seed=1):
@@ -484,14 +496,29 @@ def config5_bench(device, steps=20, warmup=3, batch=32):
         yn = pad(noisy)
         y_lens = [int(v) + 1 for v in (y != 0).sum(-1)]
         n_lens = [int(v) + 1 for v in (yn != 0).sum(-1)]
-        data.append((x.to(device), y.to(device), lens, label_geometry(y)[1], yn.to(device), y_lens, n_lens))
+        x800 = torch.zeros(x.shape[0], 800, x.shape[2])
+        x800[:, :x.shape[1]] = x
+        data.append((x.to(device), y.to(device), lens, label_geometry(y)[1], yn.to(device), y_lens, n_lens, x800.to(device)))
 
     def tae_only(i):
-        x, y, lens, ans, yn, yl, nl = data[i % len(data)]
+        x, y, lens, ans, yn, yl, nl, _ = data[i % len(data)]
         return tae_step(y, yn, yl, nl)
 
+    def adv_only(i):
+        x, y, lens, ans, yn, yl, nl, _ = data[i % len(data)]
+        return adv_step(x, lens, y)[2]
+
+    def sae_only(i):
+        x, y, lens, ans, yn, yl, nl, x800 = data[i % len(data)]
+        return sae_step(x800, lens)
+
+    def seed_round(i):
+        tae_only(i)
+        adv_only(i)
+        return sae_only(i)
+
     def both(i):
-        x, y, lens, ans, yn, yl, nl = data[i % len(data)]
+        x, y, lens, ans, yn, yl, nl, _ = data[i % len(data)]
         asr_step(x, y, lens, ans)
         return tae_step(y, yn, yl, nl)
 
@@ -505,18 +532,25 @@ def config5_bench(device, steps=20, warmup=3, batch=32):
             loss = fn(warmup + i)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        tae_step.finish(); asr_step.finish()
+        for st in (tae_step, asr_step, adv_step, sae_step):
+            st.finish()
         return dt, float(loss)
 
     dt_t, loss_t = timed(tae_only)
+    dt_a, loss_a = timed(adv_only)
+    dt_s, loss_s = timed(sae_only)
+    dt_r, loss_r = timed(seed_round)
     dt_b, loss_b = timed(both)
-    return dict(workload='BASELINE.json configs[4], the legs in scope: TAETrainer step (text autoencoder 128 / 256 x 2 layers + the shared '
-                         'LAS attention / speller, Adam 1e-4) on %d label rows of %d-%d characters, drop rate 0.1; and alternating with the '
-                         'ASRTrainer step on the same ASR object' % (batch, min(min(d[5]) for d in data) - 2, max(max(d[5]) for d in data) - 2),
+    return dict(workload='BASELINE.json configs[4]: the Seed loop\'s legs as their step objects on one shared ASR object, %d utterances '
+                         '(<= 800 frames, label rows of %d-%d characters) per step; text autoencoder 128 / 256 x 2 layers, '
+                         'discriminator 512-256-256-1, speech autoencoder conv [1,36]x32 / [5,1]x64 / [3,1]x256'
+                         % (batch, min(min(d[5]) for d in data) - 2, max(max(d[5]) for d in data) - 2),
                 tae_step=dict(ms_per_step=round(dt_t * 1e3, 3), rows_per_sec=round(batch / dt_t, 1), final_loss=round(loss_t, 4)),
+                adv_step=dict(ms_per_step=round(dt_a * 1e3, 3), utt_per_sec=round(batch / dt_a, 1), final_g_loss=round(loss_a, 4)),
+                sae_step=dict(ms_per_step=round(dt_s * 1e3, 3), utt_per_sec=round(batch / dt_s, 1), final_loss=round(loss_s, 4)),
+                seed_round=dict(ms_per_round=round(dt_r * 1e3, 3), legs='tae, adv, sae', final_sae_loss=round(loss_r, 4)),
                 asr_plus_tae_round=dict(ms_per_round=round(dt_b * 1e3, 3), final_tae_loss=round(loss_b, 4)),
-                steps=steps, warmup=warmup,
-                note='SAETrainer / ADVTrainer (CNN autoencoder, discriminator) are out of scope: SURVEY.md 2 rows 15-16')
+                steps=steps, warmup=warmup)
 
 
 def cpu_baseline(batches):

@@ -1,7 +1,7 @@
 """Solver / ASRTrainer with the surface of the reference's src/trainer.py
-(Solver :33-195, ASRTrainer :374-545, TAETrainer :594-758, asr_seed_train :1126-1177) so that
-``src/train.py`` drives it unchanged: ``getattr(trainer, 'ASRTrainer')(config, paras)`` then
-``load_data()``, ``set_model()``, ``exec()``.
+(Solver :33-195, ASRTrainer :374-545, TAETrainer :594-758, SAETrainer :760-907, ADVTrainer :909-1124,
+asr_seed_train :1126-1177) so that ``src/train.py`` drives it unchanged:
+``getattr(trainer, 'ASRTrainer')(config, paras)`` then ``load_data()``, ``set_model()``, ``exec()``.
 
 Differences, all inside the same call surface:
   * the model computes through libssasr_hip.so (MI355X only);
@@ -732,31 +732,56 @@ class SAETrainer(Solver):
             torch.save(self.asr_model.state_dict(), self.asrpath_out)
 
 
+# src/train.py:19-20 offers the choice 'AdvTrainer' and resolves it with getattr(trainer, ...); the reference's
+# trainer.py only defines ADVTrainer -- here the CLI's spelling resolves
+AdvTrainer = ADVTrainer
+
+
 def asr_seed_train(config, paras):
-    """The Seed loop, src/trainer.py:1126-1177 (`train.py Seed`): `seed_train.its` super-iterations in which
-    several trainers take turns on ONE ASR model, handed from leg to leg through the checkpoint chain
-    asr_1.cpt -> ... under <ckpdir>/<name>/.  The reference's legs are TAETrainer -> ADVTrainer -> SAETrainer;
-    ADVTrainer's Discriminator and SAETrainer's SpeechAutoEncoder (CNN + batch norm) are outside this build's
-    scope, so the legs here are the two whose arithmetic runs on the kernels:
-    `seed_train.legs` (default ['tae', 'asr']) -- the text-autoencoder leg, which trains the shared attention /
-    speller, then the supervised ASRTrainer leg on the same checkpoint.  Naming 'adv' or 'sae' raises."""
+    """The Seed loop, src/trainer.py:1126-1177 (`train.py Seed`): super-iterations in which three trainers take
+    turns on ONE ASR model, handed from leg to leg through checkpoints under <ckpdir>/<name>/ exactly as the
+    reference chains them -- TAETrainer reads and writes asr_1.cpt (it trains the attention / speller half),
+    ADVTrainer reads asr_1.cpt and the text autoencoder's checkpoint and writes asr_2.cpt (it trains the Listener
+    against the text encoder), SAETrainer reads asr_2.cpt and writes asr_3.cpt (Listener again, through the speech
+    autoencoder).  The count of super-iterations is `seed_train.its` (the key :1146 reads) or, when the config
+    only has it, `seed_train.super_its` (the key conf/default.yaml:103-104 carries).
+
+    `seed_train.legs` (this build; default ['tae', 'adv', 'sae'], the reference's sequence) may also name 'asr':
+    a supervised ASRTrainer leg on the checkpoint the previous leg wrote."""
     ckpdir = os.path.join(paras.ckpdir, paras.name)
-    legs = config['seed_train'].get('legs', ['tae', 'asr'])
-    chain = os.path.join(ckpdir, 'asr_1.cpt')
-    for i in range(config['seed_train']['its']):
+    seed = config['seed_train']
+    its = seed['its'] if 'its' in seed else seed['super_its']
+    legs = seed.get('legs', ['tae', 'adv', 'sae'])
+    cpt = lambda k: os.path.join(ckpdir, 'asr_%d.cpt' % k)
+    for i in range(its):
         print('Starting Super Iteration {}'.format(i + 1))
+        tae_path, last = None, cpt(1)
         for leg in legs:
             if leg == 'tae':
                 print('Starting TAE training')
                 solver = TAETrainer(config, paras)
+                solver.load_data()
+                solver.set_model(asrpath=(cpt(1), cpt(1)))
+                tae_path, last = solver.ckppath, cpt(1)
+            elif leg == 'adv':
+                print('Starting ADV training')
+                solver = ADVTrainer(config, paras)
+                solver.load_data()
+                solver.set_model(taepath=tae_path, asrpath=(cpt(1), cpt(2)))
+                last = cpt(2)
+            elif leg == 'sae':
+                print('Starting SAE training')
+                solver = SAETrainer(config, paras)
+                solver.load_data()
+                solver.set_model(asrpath=(cpt(2), cpt(3)))
+                last = cpt(3)
             elif leg == 'asr':
                 print('Starting ASR training')
                 solver = ASRTrainer(config, paras)
+                solver.load_data()
+                solver.set_model(asrpath=(last, last))
             else:
-                raise NotImplementedError("seed_train leg %r: ADVTrainer / SAETrainer (Discriminator, SpeechAutoEncoder) "
-                                          "are out of this build's scope (SURVEY.md section 2 rows 15-16)" % (leg,))
-            solver.load_data()
-            solver.set_model(asrpath=(chain, chain))
+                raise ValueError("seed_train leg %r (known: 'tae', 'adv', 'sae', 'asr')" % (leg,))
             solver.exec()
             solver.close()
             del solver

@@ -550,3 +550,139 @@ def test_sae_gradients_match_the_oracle_tensor_by_tensor(golden, name):
     ngpu = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in sae.parameters())))
     print('clipped norm: float64 oracle %.7f, this build %.7f, reference float32 %.7f' % (n64, ngpu, float(fx['norm'][0])))
     assert abs(ngpu - n64) < 3e-6 * n64
+
+
+# ------------------------------------------------- config 5: the trainers of the ADV and SAE legs, the Seed loop ----
+def _seed_config(index, n_epochs=2):
+    conf = config_for(index)
+    conf['asr']['n_epochs'] = 1
+    common = {'train_index': index, 'valid_index': index, 'train_batch_size': 16, 'valid_batch_size': 16, 'n_epochs': n_epochs,
+              'logging_step': 1, 'save_step': 1, 'valid_step': 2, 'loader_jobs': 0}
+    conf['tae'] = dict(common, opt={'type': 'Adam', 'learning_rate': 0.0001},
+                       mdl={'state_size': 256, 'emb_dim': 128, 'num_layers': 2}, drop_rate=0.1)
+    conf['adv'] = dict(common, G_opt={'type': 'Adadelta', 'learning_rate': 1.0}, D_opt={'type': 'Adadelta', 'learning_rate': 1.0},
+                       mdl={'hidden_dim': 256}, label_smoothing=0.1)
+    # 32 frames: conv [1, 36] -> 32 x 45, pool [3, 1] -> 10, conv [5, 1] -> 6, pool [2, 1] -> 3, conv [3, 1] -> 1, pool [1, 40]
+    conf['sae'] = dict(common, opt={'type': 'Adam', 'learning_rate': 0.0001},
+                       mdl={'kernel_sizes': [[1, 36], [5, 1], [3, 1]], 'num_filters': [32, 64, 256],
+                            'pool_kernel_sizes': [[3, 1], [2, 1], [1, 40]]})
+    return conf
+
+
+def _paras(root, name):
+    return types.SimpleNamespace(name=name, logdir=os.path.join(root, 'runs'), ckpdir=os.path.join(root, 'result'),
+                                 verbose=False, seed=1)
+
+
+def _events(root, name, module):
+    return [json.loads(l) for l in open(os.path.join(root, 'runs', name, module, 'events.jsonl'))]
+
+
+def test_adv_trainer_end_to_end(tmp_path):
+    """ADVTrainer driven as src/train.py drives it (load_data -> set_model -> exec -> close) on a 16-utterance
+    index: the first iteration's three losses against the CPU oracle from the same initial weights and batch,
+    validation, both checkpoints, and an update that moved the Listener and the discriminator but nothing
+    behind the Listener."""
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_x, prepare_y
+    from ss_asr_amd.trainer import ADVTrainer
+    root = str(tmp_path)
+    index, _ = make_corpus(root, n=16, t_max=32, feat=80, seed=5)
+    conf = _seed_config(index)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = ADVTrainer(conf, _paras(root, 'adv1'))
+    tr.load_data()
+    tr.set_model()
+    asr0, tae0, d0 = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+                      for m in (tr.asr_model, tr.text_autoenc, tr.discriminator))
+    tr.exec()
+    tr.close()
+    ckpdir = os.path.join(root, 'result', 'adv1')
+    assert json.load(open(os.path.join(ckpdir, 'tracker.json')))['adv']['step'] == 2
+    for f in ('adv.cpt', 'adv_best.cpt', 'asr.cpt'):
+        assert os.path.isfile(os.path.join(ckpdir, f)), f
+    ev = _events(root, 'adv1', 'adv')
+    got = [[e['value'] for e in ev if e['key'] == 'adv_' + k][0] for k in
+           ('discrim_real_loss_train', 'discrim_fake_loss_train', 'gen_loss_train')]
+    assert any(e['key'] == 'adv_discrim_loss_eval' for e in ev) and any(e['kind'] == 'embedding' for e in ev)
+    _, _, loader = load_asr_dataset(index, batch_size=16, n_jobs=0)
+    x, y = next(iter(loader))
+    x, _ = prepare_x(x)
+    y, _ = prepare_y(y)
+    ref_asr = lo.OracleASR(50, 256, 256, 128, 80, 1.0)
+    ref_asr.load_state_dict(asr0)
+    ref_tae = lo.OracleTextAutoEncoder(50, 128, 256, 2)
+    ref_tae.load_state_dict(tae0)
+    ref_d = lo.OracleDiscriminator(512, 256)
+    ref_d.load_state_dict(d0)
+    G, D = lo.make_adv_optimizers(ref_asr, ref_d)
+    want = lo.adv_train_step(ref_asr, ref_tae.encoder, ref_d, G, D, x, y, 0.1)[:3]
+    np.testing.assert_allclose(got, want, atol=1e-5, rtol=0)
+    asr1 = torch.load(os.path.join(ckpdir, 'asr.cpt'), map_location='cpu')
+    d1 = torch.load(os.path.join(ckpdir, 'adv.cpt'), map_location='cpu')
+    assert all(torch.equal(asr1[k], asr0[k]) for k in asr0 if not k.startswith('encoder.'))
+    assert not torch.equal(asr1['encoder.blstm_1.layer.weight_hh_l0'], asr0['encoder.blstm_1.layer.weight_hh_l0'])
+    assert not torch.equal(d1['core.0.weight'], d0['core.0.weight'])
+
+
+def test_sae_trainer_end_to_end(tmp_path):
+    """SAETrainer end to end on a 16-utterance index: first-iteration loss against the CPU oracle, the eval-mode
+    validation with its figure records, both checkpoints (batch-norm buffers included), and an update that
+    moved the Listener and the speech autoencoder but nothing behind the Listener."""
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_x
+    from ss_asr_amd.trainer import SAETrainer
+    root = str(tmp_path)
+    index, _ = make_corpus(root, n=16, t_max=32, feat=80, seed=6)
+    conf = _seed_config(index)
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = SAETrainer(conf, _paras(root, 'sae1'))
+    tr.load_data()
+    tr.set_model()
+    asr0, sae0 = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in (tr.asr_model, tr.speech_autoenc))
+    tr.exec()
+    tr.close()
+    ckpdir = os.path.join(root, 'result', 'sae1')
+    assert json.load(open(os.path.join(ckpdir, 'tracker.json')))['sae']['step'] == 2
+    for f in ('sae.cpt', 'sae_best.cpt', 'asr.cpt'):
+        assert os.path.isfile(os.path.join(ckpdir, f)), f
+    ev = _events(root, 'sae1', 'sae')
+    losses = [e['value'] for e in ev if e['key'] == 'sae_train_loss']
+    assert len(losses) == 2 and any(e['key'] == 'sae_eval_loss' for e in ev) and any(e['kind'] == 'figure' for e in ev)
+    _, _, loader = load_asr_dataset(index, batch_size=16, n_jobs=0)
+    x, _ = next(iter(loader))
+    x, _ = prepare_x(x)
+    ref_asr = lo.OracleASR(50, 256, 256, 128, 80, 1.0)
+    ref_asr.load_state_dict(asr0)
+    ref_sae = lo.OracleSpeechAutoEncoder(512, 80, **conf['sae']['mdl'])
+    ref_sae.load_state_dict(sae0)
+    want, _ = lo.sae_train_step(ref_asr, ref_sae, lo.make_sae_optimizer(ref_sae, ref_asr), x)
+    assert abs(losses[0] - want) < 1e-5, (losses[0], want)
+    asr1 = torch.load(os.path.join(ckpdir, 'asr.cpt'), map_location='cpu')
+    sae1 = torch.load(os.path.join(ckpdir, 'sae.cpt'), map_location='cpu')
+    assert all(torch.equal(asr1[k], asr0[k]) for k in asr0 if not k.startswith('encoder.'))
+    assert not torch.equal(asr1['encoder.blstm_1.layer.weight_hh_l0'], asr0['encoder.blstm_1.layer.weight_hh_l0'])
+    assert int(sae1['encoder.conv_1.1.num_batches_tracked']) == 2
+    assert not torch.equal(sae1['encoder.conv_2.1.running_mean'], sae0['encoder.conv_2.1.running_mean'])
+
+
+def test_seed_loop_runs_the_three_legs_over_the_checkpoint_chain(tmp_path):
+    """trainer.asr_seed_train (src/trainer.py:1126-1177; BASELINE.json configs[4]) with the reference's legs and
+    checkpoint chain: TAETrainer on asr_1.cpt, ADVTrainer asr_1 -> asr_2 (with the text autoencoder TAETrainer
+    left), SAETrainer asr_2 -> asr_3.  What each leg may touch is checked on the checkpoints: the text leg leaves
+    the Listener alone, the adversarial and speech legs leave everything behind the Listener alone."""
+    from ss_asr_amd.trainer import asr_seed_train
+    root = str(tmp_path)
+    index, _ = make_corpus(root, n=16, t_max=32, feat=80, seed=7)
+    conf = _seed_config(index, n_epochs=1)
+    conf['seed_train'] = {'super_its': 1}
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    asr_seed_train(conf, _paras(root, 'seed1'))
+    ckpdir = os.path.join(root, 'result', 'seed1')
+    a1, a2, a3 = (torch.load(os.path.join(ckpdir, 'asr_%d.cpt' % k), map_location='cpu') for k in (1, 2, 3))
+    for f in ('tae.cpt', 'adv.cpt', 'sae.cpt', 'tracker.json'):
+        assert os.path.isfile(os.path.join(ckpdir, f)), f
+    tracker = json.load(open(os.path.join(ckpdir, 'tracker.json')))
+    assert tracker['tae']['step'] == 1 and tracker['adv']['step'] == 1 and tracker['sae']['step'] == 1
+    behind = [k for k in a1 if not k.startswith('encoder.')]
+    assert all(torch.equal(a1[k], a2[k]) and torch.equal(a2[k], a3[k]) for k in behind)
+    assert not torch.equal(a1['encoder.blstm_2.layer.weight_ih_l0'], a2['encoder.blstm_2.layer.weight_ih_l0'])
+    assert not torch.equal(a2['encoder.blstm_2.layer.weight_ih_l0'], a3['encoder.blstm_2.layer.weight_ih_l0'])

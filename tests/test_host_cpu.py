@@ -361,7 +361,7 @@ REFERENCE_TRAIN = '/root/reference/src/train.py'
 
 @pytest.mark.skipif(not os.path.isfile(REFERENCE_TRAIN),
                     reason='build-container only: the reference tree does not travel to the GPU box')
-@pytest.mark.parametrize('kind', ['ASRTrainer', 'TAETrainer', 'Seed'])
+@pytest.mark.parametrize('kind', ['ASRTrainer', 'TAETrainer', 'AdvTrainer', 'SAETrainer', 'Seed'])
 def test_reference_train_script_runs_unchanged_against_the_shims(tmp_path, kind):
     """`python -m ss_asr_amd.run_reference <reference>/src/train.py ...`
     executes the reference's unmodified entry point with its bare imports (`import trainer`,
@@ -384,7 +384,16 @@ def test_reference_train_script_runs_unchanged_against_the_shims(tmp_path, kind)
                     'mdl': {'state_size': 32, 'emb_dim': 8, 'num_layers': 2}, 'drop_rate': 0.1,
                     'train_index': index, 'valid_index': index, 'train_batch_size': 16, 'valid_batch_size': 16,
                     'n_epochs': 1, 'loader_jobs': 0},
-            'seed_train': {'its': 1}}
+            # the other two legs (conf/default.yaml:23-40, :62-82 in miniature; 24 frames leave [1, 40] for the last pooling)
+            'adv': {'G_opt': {'type': 'Adadelta', 'learning_rate': 1.0}, 'D_opt': {'type': 'Adadelta', 'learning_rate': 1.0},
+                    'mdl': {'hidden_dim': 16}, 'label_smoothing': 0.1, 'train_index': index, 'valid_index': index,
+                    'train_batch_size': 16, 'valid_batch_size': 16, 'n_epochs': 1, 'loader_jobs': 0},
+            'sae': {'opt': {'type': 'Adam', 'learning_rate': 0.0001},
+                    'mdl': {'kernel_sizes': [[1, 36], [5, 1], [3, 1]], 'num_filters': [8, 8, 16],
+                            'pool_kernel_sizes': [[3, 1], [1, 1], [2, 40]]},
+                    'train_index': index, 'valid_index': index, 'train_batch_size': 16, 'valid_batch_size': 16,
+                    'n_epochs': 1, 'loader_jobs': 0},
+            'seed_train': {'super_its': 1}}
     conf_path = os.path.join(root, 'conf.yaml')
     with open(conf_path, 'w') as f:
         yaml.safe_dump(conf, f)
