@@ -461,6 +461,8 @@ int ssasr_conv2d_bwd(const float* dy, int dy_bordered, const float* x, const flo
  *   ws: float[ssasr_bn_ws_floats(C)] scratch (shared with ssasr_bn_relu_pool_bwd).
  * ssasr_bn_relu_pool_fwd: p [B][T / ph][W / pw][C] = max over each window of relu(y * scale + shift) (floor
  *   mode: remainder rows / columns dropped); idx: offset i * pw + j of the FIRST maximum inside its window.
+ *   ws: float[ssasr_pool_ws_floats(...)] scratch (0 floats, NULL allowed, for windows of fewer than 64 values;
+ *   larger windows are reduced in chunks across the chip).
  * ssasr_bn_relu_pool_bwd (training-mode batch norm): from dp, the gradient of p, writes the gradient of the
  *   convolution output y, dy [B][T + 2 border_t][W + 2 border_w][C] (the border zeroed here), and adds
  *   dgamma / dbeta (optional).  Windows whose maximum is 0 pass nothing (ReLU). */
@@ -468,8 +470,9 @@ int64_t ssasr_bn_ws_floats(int64_t C);
 int ssasr_bn_stats(const float* y, int64_t rows, int64_t C, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, int training, float* ws,
                    float* save, void* stream);
+int64_t ssasr_pool_ws_floats(int64_t B, int64_t T, int64_t W, int64_t C, int64_t ph, int64_t pw);
 int ssasr_bn_relu_pool_fwd(const float* y, const float* save, int64_t B, int64_t T, int64_t W, int64_t C,
-                           int64_t ph, int64_t pw, float* p, int32_t* idx, void* stream);
+                           int64_t ph, int64_t pw, float* p, int32_t* idx, float* ws, void* stream);
 int ssasr_bn_relu_pool_bwd(const float* dp, const float* p, const int32_t* idx, const float* y, const float* save,
                            const float* gamma, int64_t B, int64_t T, int64_t W, int64_t C, int64_t ph, int64_t pw,
                            int64_t border_t, int64_t border_w, float* dy, float* dgamma, float* dbeta, float* ws,

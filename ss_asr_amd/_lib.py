@@ -95,7 +95,8 @@ SIGNATURES = {
     'ssasr_conv2d_bwd': (I32, [P, I32, P, P, P, P] + [I64] * 7 + [P, P]),
     'ssasr_bn_ws_floats': (I64, [I64]),
     'ssasr_bn_stats': (I32, [P, I64, I64, P, P, P, P, F32, F32, I32, P, P, P]),
-    'ssasr_bn_relu_pool_fwd': (I32, [P, P] + [I64] * 6 + [P, P, P]),
+    'ssasr_pool_ws_floats': (I64, [I64] * 6),
+    'ssasr_bn_relu_pool_fwd': (I32, [P, P] + [I64] * 6 + [P, P, P, P]),
     'ssasr_bn_relu_pool_bwd': (I32, [P, P, P, P, P, P] + [I64] * 8 + [P, P, P, P, P]),
     'ssasr_sae_concat_fwd': (I32, [P, P, I64, I64, I64, I64, P, P]),
     'ssasr_sae_concat_bwd': (I32, [P, I64, I64, I64, I64, P, P, P]),

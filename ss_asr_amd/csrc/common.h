@@ -168,6 +168,7 @@ struct GemmDesc {
   // -- e.g. the input gradient dX = dG_f W_f + dG_r W_r of a BiLSTM layer as one launch, C written once
   int kcat;
   int64_t ska, skb;
+  int tile;            // 0: the launcher chooses; 64 / 128: this tile shape (skinny products whose caller knows better)
 };
 int ssasr_launch_gemm(const GemmDesc& g, hipStream_t st);
 int ssasr_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);

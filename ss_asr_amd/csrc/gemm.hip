@@ -798,6 +798,8 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   const bool vecB = aligned16(g.B) && map_vec_ok(g.mb) && (g.sb % 4 == 0) && (g.kcat <= 1 || g.skb % 4 == 0);
   // 128x128 tiles only when they still give every CU work.
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
+  if (g.tile == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
+  if (g.tile == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
   if (const int forced = ssasr_options().gemm_tile) {       // diagnostic: force a tile shape
     if (forced == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
     if (forced == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);

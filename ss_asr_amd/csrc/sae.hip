@@ -110,14 +110,17 @@ __global__ __launch_bounds__(256) void bn_sum_kernel(const float* y, int64_t row
   const float mean = (CENTERED && c < C) ? (float)(acc[c] / (double)rows) : 0.f;
   double tot = 0.0;
   if (c < C) {
+    auto term = [&](int64_t r) { const float v = y[r * C + c] - mean; return CENTERED ? v * v : v; };
     int64_t r = r0 + rl;
     while (r < r1) {
-      float part = 0.f;                                    // fp32 over a short run, double across runs
-      for (int k = 0; k < 64 && r < r1; ++k, r += RL) {
-        const float v = y[r * C + c] - mean;
-        part += CENTERED ? v * v : v;
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;        // fp32 over a short run (four chains), double across runs
+      int k = 0;
+      for (; k < 16 && r + 3 * (int64_t)RL < r1; ++k, r += 4 * (int64_t)RL) {
+        p0 += term(r); p1 += term(r + RL); p2 += term(r + 2 * (int64_t)RL); p3 += term(r + 3 * (int64_t)RL);
       }
-      tot += (double)part;
+      if (k < 16)
+        for (; r < r1; r += RL) p0 += term(r);
+      tot += (double)((p0 + p1) + (p2 + p3));
     }
   }
   sm[threadIdx.x] = tot;
@@ -177,38 +180,47 @@ __global__ void pool_fwd_small_kernel(const float* y, const float* save, int64_t
   }
 }
 
-// Large windows (the last layer pools a whole utterance, [2000, 40] in conf/default.yaml:30): one workgroup per
-// output pixel and tile of CT channels, the window split over 256 / CT thread rows, combined through LDS.
+// Large windows (the last layer pools a whole utterance, [2000, 40] in conf/default.yaml:30): the window is cut
+// into chunks over blockIdx.y so that a handful of output pixels still fill the chip; a workgroup takes one
+// chunk for a tile of CT channels (256 / CT thread rows over the chunk, combined through LDS) and merges its
+// best (value, offset) into a 64-bit key per output value with one atomic max: value bits (>= +0, so ordered as
+// unsigned) above the complemented offset, so that equal values keep the FIRST offset.  A second pass unpacks.
+__device__ __forceinline__ unsigned long long pool_key(float v, int e) {
+  return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xffffffffu - (unsigned)e);
+}
 __global__ __launch_bounds__(256) void pool_fwd_large_kernel(const float* y, const float* save, int64_t T, int64_t W, int C,
-                                                            int CT, int ph, int pw, int64_t To, int64_t Wo, float* p,
-                                                            int32_t* idx) {
-  __shared__ float sv[256];
-  __shared__ int si[256];
+                                                            int CT, int ph, int pw, int64_t To, int64_t Wo, int chunk,
+                                                            unsigned long long* keys) {
+  __shared__ unsigned long long sk[256];
   const int cl = threadIdx.x % CT, wl = threadIdx.x / CT, WL = 256 / CT;
-  const int c = blockIdx.y * CT + cl;
+  const int c = blockIdx.z * CT + cl;
   const int64_t pos = blockIdx.x, wo = pos % Wo, to = (pos / Wo) % To, b = pos / (Wo * To);
-  float best = -INFINITY;
-  int bi = 0x7fffffff;
+  const int win = ph * pw, e0 = blockIdx.y * chunk, e1 = min(win, e0 + chunk);
+  unsigned long long best = 0ull;
   if (c < C) {
     const float sc = save[2 * C + c], sh = save[3 * C + c];
     const float* base = y + ((b * T + to * ph) * W + wo * pw) * C + c;
-    const int win = ph * pw;
-    for (int e = wl; e < win; e += WL) {
-      const int i = e / pw, j = e % pw;
-      const float v = fmaxf(fmaf(base[((int64_t)i * W + j) * C], sc, sh), 0.f);
-      if (v > best) { best = v; bi = e; }
+    for (int e = e0 + wl; e < e1; e += WL) {
+      const int i = e / pw, j = e - i * pw;
+      float v = fmaf(base[((int64_t)i * W + j) * C], sc, sh);
+      v = v > 0.f ? v : 0.f;
+      const unsigned long long k = pool_key(v, e);
+      best = k > best ? k : best;
     }
   }
-  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  sk[threadIdx.x] = best;
   __syncthreads();
   if (wl == 0 && c < C) {
-    for (int k = 1; k < WL; ++k) {
-      const float v = sv[k * CT + cl];
-      const int vi = si[k * CT + cl];
-      if (v > best || (v == best && vi < bi)) { best = v; bi = vi; }
-    }
-    p[pos * C + c] = best;
-    idx[pos * C + c] = bi;
+    for (int k = 1; k < WL; ++k) { const unsigned long long o = sk[k * CT + cl]; best = o > best ? o : best; }
+    atomicMax(keys + pos * C + c, best);
+  }
+}
+__global__ void pool_unpack_kernel(const unsigned long long* keys, int64_t n, float* p, int32_t* idx) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const unsigned long long k = keys[e];
+    p[e] = __uint_as_float((unsigned)(k >> 32));
+    idx[e] = (int32_t)(0xffffffffu - (unsigned)(k & 0xffffffffull));
   }
 }
 
@@ -251,11 +263,12 @@ __global__ __launch_bounds__(256) void pool_bwd_sums_kernel(const float* dp, con
 // (batch norm in training mode), written inside a zero border of (bt, bw) pixels when the convolution's input
 // gradient is wanted next (its full correlation then reads the border in place).  Block 0 also adds the two
 // parameter gradients: dgamma += s2, dbeta += s1.
-__global__ void bn_pool_bwd_apply_kernel(const float* dp, const float* p, const int32_t* idx, const float* y,
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* dp, const float* p, const int32_t* idx, const float* y,
                                          const float* save, const float* gamma, const double* acc, int64_t B, int64_t T,
                                          int64_t W, int C, int ph, int pw, int bt, int bw, float* dy, float* dgamma,
                                          float* dbeta) {
-  const int64_t To = T / ph, Wo = W / pw, n = B * T * W * C, stride = (int64_t)gridDim.x * blockDim.x;
+  // one workgroup per row (b, t) of the layer (blockIdx.x walks rows), threads over its W * C values
+  const int64_t To = T / ph, Wo = W / pw;
   const double count = (double)(B * T * W);
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -263,19 +276,26 @@ __global__ void bn_pool_bwd_apply_kernel(const float* dp, const float* p, const 
       if (dbeta) dbeta[c] += (float)acc[c];
     }
   const int64_t Tp = T + 2 * bt, Wp = W + 2 * bw;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-    const int c = (int)(e % C);
-    const int64_t pos = e / C, m = pos % W, t = (pos / W) % T, b = pos / (W * T);
-    const float mean = save[c], invstd = save[C + c];
-    const float xhat = (y[e] - mean) * invstd;
-    const int64_t to = t / ph, wo = m / pw;
-    float dz = 0.f;
-    if (to < To && wo < Wo) {
-      const int64_t q = ((b * To + to) * Wo + wo) * C + c;
-      if (p[q] > 0.f && idx[q] == (int)((t % ph) * pw + (m % pw))) dz = dp[q];
+  const int rowlen = (int)(W * C);
+  for (int64_t row = blockIdx.x; row < B * T; row += gridDim.x) {
+    const int64_t b = row / T, t = row - b * T, to = t / ph;
+    const int ti = (int)(t - to * ph);
+    const float* yr = y + row * rowlen;
+    float* dyr = dy + ((b * Tp + t + bt) * Wp + bw) * C;
+    const int64_t qrow = (b * To + to) * Wo;              // first pooled pixel of the window row
+    for (int e = threadIdx.x; e < rowlen; e += 256) {
+      const int m = e / C, c = e - m * C;
+      const float mean = save[c], invstd = save[C + c];
+      const float xhat = (yr[e] - mean) * invstd;
+      const int wo = m / pw;
+      float dz = 0.f;
+      if (to < To && wo < Wo) {
+        const int64_t q = (qrow + wo) * C + c;
+        if (p[q] > 0.f && idx[q] == ti * pw + (m - wo * pw)) dz = dp[q];
+      }
+      const float m1 = (float)(acc[c] / count), m2 = (float)(acc[C + c] / count);
+      dyr[e] = gamma[c] * invstd * (dz - m1 - xhat * m2);
     }
-    const float m1 = (float)(acc[c] / count), m2 = (float)(acc[C + c] / count);
-    dy[((b * Tp + t + bt) * Wp + m + bw) * C + c] = gamma[c] * invstd * (dz - m1 - xhat * m2);
   }
 }
 
@@ -418,6 +438,7 @@ extern "C" int ssasr_conv2d_bwd(const float* dy, int dy_bordered, const float* x
         g.M = (int)F; g.N = (int)(kw * C); g.K = (int)(To * Wo);
         g.alpha = 1.f; g.beta = 1.f; g.splitk = (int)s;
         g.batch = (int)B; g.sa = Tp * Wp * F; g.sb = T * W * C; g.sc = 0;
+        g.tile = 64;                                                  // (a few tiles of <= 256 x kw C: fine-grained)
         if ((rc = ssasr_launch_gemm(g, st))) return rc;
       }
       hipLaunchKernelGGL(conv_dw_fold_kernel, dim3(stream_grid(n_w, 1)), dim3(256), 0, st, dwl, dw, (int)F, (int)C, ikh, ikw, 0);
@@ -434,6 +455,7 @@ extern "C" int ssasr_conv2d_bwd(const float* dy, int dy_bordered, const float* x
       g.M = (int)F; g.N = (int)K; g.K = (int)(To * Wo);
       g.alpha = 1.f; g.beta = 1.f;
       g.batch = (int)B; g.sa = Tp * Wp * F; g.sb = To * Wo * K; g.sc = 0;
+      g.tile = 64;
       const int64_t tiles = ((F + 63) / 64) * ((K + 63) / 64);
       int64_t s = (512 + tiles * B - 1) / (tiles * B), smax = (To * Wo) / 256;
       if (s > smax) s = smax;
@@ -481,8 +503,23 @@ extern "C" int ssasr_bn_stats(const float* y, int64_t rows, int64_t C, const flo
   return SSASR_OK;
 }
 
+static int pool_chunks(int64_t npos, int64_t C, int64_t win, int* chunk) {
+  const int CT = chan_tile(C);
+  const int64_t base = npos * ((C + CT - 1) / CT);
+  int64_t n = (1024 + base - 1) / base, nmax = (win + 63) / 64;
+  if (n > nmax) n = nmax;
+  if (n < 1) n = 1;
+  *chunk = (int)((win + n - 1) / n);
+  return (int)((win + *chunk - 1) / *chunk);
+}
+
+extern "C" int64_t ssasr_pool_ws_floats(int64_t B, int64_t T, int64_t W, int64_t C, int64_t ph, int64_t pw) {
+  if (B <= 0 || C <= 0 || ph <= 0 || pw <= 0 || T < ph || W < pw || ph * pw < 64) return 0;
+  return 2 * B * (T / ph) * (W / pw) * C + 2;                     // one 64-bit key per output value (+ alignment slack)
+}
+
 extern "C" int ssasr_bn_relu_pool_fwd(const float* y, const float* save, int64_t B, int64_t T, int64_t W, int64_t C,
-                                      int64_t ph, int64_t pw, float* p, int32_t* idx, void* stream) {
+                                      int64_t ph, int64_t pw, float* p, int32_t* idx, float* ws, void* stream) {
   if (!y || !save || !p || !idx || B <= 0 || C <= 0 || ph <= 0 || pw <= 0 || T < ph || W < pw || ph * pw > 0x7ffffff)
     return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
@@ -491,10 +528,16 @@ extern "C" int ssasr_bn_relu_pool_fwd(const float* y, const float* save, int64_t
     hipLaunchKernelGGL(pool_fwd_small_kernel, dim3(stream_grid(B * To * Wo * C, 1)), dim3(256), 0, st, y, save, B, T, W, (int)C,
                        (int)ph, (int)pw, p, idx);
   } else {
+    if (!ws || B * To * Wo > 0x7fffffff) return SSASR_EARG;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(bn_acc(ws));
+    const int64_t n = B * To * Wo * C;
+    SSASR_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * n, st));
     const int CT = chan_tile(C);
-    if (B * To * Wo > 0x7fffffff) return SSASR_EARG;
-    dim3 grid((unsigned)(B * To * Wo), (unsigned)((C + CT - 1) / CT));
-    hipLaunchKernelGGL(pool_fwd_large_kernel, grid, dim3(256), 0, st, y, save, T, W, (int)C, CT, (int)ph, (int)pw, To, Wo, p, idx);
+    int chunk;
+    const int nchunks = pool_chunks(B * To * Wo, C, ph * pw, &chunk);
+    dim3 grid((unsigned)(B * To * Wo), (unsigned)nchunks, (unsigned)((C + CT - 1) / CT));
+    hipLaunchKernelGGL(pool_fwd_large_kernel, grid, dim3(256), 0, st, y, save, T, W, (int)C, CT, (int)ph, (int)pw, To, Wo, chunk, keys);
+    hipLaunchKernelGGL(pool_unpack_kernel, dim3(stream_grid(n, 1)), dim3(256), 0, st, keys, n, p, idx);
   }
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
@@ -518,7 +561,8 @@ extern "C" int ssasr_bn_relu_pool_bwd(const float* dp, const float* p, const int
   gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
   hipLaunchKernelGGL(pool_bwd_sums_kernel, dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
                      B, T, W, (int)C, CT, (int)ph, (int)pw, acc);
-  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(stream_grid(B * T * W * C)), dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
+  const int64_t nrows = B * T;
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3((unsigned)(nrows > 65536 ? 65536 : nrows)), dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
                      B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;

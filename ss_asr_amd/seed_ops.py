@@ -129,7 +129,8 @@ class _SpeechEncoder(torch.autograd.Function):
             if To < ph or Wo < pw:
                 raise RuntimeError('max pool %d: kernel %s is larger than its input (%d x %d): output size is too small'
                                    % (l + 1, (ph, pw), To, Wo))
-            ws = _ws(max(lib.ssasr_conv2d_ws_floats(B, T, W, C, F, kh, kw), lib.ssasr_bn_ws_floats(F)), dev)
+            ws = _ws(max(lib.ssasr_conv2d_ws_floats(B, T, W, C, F, kh, kw), lib.ssasr_bn_ws_floats(F),
+                         lib.ssasr_pool_ws_floats(B, To, Wo, F, ph, pw)), dev)
             y = torch.empty(B, To, Wo, F, device=dev, dtype=torch.float32)
             check(lib.ssasr_conv2d_fwd(_p(cur), _p(w), _p(y), B, T, W, C, F, kh, kw, _p(ws), _stream()), 'ssasr_conv2d_fwd')
             save = torch.empty(4 * F, device=dev, dtype=torch.float32)
@@ -138,7 +139,7 @@ class _SpeechEncoder(torch.autograd.Function):
             Tp, Wp = To // ph, Wo // pw
             p = torch.empty(B, Tp, Wp, F, device=dev, dtype=torch.float32)
             idx = torch.empty(B, Tp, Wp, F, device=dev, dtype=torch.int32)
-            check(lib.ssasr_bn_relu_pool_fwd(_p(y), _p(save), B, To, Wo, F, ph, pw, _p(p), _p(idx), _stream()),
+            check(lib.ssasr_bn_relu_pool_fwd(_p(y), _p(save), B, To, Wo, F, ph, pw, _p(p), _p(idx), _p(ws), _stream()),
                   'ssasr_bn_relu_pool_fwd')
             saved += [cur, w, gamma, y, save, p, idx]
             geom.append((T, W, C, F, kh, kw, ph, pw))

@@ -136,7 +136,7 @@ def test_batch_norm_relu_pool_matches_torch(B, T, W, C, ph, pw, border):
     dp = torch.randn(B, T // ph, W // pw, C, generator=g)
     pr.backward(dp.permute(0, 3, 1, 2).double())
     yg, gam, bet, rm, rv = (t.cuda() for t in (y, gamma, beta, rm0.clone(), rv0.clone()))
-    ws = torch.empty(int(lib.ssasr_bn_ws_floats(C)), device='cuda')
+    ws = torch.empty(max(int(lib.ssasr_bn_ws_floats(C)), int(lib.ssasr_pool_ws_floats(B, T, W, C, ph, pw))), device='cuda')
     save = torch.empty(4 * C, device='cuda')
     assert lib.ssasr_bn_stats(p(yg), B * T * W, C, p(gam), p(bet), p(rm), p(rv), 0.1, 1e-5, 1, p(ws), p(save), st()) == 0
     np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), atol=2e-6)
@@ -144,7 +144,7 @@ def test_batch_norm_relu_pool_matches_torch(B, T, W, C, ph, pw, border):
     To, Wo = T // ph, W // pw
     pg = torch.empty(B, To, Wo, C, device='cuda')
     idx = torch.empty(B, To, Wo, C, device='cuda', dtype=torch.int32)
-    assert lib.ssasr_bn_relu_pool_fwd(p(yg), p(save), B, T, W, C, ph, pw, p(pg), p(idx), st()) == 0
+    assert lib.ssasr_bn_relu_pool_fwd(p(yg), p(save), B, T, W, C, ph, pw, p(pg), p(idx), p(ws), st()) == 0
     want = pr.detach().permute(0, 2, 3, 1)
     assert float((pg.cpu().double() - want).abs().max()) < 3e-6 * max(1.0, float(want.abs().max()))
     bt, bw = border
@@ -168,7 +168,7 @@ def test_batch_norm_relu_pool_matches_torch(B, T, W, C, ph, pw, border):
     pe = F.max_pool2d(torch.relu(bn(y.permute(0, 3, 1, 2).double())), (ph, pw)).permute(0, 2, 3, 1)
     rm1, rv1 = rm.clone(), rv.clone()
     assert lib.ssasr_bn_stats(p(yg), B * T * W, C, p(gam), p(bet), p(rm), p(rv), 0.1, 1e-5, 0, p(ws), p(save), st()) == 0
-    assert lib.ssasr_bn_relu_pool_fwd(p(yg), p(save), B, T, W, C, ph, pw, p(pg), p(idx), st()) == 0
+    assert lib.ssasr_bn_relu_pool_fwd(p(yg), p(save), B, T, W, C, ph, pw, p(pg), p(idx), p(ws), st()) == 0
     assert torch.equal(rm, rm1) and torch.equal(rv, rv1)
     assert float((pg.cpu().double() - pe.detach()).abs().max()) < 3e-6 * max(1.0, float(pe.detach().abs().max()))
 
