@@ -355,11 +355,12 @@ __global__ __launch_bounds__(256) void sl1_fwd_kernel(const float* pred, const f
   if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
 __global__ void sl1_mean_kernel(const double* partial, int nblocks, double count, float* loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int k = 0; k < nblocks; ++k) s += partial[k];       // fixed order: deterministic
-    *loss = (float)(s / count);
-  }
+  // one wave; lane l adds partials l, l + 64, ... in order, then a fixed butterfly: deterministic
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nblocks; k += 64) s += partial[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) *loss = (float)(s / count);
 }
 // dpred[b][r][f] = upstream * clamp(d, -1, 1) / (B * bt * F), rows r < R only (the zero rows are constants)
 __global__ void sl1_bwd_kernel(const float* pred, const float* x, int64_t B, int64_t bt, int64_t R, int64_t Tx, int F,
