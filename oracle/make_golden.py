@@ -525,6 +525,14 @@ def main(only=None):
                          dict(kernel_sizes=[[7, 1], [1, 3], [2, 2]], num_filters=[6, 12, 20],
                               pool_kernel_sizes=[[2, 1], [1, 2], [28, 3]]),
                          [[64, 56, 48, 40], [61, 50, 33, 17], [56, 56, 41, 24]], 64, 62, opt=('Adam', 1e-3))
+    # the yaml's speech autoencoder AS SHIPPED (conf/default.yaml:27-30): its last pooling window [2000, 40] only fits
+    # utterances of 30,050 .. 60,000 frames (five to ten minutes of audio) -- two of them, one iteration, full layer
+    # sizes: the Listener's recurrences run 30,100 / 15,050 / 7,525 steps.  Minutes of reference CPU time: on request
+    if only and 'sae_yaml_b2_t30100' in only:
+        capture_sae_traj(asr_mod, sae_mod, 'sae_yaml_b2_t30100', full,
+                         dict(kernel_sizes=[[1, 36], [5, 1], [3, 1]], num_filters=[32, 64, 256],
+                              pool_kernel_sizes=[[3, 1], [5, 1], [2000, 40]]),
+                         [[30100, 27013]], 30100, 63)
     for name, pick, seed, wseed in (('bench_b32_t800', 0, 8, 14), ('bench_b32_median', 4, 9, 15)):
         x, y, lens = config2_batches(8, batch_size=32, feat_dim=80, seed=1)[pick]
         ylens = [int(v) - 1 for v in (y != 0).sum(-1)]

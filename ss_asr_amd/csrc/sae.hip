@@ -98,37 +98,70 @@ inline int64_t conv_col_floats(int64_t B, int64_t T, int64_t W, int64_t C, int k
 }
 
 // ------------------------------------------------------------------ batch norm ----
+// V consecutive floats / ints (V = 4: one 16-byte access; the callers check alignment and C % 4 == 0)
+template <int V> __device__ __forceinline__ void ldv(const float* p, float (&v)[V]) {
+  if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  else v[0] = *p;
+}
+template <int V> __device__ __forceinline__ void ldv(const int32_t* p, int (&v)[V]) {
+  if constexpr (V == 4) { const int4 t = *reinterpret_cast<const int4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  else v[0] = *p;
+}
+template <int V> __device__ __forceinline__ void stv(float* p, const float (&v)[V]) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else *p = v[0];
+}
+template <int V> __device__ __forceinline__ void stv(int32_t* p, const int (&v)[V]) {
+  if constexpr (V == 4) *reinterpret_cast<int4*>(p) = make_int4(v[0], v[1], v[2], v[3]);
+  else *p = v[0];
+}
+
 // per-channel sums over the rows of a channels-last [rows][C] tensor, in double:
 //   CENTERED = false: acc[c] += sum_r y[r][c];  true: acc[C + c] += sum_r (y[r][c] - acc[c] / rows)^2
-template <bool CENTERED>
+// A thread owns V consecutive channels (CT groups of V channels per row, 256 / CT rows per pass).
+template <bool CENTERED, int V>
 __global__ __launch_bounds__(256) void bn_sum_kernel(const float* y, int64_t rows, int C, int CT, double* acc) {
-  __shared__ double sm[256];
+  __shared__ double sm[V][256];
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT, RL = 256 / CT;
-  const int c = blockIdx.y * CT + cl;
+  const int c = (blockIdx.y * CT + cl) * V;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
-  const float mean = (CENTERED && c < C) ? (float)(acc[c] / (double)rows) : 0.f;
-  double tot = 0.0;
+  float mean[V];
+  double tot[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { mean[e] = (CENTERED && c < C) ? (float)(acc[c + e] / (double)rows) : 0.f; tot[e] = 0.0; }
   if (c < C) {
-    auto term = [&](int64_t r) { const float v = y[r * C + c] - mean; return CENTERED ? v * v : v; };
+    auto add = [&](float (&p)[V], int64_t r) {
+      float v[V];
+      ldv<V>(y + r * C + c, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { const float d = v[e] - mean[e]; p[e] += CENTERED ? d * d : d; }
+    };
     int64_t r = r0 + rl;
     while (r < r1) {
-      float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;        // fp32 over a short run (four chains), double across runs
+      float p0[V], p1[V], p2[V], p3[V];        // fp32 over a short run (four chains), double across runs
+#pragma unroll
+      for (int e = 0; e < V; ++e) p0[e] = p1[e] = p2[e] = p3[e] = 0.f;
       int k = 0;
       for (; k < 16 && r + 3 * (int64_t)RL < r1; ++k, r += 4 * (int64_t)RL) {
-        p0 += term(r); p1 += term(r + RL); p2 += term(r + 2 * (int64_t)RL); p3 += term(r + 3 * (int64_t)RL);
+        add(p0, r); add(p1, r + RL); add(p2, r + 2 * (int64_t)RL); add(p3, r + 3 * (int64_t)RL);
       }
       if (k < 16)
-        for (; r < r1; r += RL) p0 += term(r);
-      tot += (double)((p0 + p1) + (p2 + p3));
+        for (; r < r1; r += RL) add(p0, r);
+#pragma unroll
+      for (int e = 0; e < V; ++e) tot[e] += (double)((p0[e] + p1[e]) + (p2[e] + p3[e]));
     }
   }
-  sm[threadIdx.x] = tot;
+#pragma unroll
+  for (int e = 0; e < V; ++e) sm[e][threadIdx.x] = tot[e];
   __syncthreads();
   if (rl == 0 && c < C) {
-    double s = 0.0;
-    for (int k = 0; k < RL; ++k) s += sm[k * CT + cl];
-    atomicAdd(acc + (CENTERED ? C : 0) + c, s);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      double t = 0.0;
+      for (int k = 0; k < RL; ++k) t += sm[e][k * CT + cl];
+      atomicAdd(acc + (CENTERED ? C : 0) + c + e, t);
+    }
   }
 }
 
@@ -159,24 +192,34 @@ __global__ void bn_finalize_kernel(const double* acc, int64_t rows, int C, const
 // ------------------------------------------------------------------ normalise + ReLU + max pool ----
 // p[b][to][wo][c] = max over the ph x pw window of relu(y * scale + shift); idx = offset (i * pw + j) of the FIRST
 // maximum inside the window (torch's rule).  Remainder rows / columns are dropped (floor mode).
-// Small windows: one thread per output value.
+// Small windows: one thread per V output values (consecutive channels of one pixel).
+template <int V>
 __global__ void pool_fwd_small_kernel(const float* y, const float* save, int64_t B, int64_t T, int64_t W, int C, int ph,
                                       int pw, float* p, int32_t* idx) {
-  const int64_t To = T / ph, Wo = W / pw, n = B * To * Wo * C, stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-    const int c = (int)(e % C);
-    const int64_t pos = e / C, wo = pos % Wo, to = (pos / Wo) % To, b = pos / (Wo * To);
-    const float sc = save[2 * C + c], sh = save[3 * C + c];
+  const int CV = C / V;
+  const int64_t To = T / ph, Wo = W / pw, n = B * To * Wo * CV, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
+    const int c = (int)(g % CV) * V;
+    const int64_t pos = g / CV, wo = pos % Wo, to = (pos / Wo) % To, b = pos / (Wo * To);
+    float sc[V], sh[V], best[V];
+    int bi[V];
+    ldv<V>(save + 2 * C + c, sc);
+    ldv<V>(save + 3 * C + c, sh);
+#pragma unroll
+    for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 0; }
     const float* base = y + ((b * T + to * ph) * W + wo * pw) * C + c;
-    float best = -INFINITY;
-    int bi = 0;
     for (int i = 0; i < ph; ++i)
       for (int j = 0; j < pw; ++j) {
-        const float v = fmaxf(fmaf(base[((int64_t)i * W + j) * C], sc, sh), 0.f);
-        if (v > best) { best = v; bi = i * pw + j; }
+        float v[V];
+        ldv<V>(base + ((int64_t)i * W + j) * C, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float z = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+          if (z > best[e]) { best[e] = z; bi[e] = i * pw + j; }
+        }
       }
-    p[e] = best;
-    idx[e] = bi;
+    stv<V>(p + pos * C + c, best);
+    stv<V>(idx + pos * C + c, bi);
   }
 }
 
@@ -226,36 +269,50 @@ __global__ void pool_unpack_kernel(const unsigned long long* keys, int64_t n, fl
 
 // Backward, first pass: per channel s1 = sum dz, s2 = sum dz * xhat over the pooled outputs, dz = dp * (p > 0)
 // landing on the window's arg-max (every other position of the layer has dz = 0).
+template <int V>
 __global__ __launch_bounds__(256) void pool_bwd_sums_kernel(const float* dp, const float* p, const int32_t* idx, const float* y,
                                                            const float* save, int64_t B, int64_t T, int64_t W, int C, int CT,
                                                            int ph, int pw, double* acc) {
-  __shared__ double s1[256], s2[256];
+  __shared__ double s1[V][256], s2[V][256];
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT, RL = 256 / CT;
-  const int c = blockIdx.y * CT + cl;
+  const int c = (blockIdx.y * CT + cl) * V;
   const int64_t To = T / ph, Wo = W / pw, npos = B * To * Wo;
   const int64_t per = (npos + gridDim.x - 1) / gridDim.x, q0 = blockIdx.x * per, q1 = min(npos, q0 + per);
-  double a1 = 0.0, a2 = 0.0;
+  double a1[V], a2[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) a1[e] = a2[e] = 0.0;
   if (c < C) {
-    const float mean = save[c], invstd = save[C + c];
+    float mean[V], invstd[V];
+    ldv<V>(save + c, mean);
+    ldv<V>(save + C + c, invstd);
     for (int64_t q = q0 + rl; q < q1; q += RL) {
-      const float pv = p[q * C + c];
-      if (pv > 0.f) {
-        const float dz = dp[q * C + c];
-        const int k = idx[q * C + c];
-        const int64_t wo = q % Wo, to = (q / Wo) % To, b = q / (Wo * To);
-        const float yv = y[((b * T + to * ph + k / pw) * W + wo * pw + k % pw) * C + c];
-        a1 += (double)dz;
-        a2 += (double)(dz * ((yv - mean) * invstd));
-      }
+      float pv[V], dz[V];
+      int k[V];
+      ldv<V>(p + q * C + c, pv);
+      ldv<V>(dp + q * C + c, dz);
+      ldv<V>(idx + q * C + c, k);
+      const int64_t wo = q % Wo, to = (q / Wo) % To, b = q / (Wo * To);
+      const float* base = y + ((b * T + to * ph) * W + wo * pw) * C + c;
+#pragma unroll
+      for (int e = 0; e < V; ++e)
+        if (pv[e] > 0.f) {
+          const float yv = base[((int64_t)(k[e] / pw) * W + k[e] % pw) * C + e];
+          a1[e] += (double)dz[e];
+          a2[e] += (double)(dz[e] * ((yv - mean[e]) * invstd[e]));
+        }
     }
   }
-  s1[threadIdx.x] = a1; s2[threadIdx.x] = a2;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { s1[e][threadIdx.x] = a1[e]; s2[e][threadIdx.x] = a2[e]; }
   __syncthreads();
   if (rl == 0 && c < C) {
-    double t1 = 0.0, t2 = 0.0;
-    for (int k = 0; k < RL; ++k) { t1 += s1[k * CT + cl]; t2 += s2[k * CT + cl]; }
-    atomicAdd(acc + c, t1);
-    atomicAdd(acc + C + c, t2);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int k = 0; k < RL; ++k) { t1 += s1[e][k * CT + cl]; t2 += s2[e][k * CT + cl]; }
+      atomicAdd(acc + c + e, t1);
+      atomicAdd(acc + C + c + e, t2);
+    }
   }
 }
 
@@ -263,11 +320,12 @@ __global__ __launch_bounds__(256) void pool_bwd_sums_kernel(const float* dp, con
 // (batch norm in training mode), written inside a zero border of (bt, bw) pixels when the convolution's input
 // gradient is wanted next (its full correlation then reads the border in place).  Block 0 also adds the two
 // parameter gradients: dgamma += s2, dbeta += s1.
+template <int V>
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* dp, const float* p, const int32_t* idx, const float* y,
                                          const float* save, const float* gamma, const double* acc, int64_t B, int64_t T,
                                          int64_t W, int C, int ph, int pw, int bt, int bw, float* dy, float* dgamma,
                                          float* dbeta) {
-  // one workgroup per row (b, t) of the layer (blockIdx.x walks rows), threads over its W * C values
+  // one workgroup per row (b, t) of the layer (blockIdx.x walks rows), threads over its W * C values, V at a time
   const int64_t To = T / ph, Wo = W / pw;
   const double count = (double)(B * T * W);
   if (blockIdx.x == 0)
@@ -283,18 +341,35 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* dp,
     const float* yr = y + row * rowlen;
     float* dyr = dy + ((b * Tp + t + bt) * Wp + bw) * C;
     const int64_t qrow = (b * To + to) * Wo;              // first pooled pixel of the window row
-    for (int e = threadIdx.x; e < rowlen; e += 256) {
-      const int m = e / C, c = e - m * C;
-      const float mean = save[c], invstd = save[C + c];
-      const float xhat = (yr[e] - mean) * invstd;
+    for (int e0 = threadIdx.x * V; e0 < rowlen; e0 += 256 * V) {
+      const int m = e0 / C, c = e0 - m * C;
+      float yv[V], mean[V], invstd[V], gam[V], out[V], dz[V];
+      ldv<V>(yr + e0, yv);
+      ldv<V>(save + c, mean);
+      ldv<V>(save + C + c, invstd);
+      ldv<V>(gamma + c, gam);
       const int wo = m / pw;
-      float dz = 0.f;
+#pragma unroll
+      for (int e = 0; e < V; ++e) dz[e] = 0.f;
       if (to < To && wo < Wo) {
         const int64_t q = (qrow + wo) * C + c;
-        if (p[q] > 0.f && idx[q] == ti * pw + (m - wo * pw)) dz = dp[q];
+        const int want = ti * pw + (m - wo * pw);
+        float pv[V], dpv[V];
+        int k[V];
+        ldv<V>(p + q, pv);
+        ldv<V>(dp + q, dpv);
+        ldv<V>(idx + q, k);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (pv[e] > 0.f && k[e] == want) dz[e] = dpv[e];
       }
-      const float m1 = (float)(acc[c] / count), m2 = (float)(acc[C + c] / count);
-      dyr[e] = gamma[c] * invstd * (dz - m1 - xhat * m2);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xhat = (yv[e] - mean[e]) * invstd[e];
+        const float m1 = (float)(acc[c + e] / count), m2 = (float)(acc[C + c + e] / count);
+        out[e] = gam[e] * invstd[e] * (dz[e] - m1 - xhat * m2);
+      }
+      stv<V>(dyr + e0, out);
     }
   }
 }
@@ -376,6 +451,7 @@ __global__ void sl1_bwd_kernel(const float* pred, const float* x, int64_t B, int
   }
 }
 
+inline bool vec4_ok(int64_t C, const void* p) { return C % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int chan_tile(int64_t C) { return C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256)); }
 
 }  // namespace
@@ -494,8 +570,13 @@ extern "C" int ssasr_bn_stats(const float* y, int64_t rows, int64_t C, const flo
     int64_t gx = (rows + (256 / CT) * 64 - 1) / ((256 / CT) * 64);
     gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
     dim3 grid((unsigned)gx, (unsigned)((C + CT - 1) / CT));
-    hipLaunchKernelGGL((bn_sum_kernel<false>), grid, dim3(256), 0, st, y, rows, (int)C, CT, acc);
-    hipLaunchKernelGGL((bn_sum_kernel<true>), grid, dim3(256), 0, st, y, rows, (int)C, CT, acc);
+    if (vec4_ok(C, y)) {
+      hipLaunchKernelGGL((bn_sum_kernel<false, 4>), grid, dim3(256), 0, st, y, rows, (int)C, CT / 4, acc);
+      hipLaunchKernelGGL((bn_sum_kernel<true, 4>), grid, dim3(256), 0, st, y, rows, (int)C, CT / 4, acc);
+    } else {
+      hipLaunchKernelGGL((bn_sum_kernel<false, 1>), grid, dim3(256), 0, st, y, rows, (int)C, CT, acc);
+      hipLaunchKernelGGL((bn_sum_kernel<true, 1>), grid, dim3(256), 0, st, y, rows, (int)C, CT, acc);
+    }
     SSASR_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, acc, rows, (int)C, gamma, beta,
@@ -526,8 +607,12 @@ extern "C" int ssasr_bn_relu_pool_fwd(const float* y, const float* save, int64_t
   hipStream_t st = (hipStream_t)stream;
   const int64_t To = T / ph, Wo = W / pw;
   if (ph * pw < 64) {
-    hipLaunchKernelGGL(pool_fwd_small_kernel, dim3(stream_grid(B * To * Wo * C, 1)), dim3(256), 0, st, y, save, B, T, W, (int)C,
-                       (int)ph, (int)pw, p, idx);
+    if (vec4_ok(C, y) && vec4_ok(C, p) && vec4_ok(C, idx) && vec4_ok(C, save))
+      hipLaunchKernelGGL((pool_fwd_small_kernel<4>), dim3(stream_grid(B * To * Wo * C / 4, 1)), dim3(256), 0, st, y, save, B, T, W, (int)C,
+                         (int)ph, (int)pw, p, idx);
+    else
+      hipLaunchKernelGGL((pool_fwd_small_kernel<1>), dim3(stream_grid(B * To * Wo * C, 1)), dim3(256), 0, st, y, save, B, T, W, (int)C,
+                         (int)ph, (int)pw, p, idx);
   } else {
     if (!ws || B * To * Wo > 0x7fffffff) return SSASR_EARG;
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(bn_acc(ws));
@@ -560,11 +645,19 @@ extern "C" int ssasr_bn_relu_pool_bwd(const float* dp, const float* p, const int
   const int64_t npos = B * (T / ph) * (W / pw);
   int64_t gx = (npos + (256 / CT) * 16 - 1) / ((256 / CT) * 16);
   gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
-  hipLaunchKernelGGL(pool_bwd_sums_kernel, dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
-                     B, T, W, (int)C, CT, (int)ph, (int)pw, acc);
   const int64_t nrows = B * T;
-  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3((unsigned)(nrows > 65536 ? 65536 : nrows)), dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
-                     B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
+  const dim3 rgrid((unsigned)(nrows > 65536 ? 65536 : nrows));
+  if (vec4_ok(C, dp) && vec4_ok(C, p) && vec4_ok(C, idx) && vec4_ok(C, y) && vec4_ok(C, save) && vec4_ok(C, gamma) && vec4_ok(C, dy)) {
+    hipLaunchKernelGGL((pool_bwd_sums_kernel<4>), dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
+                       B, T, W, (int)C, CT / 4, (int)ph, (int)pw, acc);
+    hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<4>), rgrid, dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
+                       B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
+  } else {
+    hipLaunchKernelGGL((pool_bwd_sums_kernel<1>), dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
+                       B, T, W, (int)C, CT, (int)ph, (int)pw, acc);
+    hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<1>), rgrid, dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
+                       B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
+  }
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
 }

@@ -294,3 +294,151 @@ def test_two_ranks_on_one_gpu_follow_the_section_8e_statement_on_the_real_step(t
             got = ranks[r]['probe'][n]
             assert max(abs(a - b) for a, b in zip(got, want)) < 5e-5, (r, n)
     assert ranks[0]['probe'] == ranks[1]['probe']
+
+
+# ---- the Seed loop's ADV and SAE legs under data parallelism: two gloo ranks on the one GPU -------------------------
+# Each rank runs ONE iteration of engine.ADVTrainStep / engine.SAETrainStep on its own batch; a single-process child
+# computes what plain data parallelism must give: every optimizer stepped once on the MEAN of the two ranks'
+# gradients (for ADV: the discriminator first, then the generator pass of BOTH batches through the updated
+# discriminator).  The ranks share the GPU, so a file lock keeps their persistent launches apart; it is released
+# around every gradient all-reduce, where the ranks must meet.
+SEED_COMMON = DDP_COMMON + r'''
+from ss_asr_amd.discriminator import Discriminator
+from ss_asr_amd.engine import ADVTrainStep, SAETrainStep
+from ss_asr_amd.speech_autoencoder import SpeechAutoEncoder
+from ss_asr_amd.text_autoencoder import TextAutoEncoder
+LEG = os.environ['SSASR_TEST_LEG']
+def seed_batch(k):
+    return make_batch(np.array([208 - 16 * k, 160, 96 + 8 * k, 40]), np.array([14, 9 + k, 6, 3]), 80, seed=90 + k, pad_to=208)
+def models():
+    torch.manual_seed(0)
+    asr = model()
+    tae = TextAutoEncoder(50, 128, 256, 2); lo.seeded_tae_weights(tae, 10)
+    if LEG == 'adv':
+        other = Discriminator(512, 256); lo.seeded_generic_weights(other, 11)
+    else:
+        other = SpeechAutoEncoder(512, 80, [[1, 36], [5, 1], [3, 1]], [32, 64, 256], [[3, 1], [5, 1], [11, 40]])
+        lo.seeded_generic_weights(other, 12)
+    return asr, tae.to('cuda:0'), other.to('cuda:0')
+def make_step(asr, tae, other):
+    return ADVTrainStep(asr, tae, other) if LEG == 'adv' else SAETrainStep(asr, other)
+def run(step, k):
+    x, y, lens = seed_batch(k)
+    return step(x.cuda(), lens, y.cuda()) if LEG == 'adv' else step(x.cuda(), lens)
+def seed_report(asr, other, **kw):
+    kw['other_wsum'] = float(torch.cat([t.detach().reshape(-1) for t in other.parameters()]).double().abs().sum())
+    kw['other_probe'] = next(other.parameters()).detach().reshape(-1)[:64].double().cpu().tolist()
+    report(asr, **kw)
+'''
+
+SEED_RANK = SEED_COMMON + r'''
+import fcntl
+rank, world, local = sdist.init_from_env()
+assert world == 2 and sdist.is_active()
+torch.cuda.set_device(0)
+asr, tae, other = models()
+step = make_step(asr, tae, other)
+lockf = open(os.environ['SSASR_TEST_LOCK'], 'w')
+real_ar = sdist.allreduce_grad
+def meet(g):
+    ops.join_side_stream(); torch.cuda.synchronize()
+    fcntl.flock(lockf, fcntl.LOCK_UN)
+    r = real_ar(g)
+    torch.cuda.synchronize()
+    fcntl.flock(lockf, fcntl.LOCK_EX)
+    return r
+sdist.allreduce_grad = meet
+import ss_asr_amd.engine as eng
+eng.sdist.allreduce_grad = meet
+fcntl.flock(lockf, fcntl.LOCK_EX)
+out = run(step, rank)
+torch.cuda.synchronize()
+fcntl.flock(lockf, fcntl.LOCK_UN)
+norm, skipped = step.finish()
+losses = [float(v) for v in out] if LEG == 'adv' else [float(out)]
+seed_report(asr, other, rank=rank, losses=losses, norm=norm, skipped=bool(skipped))
+sdist.shutdown()
+'''
+
+SEED_SINGLE = SEED_COMMON + r'''
+from ss_asr_amd.seed_ops import bce_loss
+torch.cuda.set_device(0)
+asr, tae, other = models()
+step = make_step(asr, tae, other)
+one = torch.ones((), device='cuda:0')
+def sync():
+    ops.join_side_stream(); torch.cuda.synchronize(); ops.check_persistent_status()
+losses = []
+if LEG == 'sae':
+    total_s, total_a = torch.zeros_like(step.sae_flat.grad), torch.zeros_like(step.asr_flat.grad)
+    for k in (0, 1):
+        step.sae_flat.zero_grad(); step.asr_flat.zero_grad()
+        x, _, lens = seed_batch(k)
+        loss, _ = step.forward_loss(x.cuda(), lens)
+        loss.backward(one); sync()
+        losses.append([float(loss)])
+        total_s += step.sae_flat.grad; total_a += step.asr_flat.grad
+    step.sae_flat.grad.copy_(total_s); step.asr_flat.grad.copy_(total_a)
+    step.optim.clip_and_step(5.0, grad_scale=0.5)
+    norm, skipped = step.optim.poll(wait=True)
+else:
+    # discriminator: both batches' two passes, one step on the mean
+    fakes, total = [], torch.zeros_like(step.d_flat.grad)
+    step.asr_flat.zero_grad()
+    for k in (0, 1):
+        step.d_flat.zero_grad()
+        x, y, lens = seed_batch(k)
+        real, fake = step.frames(x.cuda(), lens, y.cuda())
+        d_real = bce_loss(step.disc(real), 0.9); d_real.backward(one)
+        d_fake = bce_loss(step.disc(fake.detach()), 0.0); d_fake.backward(one)
+        sync()
+        losses.append([float(d_real), float(d_fake)])
+        fakes.append(fake)
+        total += step.d_flat.grad
+    step.d_flat.grad.copy_(total)
+    step.D_optim.clip_and_step(5.0, grad_scale=0.5)
+    assert not step.D_optim.poll(wait=True)[1]
+    # generator: both batches through the updated discriminator, one step on the mean
+    for k in (0, 1):
+        g = bce_loss(step.disc(fakes[k], frozen=True), 1.0)
+        g.backward(one); sync()
+        losses[k].append(float(g))
+    step.G_optim.clip_and_step(5.0, grad_scale=0.5)
+    norm, skipped = step.G_optim.poll(wait=True)
+assert not skipped
+seed_report(asr, other, losses=losses, norm=norm, skipped=False)
+'''
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('leg', ['adv', 'sae'])
+def test_two_ranks_run_the_seed_loops_other_legs_as_plain_data_parallelism(tmp_path, leg):
+    base = dict(os.environ, SSASR_TEST_LEG=leg)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND', 'SSASR_DDP_NO_OVERLAP'):
+        base.pop(k, None)
+    single = _result(_child(SEED_SINGLE, base), 420)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    lock = str(tmp_path / 'gpu.lock')
+    procs = [_child(SEED_RANK, dict(base, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                                    MASTER_PORT=str(port), SSASR_DIST_BACKEND='gloo', SSASR_TEST_LOCK=lock)) for r in range(2)]
+    try:
+        ranks = [_result(p, 600) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    ranks.sort(key=lambda d: d['rank'])
+    assert not any(d['skipped'] for d in ranks)
+    for r in range(2):
+        # rank-local losses = the single-process losses on that batch (ADV: its generator loss is taken through the
+        # discriminator updated with the MEAN gradient, as in the single-process run)
+        assert max(abs(a - b) for a, b in zip(ranks[r]['losses'], single['losses'][r])) < 5e-6, (r, ranks[r]['losses'], single['losses'])
+        assert abs(ranks[r]['norm'] - single['norm']) < 5e-5 * max(1.0, single['norm'])
+        assert abs(ranks[r]['wsum'] - single['wsum']) < 1e-6 * single['wsum']
+        assert abs(ranks[r]['other_wsum'] - single['other_wsum']) < 1e-6 * single['other_wsum']
+        for n, want in single['probe'].items():
+            assert max(abs(a - b) for a, b in zip(ranks[r]['probe'][n], want)) < 5e-5, (r, n)
+        assert max(abs(a - b) for a, b in zip(ranks[r]['other_probe'], single['other_probe'])) < 5e-5
+    assert ranks[0]['probe'] == ranks[1]['probe'] and ranks[0]['other_probe'] == ranks[1]['other_probe']
