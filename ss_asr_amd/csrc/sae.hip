@@ -116,67 +116,90 @@ template <int V> __device__ __forceinline__ void stv(int32_t* p, const int (&v)[
   else *p = v[0];
 }
 
-// per-channel sums over the rows of a channels-last [rows][C] tensor, in double:
-//   CENTERED = false: acc[c] += sum_r y[r][c];  true: acc[C + c] += sum_r (y[r][c] - acc[c] / rows)^2
+// Per-channel first and second moments of a channels-last [rows][C] tensor in ONE pass, shifted by the channel's
+// first value s[c] = y[0][c] (a sample lies within a few standard deviations of the mean, so
+// var = (S2 - S1^2 / n) / n cancels nothing that matters once S1, S2 are carried in double):
+//   partial[blk][c] = sum_r (y[r][c] - s[c]),  partial[blk][C + c] = sum_r (y[r][c] - s[c])^2
+// over the block's rows -- fp32 over runs of <= 64 values on four independent chains, double across runs.  Every
+// workgroup writes its own partials (no atomics: 2,048 workgroups adding into 32 addresses was the kernel's
+// bound; and the result is deterministic); the finalize kernel adds them in a fixed order.
 // A thread owns V consecutive channels (CT groups of V channels per row, 256 / CT rows per pass).
-template <bool CENTERED, int V>
-__global__ __launch_bounds__(256) void bn_sum_kernel(const float* y, int64_t rows, int C, int CT, double* acc) {
-  __shared__ double sm[V][256];
+constexpr int BN_BLOCKS = 512;
+template <int V>
+__global__ __launch_bounds__(256) void bn_moments_kernel(const float* y, int64_t rows, int C, int CT, double* partial) {
+  __shared__ double sm[2 * V][256];
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT, RL = 256 / CT;
   const int c = (blockIdx.y * CT + cl) * V;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
-  float mean[V];
-  double tot[V];
+  float shift[V];
+  double t1[V], t2[V];
 #pragma unroll
-  for (int e = 0; e < V; ++e) { mean[e] = (CENTERED && c < C) ? (float)(acc[c + e] / (double)rows) : 0.f; tot[e] = 0.0; }
+  for (int e = 0; e < V; ++e) { shift[e] = 0.f; t1[e] = t2[e] = 0.0; }
   if (c < C) {
-    auto add = [&](float (&p)[V], int64_t r) {
+    ldv<V>(y + c, shift);
+    auto add = [&](float (&p)[V], float (&q)[V], int64_t r) {
       float v[V];
       ldv<V>(y + r * C + c, v);
 #pragma unroll
-      for (int e = 0; e < V; ++e) { const float d = v[e] - mean[e]; p[e] += CENTERED ? d * d : d; }
+      for (int e = 0; e < V; ++e) { const float d = v[e] - shift[e]; p[e] += d; q[e] = fmaf(d, d, q[e]); }
     };
     int64_t r = r0 + rl;
     while (r < r1) {
-      float p0[V], p1[V], p2[V], p3[V];        // fp32 over a short run (four chains), double across runs
+      float p0[V], p1[V], p2[V], p3[V], q0[V], q1[V], q2[V], q3[V];
 #pragma unroll
-      for (int e = 0; e < V; ++e) p0[e] = p1[e] = p2[e] = p3[e] = 0.f;
+      for (int e = 0; e < V; ++e) p0[e] = p1[e] = p2[e] = p3[e] = q0[e] = q1[e] = q2[e] = q3[e] = 0.f;
       int k = 0;
       for (; k < 16 && r + 3 * (int64_t)RL < r1; ++k, r += 4 * (int64_t)RL) {
-        add(p0, r); add(p1, r + RL); add(p2, r + 2 * (int64_t)RL); add(p3, r + 3 * (int64_t)RL);
+        add(p0, q0, r); add(p1, q1, r + RL); add(p2, q2, r + 2 * (int64_t)RL); add(p3, q3, r + 3 * (int64_t)RL);
       }
       if (k < 16)
-        for (; r < r1; r += RL) add(p0, r);
+        for (; r < r1; r += RL) add(p0, q0, r);
 #pragma unroll
-      for (int e = 0; e < V; ++e) tot[e] += (double)((p0[e] + p1[e]) + (p2[e] + p3[e]));
+      for (int e = 0; e < V; ++e) {
+        t1[e] += (double)((p0[e] + p1[e]) + (p2[e] + p3[e]));
+        t2[e] += (double)((q0[e] + q1[e]) + (q2[e] + q3[e]));
+      }
     }
   }
 #pragma unroll
-  for (int e = 0; e < V; ++e) sm[e][threadIdx.x] = tot[e];
+  for (int e = 0; e < V; ++e) { sm[e][threadIdx.x] = t1[e]; sm[V + e][threadIdx.x] = t2[e]; }
   __syncthreads();
-  if (rl == 0 && c < C) {
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
+  // thread (cl, rl) adds columns rl, rl + RL, ... of the 2 V columns of its channel group over the row lanes
+  if (c < C)
+    for (int col = rl; col < 2 * V; col += RL) {
       double t = 0.0;
-      for (int k = 0; k < RL; ++k) t += sm[e][k * CT + cl];
-      atomicAdd(acc + (CENTERED ? C : 0) + c + e, t);
+      for (int k = 0; k < RL; ++k) t += sm[col][k * CT + cl];
+      partial[(int64_t)blockIdx.x * 2 * C + (col < V ? 0 : C) + c + (col % V)] = t;
     }
+}
+
+// acc[k] = sum over the nblk workgroups' partial[blk][k], k < n (fixed order)
+__global__ void bn_reduce_kernel(const double* partial, int nblk, int n, double* acc) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    double t = 0.0;
+    for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * n + k];
+    acc[k] = t;
   }
 }
 
 // save[0][c] mean, [1] 1 / sqrt(var + eps), [2] scale = gamma * invstd, [3] shift = beta - mean * scale;
-// training: batch statistics (biased variance), running statistics updated with the unbiased one
-// (nn.BatchNorm2d, momentum 0.1); eval: the running statistics.
-__global__ void bn_finalize_kernel(const double* acc, int64_t rows, int C, const float* gamma, const float* beta,
-                                   float* running_mean, float* running_var, float momentum, float eps, int training,
-                                   float* save) {
+// training: batch statistics (biased variance) from the shifted moments, running statistics updated with the
+// unbiased variance (nn.BatchNorm2d, momentum 0.1); eval: the running statistics.
+__global__ void bn_finalize_kernel(const double* partial, int nblk, const float* y, int64_t rows, int C, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                   int training, float* save) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
     float mean, var;
     if (training) {
-      mean = (float)(acc[c] / (double)rows);
-      var = (float)(acc[C + c] / (double)rows);
-      const float unbiased = rows > 1 ? (float)(acc[C + c] / (double)(rows - 1)) : var;
+      double s1 = 0.0, s2 = 0.0;
+      for (int b = 0; b < nblk; ++b) { s1 += partial[(int64_t)b * 2 * C + c]; s2 += partial[(int64_t)b * 2 * C + C + c]; }
+      const double n = (double)rows;
+      double m2 = s2 - s1 * s1 / n;                       // sum of squared deviations from the mean
+      if (m2 < 0.0) m2 = 0.0;
+      mean = (float)((double)y[c] + s1 / n);
+      var = (float)(m2 / n);
+      const float unbiased = rows > 1 ? (float)(m2 / (double)(rows - 1)) : var;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     } else {
@@ -272,7 +295,7 @@ __global__ void pool_unpack_kernel(const unsigned long long* keys, int64_t n, fl
 template <int V>
 __global__ __launch_bounds__(256) void pool_bwd_sums_kernel(const float* dp, const float* p, const int32_t* idx, const float* y,
                                                            const float* save, int64_t B, int64_t T, int64_t W, int C, int CT,
-                                                           int ph, int pw, double* acc) {
+                                                           int ph, int pw, double* partial) {
   __shared__ double s1[V][256], s2[V][256];
   const int cl = threadIdx.x % CT, rl = threadIdx.x / CT, RL = 256 / CT;
   const int c = (blockIdx.y * CT + cl) * V;
@@ -310,8 +333,8 @@ __global__ __launch_bounds__(256) void pool_bwd_sums_kernel(const float* dp, con
     for (int e = 0; e < V; ++e) {
       double t1 = 0.0, t2 = 0.0;
       for (int k = 0; k < RL; ++k) { t1 += s1[e][k * CT + cl]; t2 += s2[e][k * CT + cl]; }
-      atomicAdd(acc + c + e, t1);
-      atomicAdd(acc + C + c + e, t2);
+      partial[(int64_t)blockIdx.x * 2 * C + c + e] = t1;            // (per workgroup: no atomics, fixed order later)
+      partial[(int64_t)blockIdx.x * 2 * C + C + c + e] = t2;
     }
   }
 }
@@ -554,7 +577,8 @@ extern "C" int ssasr_conv2d_bwd(const float* dy, int dy_bordered, const float* x
   return SSASR_OK;
 }
 
-extern "C" int64_t ssasr_bn_ws_floats(int64_t C) { return 4 * C + 8; }        // 2 C doubles (+ alignment slack)
+// 2 C doubles of sums + BN_BLOCKS x 2 C doubles of per-workgroup partials (+ alignment slack)
+extern "C" int64_t ssasr_bn_ws_floats(int64_t C) { return 2 * (2 * C + (int64_t)BN_BLOCKS * 2 * C) + 8; }
 
 static double* bn_acc(float* ws) { return reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7); }
 
@@ -563,23 +587,19 @@ extern "C" int ssasr_bn_stats(const float* y, int64_t rows, int64_t C, const flo
                               float* save, void* stream) {
   if (!y || !gamma || !beta || !running_mean || !running_var || !ws || !save || rows <= 0 || C <= 0) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
-  double* acc = bn_acc(ws);
+  double* partial = bn_acc(ws) + 2 * C;
+  int nblk = 0;
   if (training) {
-    SSASR_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st));
     const int CT = chan_tile(C);
     int64_t gx = (rows + (256 / CT) * 64 - 1) / ((256 / CT) * 64);
-    gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
+    gx = gx < 1 ? 1 : (gx > BN_BLOCKS ? BN_BLOCKS : gx);
+    nblk = (int)gx;
     dim3 grid((unsigned)gx, (unsigned)((C + CT - 1) / CT));
-    if (vec4_ok(C, y)) {
-      hipLaunchKernelGGL((bn_sum_kernel<false, 4>), grid, dim3(256), 0, st, y, rows, (int)C, CT / 4, acc);
-      hipLaunchKernelGGL((bn_sum_kernel<true, 4>), grid, dim3(256), 0, st, y, rows, (int)C, CT / 4, acc);
-    } else {
-      hipLaunchKernelGGL((bn_sum_kernel<false, 1>), grid, dim3(256), 0, st, y, rows, (int)C, CT, acc);
-      hipLaunchKernelGGL((bn_sum_kernel<true, 1>), grid, dim3(256), 0, st, y, rows, (int)C, CT, acc);
-    }
+    if (vec4_ok(C, y)) hipLaunchKernelGGL((bn_moments_kernel<4>), grid, dim3(256), 0, st, y, rows, (int)C, CT / 4, partial);
+    else hipLaunchKernelGGL((bn_moments_kernel<1>), grid, dim3(256), 0, st, y, rows, (int)C, CT, partial);
     SSASR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, acc, rows, (int)C, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, partial, nblk, y, rows, (int)C, gamma, beta,
                      running_mean, running_var, momentum, eps, training, save);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
@@ -638,23 +658,25 @@ extern "C" int ssasr_bn_relu_pool_bwd(const float* dp, const float* p, const int
     return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
   double* acc = bn_acc(ws);
-  SSASR_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st));
+  double* partial = acc + 2 * C;
   if (border_t || border_w)
     SSASR_HIP(hipMemsetAsync(dy, 0, sizeof(float) * B * (T + 2 * border_t) * (W + 2 * border_w) * C, st));
   const int CT = chan_tile(C);
   const int64_t npos = B * (T / ph) * (W / pw);
   int64_t gx = (npos + (256 / CT) * 16 - 1) / ((256 / CT) * 16);
-  gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
+  gx = gx < 1 ? 1 : (gx > BN_BLOCKS ? BN_BLOCKS : gx);
   const int64_t nrows = B * T;
   const dim3 rgrid((unsigned)(nrows > 65536 ? 65536 : nrows));
   if (vec4_ok(C, dp) && vec4_ok(C, p) && vec4_ok(C, idx) && vec4_ok(C, y) && vec4_ok(C, save) && vec4_ok(C, gamma) && vec4_ok(C, dy)) {
     hipLaunchKernelGGL((pool_bwd_sums_kernel<4>), dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
-                       B, T, W, (int)C, CT / 4, (int)ph, (int)pw, acc);
+                       B, T, W, (int)C, CT / 4, (int)ph, (int)pw, partial);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, partial, (int)gx, (int)(2 * C), acc);
     hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<4>), rgrid, dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
                        B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
   } else {
     hipLaunchKernelGGL((pool_bwd_sums_kernel<1>), dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
-                       B, T, W, (int)C, CT, (int)ph, (int)pw, acc);
+                       B, T, W, (int)C, CT, (int)ph, (int)pw, partial);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, partial, (int)gx, (int)(2 * C), acc);
     hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<1>), rgrid, dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
                        B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
   }
