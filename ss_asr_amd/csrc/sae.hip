@@ -174,42 +174,54 @@ __global__ __launch_bounds__(256) void bn_moments_kernel(const float* y, int64_t
     }
 }
 
-// acc[k] = sum over the nblk workgroups' partial[blk][k], k < n (fixed order)
-__global__ void bn_reduce_kernel(const double* partial, int nblk, int n, double* acc) {
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-    double t = 0.0;
-    for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * n + k];
-    acc[k] = t;
-  }
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// acc[k] = sum over the nblk workgroups' partial[blk][k]: one wave per k (lane l adds blocks l, l + 64, ... in
+// order, then a fixed butterfly: deterministic)
+__global__ __launch_bounds__(64) void bn_reduce_kernel(const double* partial, int nblk, int n, double* acc) {
+  const int k = blockIdx.x;
+  double t = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) t += partial[(int64_t)b * n + k];
+  t = wave_sum_d(t);
+  if (threadIdx.x == 0) acc[k] = t;
 }
 
 // save[0][c] mean, [1] 1 / sqrt(var + eps), [2] scale = gamma * invstd, [3] shift = beta - mean * scale;
 // training: batch statistics (biased variance) from the shifted moments, running statistics updated with the
-// unbiased variance (nn.BatchNorm2d, momentum 0.1); eval: the running statistics.
-__global__ void bn_finalize_kernel(const double* partial, int nblk, const float* y, int64_t rows, int C, const float* gamma,
-                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                   int training, float* save) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-    float mean, var;
-    if (training) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int b = 0; b < nblk; ++b) { s1 += partial[(int64_t)b * 2 * C + c]; s2 += partial[(int64_t)b * 2 * C + C + c]; }
-      const double n = (double)rows;
-      double m2 = s2 - s1 * s1 / n;                       // sum of squared deviations from the mean
-      if (m2 < 0.0) m2 = 0.0;
-      mean = (float)((double)y[c] + s1 / n);
-      var = (float)(m2 / n);
-      const float unbiased = rows > 1 ? (float)(m2 / (double)(rows - 1)) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-    } else {
-      mean = running_mean[c];
-      var = running_var[c];
-    }
-    const float invstd = 1.0f / sqrtf(var + eps);
-    const float scale = gamma[c] * invstd;
-    save[c] = mean; save[C + c] = invstd; save[2 * C + c] = scale; save[3 * C + c] = beta[c] - mean * scale;
+// unbiased variance (nn.BatchNorm2d, momentum 0.1); eval: the running statistics.  One wave per channel.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* partial, int nblk, const float* y, int64_t rows, int C,
+                                                        const float* gamma, const float* beta, float* running_mean,
+                                                        float* running_var, float momentum, float eps, int training,
+                                                        float* save) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  if (training) {
+    for (int b = threadIdx.x; b < nblk; b += 64) { s1 += partial[(int64_t)b * 2 * C + c]; s2 += partial[(int64_t)b * 2 * C + C + c]; }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
   }
+  if (threadIdx.x != 0) return;
+  float mean, var;
+  if (training) {
+    const double n = (double)rows;
+    double m2 = s2 - s1 * s1 / n;                       // sum of squared deviations from the mean
+    if (m2 < 0.0) m2 = 0.0;
+    mean = (float)((double)y[c] + s1 / n);
+    var = (float)(m2 / n);
+    const float unbiased = rows > 1 ? (float)(m2 / (double)(rows - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float scale = gamma[c] * invstd;
+  save[c] = mean; save[C + c] = invstd; save[2 * C + c] = scale; save[3 * C + c] = beta[c] - mean * scale;
 }
 
 // ------------------------------------------------------------------ normalise + ReLU + max pool ----
@@ -599,7 +611,7 @@ extern "C" int ssasr_bn_stats(const float* y, int64_t rows, int64_t C, const flo
     else hipLaunchKernelGGL((bn_moments_kernel<1>), grid, dim3(256), 0, st, y, rows, (int)C, CT, partial);
     SSASR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, partial, nblk, y, rows, (int)C, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, nblk, y, rows, (int)C, gamma, beta,
                      running_mean, running_var, momentum, eps, training, save);
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
@@ -670,13 +682,13 @@ extern "C" int ssasr_bn_relu_pool_bwd(const float* dp, const float* p, const int
   if (vec4_ok(C, dp) && vec4_ok(C, p) && vec4_ok(C, idx) && vec4_ok(C, y) && vec4_ok(C, save) && vec4_ok(C, gamma) && vec4_ok(C, dy)) {
     hipLaunchKernelGGL((pool_bwd_sums_kernel<4>), dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
                        B, T, W, (int)C, CT / 4, (int)ph, (int)pw, partial);
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, partial, (int)gx, (int)(2 * C), acc);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)(2 * C)), dim3(64), 0, st, partial, (int)gx, (int)(2 * C), acc);
     hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<4>), rgrid, dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
                        B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
   } else {
     hipLaunchKernelGGL((pool_bwd_sums_kernel<1>), dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
                        B, T, W, (int)C, CT, (int)ph, (int)pw, partial);
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(64), 0, st, partial, (int)gx, (int)(2 * C), acc);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)(2 * C)), dim3(64), 0, st, partial, (int)gx, (int)(2 * C), acc);
     hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<1>), rgrid, dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
                        B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
   }
