@@ -913,7 +913,7 @@ def main():
         note('config 4: %s' % out['config4'])
     if world == 1 and not args.no_config4:
         out['config5'] = config5_bench(device)
-        note('config 5 (TAE leg): %s' % out['config5'])
+        note('config 5 (Seed loop legs): %s' % out['config5'])
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline([host_batches[k] for k in (2, 4, 6)])
     print(json.dumps(out), flush=True)

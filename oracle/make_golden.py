@@ -526,10 +526,13 @@ def main(only=None):
                               pool_kernel_sizes=[[2, 1], [1, 2], [28, 3]]),
                          [[64, 56, 48, 40], [61, 50, 33, 17], [56, 56, 41, 24]], 64, 62, opt=('Adam', 1e-3))
     # the yaml's speech autoencoder AS SHIPPED (conf/default.yaml:27-30): its last pooling window [2000, 40] only fits
-    # utterances of 30,050 .. 60,000 frames (five to ten minutes of audio) -- two of them, one iteration, full layer
-    # sizes: the Listener's recurrences run 30,100 / 15,050 / 7,525 steps.  Minutes of reference CPU time: on request
+    # utterances of 30,050 .. 60,000 frames (five to ten minutes of audio) -- two of them, one iteration; the
+    # Listener's recurrences run 30,100 / 15,050 / 7,525 steps.  Listener of 64 units per direction (the smallest
+    # width whose recurrences take the persistent kernels): at the full 256 the reference's CPU backward -- a 5 MB
+    # weight-gradient accumulation per time step and direction -- did not finish within 50 minutes on 8 cores.
+    # Minutes of reference CPU time all the same: on request
     if only and 'sae_yaml_b2_t30100' in only:
-        capture_sae_traj(asr_mod, sae_mod, 'sae_yaml_b2_t30100', full,
+        capture_sae_traj(asr_mod, sae_mod, 'sae_yaml_b2_t30100', (50, 64, 64, 32, 80),
                          dict(kernel_sizes=[[1, 36], [5, 1], [3, 1]], num_filters=[32, 64, 256],
                               pool_kernel_sizes=[[3, 1], [5, 1], [2000, 40]]),
                          [[30100, 27013]], 30100, 63)

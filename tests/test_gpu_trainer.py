@@ -462,14 +462,17 @@ def _sae_models(fx):
     return asr.to('cuda:0'), sae.to('cuda:0'), dims
 
 
-@pytest.mark.parametrize('name', ['sae_traj_full_b8', 'sae_traj_small'])
+@pytest.mark.parametrize('name', ['sae_traj_full_b8', 'sae_traj_small', 'sae_yaml_b2_t30100'])
 def test_sae_train_steps_follow_the_reference_trajectory(golden, name):
     """Config 5's third leg (SAETrainer, src/trainer.py:760-907): three engine.SAETrainStep iterations against the
     trajectory captured from the reference's SpeechAutoEncoder + Listener classes: loss and clipped norm (the
     speech autoencoder's alone) of every iteration, per-tensor norms of the total update, final weights AND
     batch-norm buffers of both models, an eval-mode prediction (running statistics); the full-size case with the
     yaml's kernels and filters (windows read in place), the small one with the docstring's orientation
-    (im2col path, odd filter counts).  Everything behind the Listener must come out untouched."""
+    (im2col path, odd filter counts); and the yaml's speech autoencoder AS SHIPPED, whose last pooling window
+    [2000, 40] only fits utterances of five to ten minutes: two utterances of 30,100 / 27,013 frames, one iteration
+    (the Listener's persistent recurrences run 30,100 steps, the last pooling reduces 80,000 values per output).
+    Everything behind the Listener must come out untouched."""
     from ss_asr_amd.engine import SAETrainStep
     from ss_asr_amd.synthetic import make_batch
     fx = golden(name)
