@@ -1,6 +1,8 @@
 """A few steps of ONE leg of the Seed loop at the bench shape (bench.config5_bench's models and batches), for a
 profiler: `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sae -- python3 tools/seed_steps.py sae 10`.
-Legs: tae, adv, sae.  Prints the wall time per step."""
+Legs: tae, adv, sae, or `round`: all three in the reference's order on the one ASR object, cycling over four of the
+corpus' batches (a soak: every 50 rounds the step objects' status words are collected -- a hand-off time-out raises).
+Prints the wall time per step."""
 import os
 import sys
 import time
@@ -37,6 +39,33 @@ if leg == 'sae':
 elif leg == 'adv':
     step = ADVTrainStep(asr, tae, Discriminator(asr.encoder.get_outdim(), 256).to(dev))
     run = lambda: step(x, lens, y)
+elif leg == 'round':
+    sae = SpeechAutoEncoder(asr.encoder.out_dim, D['feature_dim'], [[1, 36], [5, 1], [3, 1]], [32, 64, 256],
+                            [[3, 1], [5, 1], [50, 40]]).to(dev)
+    steps3 = (TAETrainStep(asr, tae), ADVTrainStep(asr, tae, Discriminator(asr.encoder.get_outdim(), 256).to(dev)),
+              SAETrainStep(asr, sae))
+    data = []
+    for bx, by, bl in config2_batches(4, batch_size=32, feat_dim=D['feature_dim'], seed=1):
+        b800 = torch.zeros(bx.shape[0], 800, bx.shape[2])
+        b800[:, :bx.shape[1]] = bx
+        data.append((bx.to(dev), by.to(dev), bl, [int(v) + 1 for v in (by != 0).sum(-1)], b800.to(dev)))
+    count = [0]
+
+    class step:                                    # (finish() of all three)
+        @staticmethod
+        def finish():
+            for s3 in steps3:
+                s3.finish()
+
+    def run():
+        bx, by, bl, yl, b800 = data[count[0] % len(data)]
+        steps3[0](by, by, yl, yl)
+        steps3[1](bx, bl, by)
+        loss = steps3[2](b800, bl)
+        count[0] += 1
+        if count[0] % 50 == 0:
+            step.finish()
+            print('round %d: sae loss %.4f' % (count[0], float(loss)), flush=True)
 else:
     step = TAETrainStep(asr, tae)
     y_lens = [int(v) + 1 for v in (y != 0).sum(-1)]
