@@ -204,3 +204,43 @@ def test_frame_decoder_input_and_smooth_l1_match_torch():
     (3.0 * got).backward()
     assert abs(float(got) - float(want)) < 2e-6 * max(1.0, float(want))
     np.testing.assert_allclose(pg.grad.cpu().numpy(), prr.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_speech_autoencoder_module_matches_the_oracle_module():
+    """speech_autoencoder.SpeechAutoEncoder against the oracle's module from the same state_dict: the training-mode
+    forward (and the running statistics it leaves), `just_first` (src/speech_autoencoder.py:66-67: the first Listener
+    frame alone), the eval-mode forward, and a kernel that does not fit its input (torch raises there too)."""
+    import las_oracle as lo
+    from ss_asr_amd.speech_autoencoder import SpeechAutoEncoder
+    cfg = ([[1, 5], [3, 1], [2, 2]], [8, 12, 16], [[2, 1], [3, 1], [4, 3]])
+    ref = lo.OracleSpeechAutoEncoder(24, 12, *cfg)
+    lo.seeded_generic_weights(ref, 77)
+    mine = SpeechAutoEncoder(24, 12, *cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda()
+    g = torch.Generator().manual_seed(3)
+    # 36 frames: conv [1, 5] -> 36 x 8, pool [2, 1] -> 18, conv [3, 1] -> 16, pool [3, 1] -> 5 x 8, conv [2, 2] -> 4 x 7,
+    # pool [4, 3] -> 1 x 2?  no: 7 // 3 = 2 columns -> the module must refuse; 33 frames likewise.  Use W that leaves 1:
+    x = torch.randn(3, 36, 12, generator=g)
+    lis = torch.randn(3, 4, 24, generator=g)
+    with pytest.raises(RuntimeError):
+        mine(x.cuda(), lis.cuda())                       # last pooling leaves 1 x 2 values per filter
+    cfg = ([[1, 5], [3, 1], [2, 2]], [8, 12, 16], [[2, 1], [3, 1], [4, 7]])
+    ref = lo.OracleSpeechAutoEncoder(24, 12, *cfg)
+    lo.seeded_generic_weights(ref, 78)
+    mine = SpeechAutoEncoder(24, 12, *cfg)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.cuda()
+    for kw in ({}, {'just_first': True}):
+        want = ref(x, lis, **kw)
+        got = mine(x.cuda(), lis.cuda(), **kw)
+        assert got.shape == want.shape
+        assert float((got.cpu() - want).abs().max()) < 2e-5
+    for k, v in ref.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            np.testing.assert_allclose(mine.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        assert float((mine(x.cuda(), lis.cuda()).cpu() - ref(x, lis)).abs().max()) < 2e-5
+    with pytest.raises(RuntimeError):
+        mine(x[:, :5].cuda(), lis.cuda())                # 5 frames: nothing left for the second block

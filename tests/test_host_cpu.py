@@ -424,3 +424,29 @@ def test_flat_shims_bind_the_product_modules():
     res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=120)
     assert res.returncode == 0 and 'bound' in res.stdout, res.stdout[-2000:]
+
+
+# ------------------------------------------------------- the Seed loop's extra modules: checkpoint compatibility ----
+def test_discriminator_and_speech_autoencoder_state_dicts_are_the_references():
+    """The parameter / buffer names of discriminator.Discriminator and speech_autoencoder.SpeechAutoEncoder against the
+    names the REFERENCE's classes had when the trajectory fixtures were captured (`param_names` of
+    adv_traj_full_b8 / sae_traj_full_b8 list the reference's own state_dict keys), in order, and their shapes against
+    the oracle's modules: a checkpoint written by either side loads in the other (batch-norm buffers included)."""
+    import las_oracle as lo
+    from ss_asr_amd.discriminator import Discriminator
+    from ss_asr_amd.speech_autoencoder import SpeechAutoEncoder
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    adv = np.load(os.path.join(gold, 'adv_traj_full_b8.npz'))
+    sae = np.load(os.path.join(gold, 'sae_traj_full_b8.npz'))
+    d, d_ref = Discriminator(512, 256), lo.OracleDiscriminator(512, 256)
+    assert sorted('disc.' + k for k in d.state_dict()) == [str(n) for n in adv['param_names'] if str(n).startswith('disc.')]
+    cfg = ([list(map(int, k)) for k in sae['kernel_sizes']], [int(v) for v in sae['num_filters']],
+           [list(map(int, k)) for k in sae['pool_kernel_sizes']])
+    s, s_ref = SpeechAutoEncoder(512, 80, *cfg), lo.OracleSpeechAutoEncoder(512, 80, *cfg)
+    assert sorted('sae.' + k for k in s.state_dict()) == [str(n) for n in sae['param_names'] if str(n).startswith('sae.')]
+    for mine, ref in ((d, d_ref), (s, s_ref)):
+        a, b = mine.state_dict(), ref.state_dict()
+        assert list(a) == list(b)
+        assert all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)
+        mine.load_state_dict(b)                      # and back
+        ref.load_state_dict(mine.state_dict())
