@@ -219,8 +219,8 @@ def test_speech_autoencoder_module_matches_the_oracle_module():
     mine.load_state_dict(ref.state_dict())
     mine = mine.cuda()
     g = torch.Generator().manual_seed(3)
-    # 36 frames: conv [1, 5] -> 36 x 8, pool [2, 1] -> 18, conv [3, 1] -> 16, pool [3, 1] -> 5 x 8, conv [2, 2] -> 4 x 7,
-    # pool [4, 3] -> 1 x 2?  no: 7 // 3 = 2 columns -> the module must refuse; 33 frames likewise.  Use W that leaves 1:
+    # 36 frames x 12 mels: conv [1, 5] -> 36 x 8, pool [2, 1] -> 18 x 8, conv [3, 1] -> 16 x 8, pool [3, 1] -> 5 x 8,
+    # conv [2, 2] -> 4 x 7; a last window of [4, 3] leaves 1 x 2 values per filter (refused), [4, 7] leaves one
     x = torch.randn(3, 36, 12, generator=g)
     lis = torch.randn(3, 4, 24, generator=g)
     with pytest.raises(RuntimeError):
@@ -235,7 +235,7 @@ def test_speech_autoencoder_module_matches_the_oracle_module():
         want = ref(x, lis, **kw)
         got = mine(x.cuda(), lis.cuda(), **kw)
         assert got.shape == want.shape
-        assert float((got.cpu() - want).abs().max()) < 2e-5
+        assert float((got.detach().cpu() - want.detach()).abs().max()) < 2e-5
     for k, v in ref.state_dict().items():
         if 'running' in k or 'num_batches' in k:
             np.testing.assert_allclose(mine.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
