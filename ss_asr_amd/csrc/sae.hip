@@ -358,10 +358,13 @@ __global__ __launch_bounds__(256) void pool_bwd_sums_kernel(const float* dp, con
 template <int V>
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* dp, const float* p, const int32_t* idx, const float* y,
                                          const float* save, const float* gamma, const double* acc, int64_t B, int64_t T,
-                                         int64_t W, int C, int ph, int pw, int bt, int bw, float* dy, float* dgamma,
+                                         int64_t W, int C, int ph, int pw, int bt, int bw, int rpb, float* dy, float* dgamma,
                                          float* dbeta) {
-  // one workgroup per row (b, t) of the layer (blockIdx.x walks rows), threads over its W * C values, V at a time
-  const int64_t To = T / ph, Wo = W / pw;
+  // one workgroup per WINDOW ROW (b, to): the ph rows t = to ph .. to ph + ph - 1 of the layer that pool into one row
+  // of outputs (blockIdx.x walks window rows; a last, partial window row has no outputs: dz = 0 there).  The pooled
+  // values / offsets / gradients of a pixel are loaded ONCE and serve its ph rows -- with one workgroup per row the
+  // ph neighbours ran on different XCDs and each fetched them from HBM again (PMC: 589 MB against 294 for block 1).
+  const int64_t To = T / ph, Wo = W / pw, Tw = (T + ph - 1) / ph;
   const double count = (double)(B * T * W);
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -370,41 +373,49 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* dp,
     }
   const int64_t Tp = T + 2 * bt, Wp = W + 2 * bw;
   const int rowlen = (int)(W * C);
-  for (int64_t row = blockIdx.x; row < B * T; row += gridDim.x) {
-    const int64_t b = row / T, t = row - b * T, to = t / ph;
-    const int ti = (int)(t - to * ph);
-    const float* yr = y + row * rowlen;
-    float* dyr = dy + ((b * Tp + t + bt) * Wp + bw) * C;
+  // (tall windows -- the last block's -- are cut into parts of rpb rows, one workgroup each: few outputs to re-read there)
+  const int parts = (ph + rpb - 1) / rpb;
+  for (int64_t item = blockIdx.x; item < B * Tw * parts; item += gridDim.x) {
+    const int64_t wrow = item / parts;
+    const int part = (int)(item - wrow * parts);
+    const int64_t b = wrow / Tw, to = wrow - b * Tw;
+    const int nrow = (int)min((int64_t)min(ph, (part + 1) * rpb), T - to * ph), row0 = part * rpb;
+    const float* yw = y + (b * T + to * ph) * rowlen;
+    float* dyw = dy + ((b * Tp + to * ph + bt) * Wp + bw) * C;
     const int64_t qrow = (b * To + to) * Wo;              // first pooled pixel of the window row
     for (int e0 = threadIdx.x * V; e0 < rowlen; e0 += 256 * V) {
       const int m = e0 / C, c = e0 - m * C;
-      float yv[V], mean[V], invstd[V], gam[V], out[V], dz[V];
-      ldv<V>(yr + e0, yv);
+      float mean[V], invstd[V], gam[V], pv[V], dpv[V], m1[V], m2[V];
+      int k[V];
       ldv<V>(save + c, mean);
       ldv<V>(save + C + c, invstd);
       ldv<V>(gamma + c, gam);
       const int wo = m / pw;
+      const bool pooled = to < To && wo < Wo;
 #pragma unroll
-      for (int e = 0; e < V; ++e) dz[e] = 0.f;
-      if (to < To && wo < Wo) {
+      for (int e = 0; e < V; ++e) {
+        pv[e] = 0.f; dpv[e] = 0.f; k[e] = -1;
+        m1[e] = (float)(acc[c + e] / count); m2[e] = (float)(acc[C + c + e] / count);
+      }
+      if (pooled) {
         const int64_t q = (qrow + wo) * C + c;
-        const int want = ti * pw + (m - wo * pw);
-        float pv[V], dpv[V];
-        int k[V];
         ldv<V>(p + q, pv);
         ldv<V>(dp + q, dpv);
         ldv<V>(idx + q, k);
-#pragma unroll
-        for (int e = 0; e < V; ++e)
-          if (pv[e] > 0.f && k[e] == want) dz[e] = dpv[e];
       }
+      const int jw = m - wo * pw;
+      for (int ti = row0; ti < nrow; ++ti) {
+        float yv[V], out[V];
+        ldv<V>(yw + (int64_t)ti * rowlen + e0, yv);
+        const int want = ti * pw + jw;
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        const float xhat = (yv[e] - mean[e]) * invstd[e];
-        const float m1 = (float)(acc[c + e] / count), m2 = (float)(acc[C + c + e] / count);
-        out[e] = gam[e] * invstd[e] * (dz[e] - m1 - xhat * m2);
+        for (int e = 0; e < V; ++e) {
+          const float dz = (pv[e] > 0.f && k[e] == want) ? dpv[e] : 0.f;
+          const float xhat = (yv[e] - mean[e]) * invstd[e];
+          out[e] = gam[e] * invstd[e] * (dz - m1[e] - xhat * m2[e]);
+        }
+        stv<V>(dyw + (int64_t)ti * Wp * C + e0, out);
       }
-      stv<V>(dyr + e0, out);
     }
   }
 }
@@ -677,20 +688,21 @@ extern "C" int ssasr_bn_relu_pool_bwd(const float* dp, const float* p, const int
   const int64_t npos = B * (T / ph) * (W / pw);
   int64_t gx = (npos + (256 / CT) * 16 - 1) / ((256 / CT) * 16);
   gx = gx < 1 ? 1 : (gx > BN_BLOCKS ? BN_BLOCKS : gx);
-  const int64_t nrows = B * T;
+  const int rpb = ph <= 8 ? (int)ph : 1;                             // rows of a window row per workgroup
+  const int64_t nrows = B * ((T + ph - 1) / ph) * ((ph + rpb - 1) / rpb);
   const dim3 rgrid((unsigned)(nrows > 65536 ? 65536 : nrows));
   if (vec4_ok(C, dp) && vec4_ok(C, p) && vec4_ok(C, idx) && vec4_ok(C, y) && vec4_ok(C, save) && vec4_ok(C, gamma) && vec4_ok(C, dy)) {
     hipLaunchKernelGGL((pool_bwd_sums_kernel<4>), dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
                        B, T, W, (int)C, CT / 4, (int)ph, (int)pw, partial);
     hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)(2 * C)), dim3(64), 0, st, partial, (int)gx, (int)(2 * C), acc);
     hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<4>), rgrid, dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
-                       B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
+                       B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, rpb, dy, dgamma, dbeta);
   } else {
     hipLaunchKernelGGL((pool_bwd_sums_kernel<1>), dim3((unsigned)gx, (unsigned)((C + CT - 1) / CT)), dim3(256), 0, st, dp, p, idx, y, save,
                        B, T, W, (int)C, CT, (int)ph, (int)pw, partial);
     hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)(2 * C)), dim3(64), 0, st, partial, (int)gx, (int)(2 * C), acc);
     hipLaunchKernelGGL((bn_pool_bwd_apply_kernel<1>), rgrid, dim3(256), 0, st, dp, p, idx, y, save, gamma, acc,
-                       B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, dy, dgamma, dbeta);
+                       B, T, W, (int)C, (int)ph, (int)pw, (int)border_t, (int)border_w, rpb, dy, dgamma, dbeta);
   }
   SSASR_LAUNCH_CHECK();
   return SSASR_OK;
