@@ -2,6 +2,8 @@
 reusable object: forward, masked CE, backward, gradient all-reduce across
 ranks, clip + NaN guard + Adadelta.  ASRTrainer.exec, bench.py, smoke() and the
 tests all run THIS object, so that what is timed and checked is what trains."""
+import os
+
 import torch
 
 from . import dist as sdist
@@ -263,15 +265,33 @@ class SAETrainStep:
                                 (self.asr_flat.data[self.lo:self.hi], self.asr_flat.grad[self.lo:self.hi], False)],
                                lr=opt[1], eps=1e-8)
         self.grad_clip = grad_clip
+        # SSASR_SAE_OVERLAP=0: the speech encoder after the Listener on one stream (A/B; same results)
+        self.overlap = os.environ.get('SSASR_SAE_OVERLAP', '1') != '0'
         self._one = torch.ones((), device=self.sae_flat.data.device)
         self.last_pred = None          # [B, 8 T', F] of the most recent step (for the trainer's figures)
         self.last_done = None
         self.skipped_steps = 0
 
     def forward_loss(self, x, x_lens):
+        """Listener and global speech encoder both read the fbanks and nothing of each other: with `overlap` the
+        speech encoder's forward is enqueued on the second stream behind the Listener's (whose recurrences leave most of
+        the chip idle), and -- created later, it comes first in autograd's order -- its backward on that stream ahead of
+        the Listener's BPTT, beside which it then runs.  The frame decoder waits for both."""
         from .seed_ops import sae_loss
+        if not (self.overlap and x.is_cuda):
+            listener_out, _ = self.asr.encoder(x, x_lens)
+            pred = self.sae(x, listener_out)
+            return sae_loss(pred, x, max(x_lens)), pred
+        cur, side = torch.cuda.current_stream(), ops.side_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)                                  # x (and the zeroed gradient buffers) are final here
         listener_out, _ = self.asr.encoder(x, x_lens)
-        pred = self.sae(x, listener_out)
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            enc = self.sae.encoder(x)
+        cur.wait_stream(side)
+        enc.record_stream(cur)
+        pred = self.sae.decode_frames(enc, listener_out)
         return sae_loss(pred, x, max(x_lens)), pred
 
     def __call__(self, x, x_lens):

@@ -85,7 +85,12 @@ class SpeechAutoEncoder(nn.Module):
         """x [batch, seq, feature_dim] padded fbanks, listener_out [batch, ~seq / 8, listener_out_dim] the ASR
         encoder's output for them.  Returns [batch, 8 * frames, feature_dim]: for every Listener frame (the first
         alone with just_first) the eight input frames it stands for."""
-        enc = self.encoder(x.unsqueeze(1))
+        return self.decode_frames(self.encoder(x.unsqueeze(1)), listener_out, just_first)
+
+    def decode_frames(self, enc, listener_out, just_first=False):
+        """The second half of forward (src/speech_autoencoder.py:58-94) from the global encoding `enc` [batch,
+        encoder.out_dim] -- split off so that a caller can compute `enc`, which depends on the fbanks alone, while the
+        Listener is still running (engine.SAETrainStep)."""
         lis = listener_out[:, :1] if just_first else listener_out
         out = self.decoder(seed_ops.sae_concat(lis, enc))          # [batch, frames, 8 * feature_dim]
         return out.reshape(out.shape[0], out.shape[1] * 8, self.feature_dim)
