@@ -265,18 +265,19 @@ class SAETrainStep:
                                 (self.asr_flat.data[self.lo:self.hi], self.asr_flat.grad[self.lo:self.hi], False)],
                                lr=opt[1], eps=1e-8)
         self.grad_clip = grad_clip
-        # SSASR_SAE_OVERLAP=0: the speech encoder after the Listener on one stream (A/B; same results)
-        self.overlap = os.environ.get('SSASR_SAE_OVERLAP', '1') != '0'
+        # SSASR_SAE_OVERLAP: 0 the speech encoder behind the Listener on one stream, 1 / 2 see forward_loss (same results)
+        self.overlap = int(os.environ.get('SSASR_SAE_OVERLAP', '1'))
         self._one = torch.ones((), device=self.sae_flat.data.device)
         self.last_pred = None          # [B, 8 T', F] of the most recent step (for the trainer's figures)
         self.last_done = None
         self.skipped_steps = 0
 
     def forward_loss(self, x, x_lens):
-        """Listener and global speech encoder both read the fbanks and nothing of each other: with `overlap` the
-        speech encoder's forward is enqueued on the second stream behind the Listener's (whose recurrences leave most of
-        the chip idle), and -- created later, it comes first in autograd's order -- its backward on that stream ahead of
-        the Listener's BPTT, beside which it then runs.  The frame decoder waits for both."""
+        """Listener and global speech encoder both read the fbanks and nothing of each other.  With `overlap` the speech
+        encoder runs on the second stream -- 1: its forward still AFTER the Listener's, its backward (autograd runs a
+        node on its forward's stream; created after the Listener's nodes it comes first in autograd's order) beside the
+        Listener's BPTT; 2: its forward beside the Listener's too (measured: the first layer's recurrence then takes
+        2.42 instead of 1.44 ms -- a loss).  The frame decoder waits for both."""
         from .seed_ops import sae_loss
         if not (self.overlap and x.is_cuda):
             listener_out, _ = self.asr.encoder(x, x_lens)
@@ -286,7 +287,10 @@ class SAETrainStep:
         ready = torch.cuda.Event()
         ready.record(cur)                                  # x (and the zeroed gradient buffers) are final here
         listener_out, _ = self.asr.encoder(x, x_lens)
-        side.wait_event(ready)
+        if self.overlap == 2:
+            side.wait_event(ready)
+        else:
+            side.wait_stream(cur)
         with torch.cuda.stream(side):
             enc = self.sae.encoder(x)
         cur.wait_stream(side)
