@@ -9,15 +9,13 @@
 The reference's scripts import their siblings by bare module name (`import trainer`,
 src/train.py:9; `from asr import ASR`, src/trainer.py:20).  `python src/train.py` puts src/ at
 sys.path[0], AHEAD of PYTHONPATH, so an environment variable cannot redirect those imports.
-This launcher puts ss_asr_amd/flat/ (shims named asr.py, trainer.py, ASRDataset.py, ...) at
-sys.path[0] instead and executes the script with runpy as `__main__`; nothing in the reference
-tree is edited and none of its other modules is imported.
+This launcher binds those names to this package's modules first (ss_asr_amd/flat.py installs them in
+sys.modules, which an import consults before any path) and executes the script with runpy as
+`__main__`; nothing in the reference tree is edited and none of its other modules is imported.
 """
 import os
 import runpy
 import sys
-
-FLAT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'flat')
 
 
 def main(argv=None):
@@ -29,8 +27,9 @@ def main(argv=None):
     if not os.path.isfile(script):
         print('run_reference: no such script: %s' % script, file=sys.stderr)
         return 2
-    # the shims first; the script's own directory is NOT added (runpy.run_path does not add it)
-    sys.path[:] = [FLAT] + [p for p in sys.path if os.path.abspath(p or '.') != os.path.dirname(script)]
+    # the flat names first; the script's own directory is NOT searched (runpy.run_path does not add it)
+    from . import flat  # noqa: F401
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or '.') != os.path.dirname(script)]
     sys.argv = [script] + argv[1:]
     runpy.run_path(script, run_name='__main__')
     return 0

@@ -362,7 +362,7 @@ REFERENCE_TRAIN = '/root/reference/src/train.py'
 @pytest.mark.skipif(not os.path.isfile(REFERENCE_TRAIN),
                     reason='build-container only: the reference tree does not travel to the GPU box')
 @pytest.mark.parametrize('kind', ['ASRTrainer', 'TAETrainer', 'AdvTrainer', 'SAETrainer', 'Seed'])
-def test_reference_train_script_runs_unchanged_against_the_shims(tmp_path, kind):
+def test_reference_train_script_runs_unchanged_against_this_package(tmp_path, kind):
     """`python -m ss_asr_amd.run_reference <reference>/src/train.py ...`
     executes the reference's unmodified entry point with its bare imports (`import trainer`,
     src/train.py:9) bound to ss_asr_amd.  Without a GPU the run must get all the way through
@@ -412,15 +412,15 @@ def test_reference_train_script_runs_unchanged_against_the_shims(tmp_path, kind)
     assert os.path.isdir(os.path.join(root, 'result', 'dropin'))
 
 
-def test_flat_shims_bind_the_product_modules():
-    """Importing `trainer` / `asr` / `ASRDataset` the way the reference's scripts do, with
-    ss_asr_amd/flat first on sys.path, yields the product's classes."""
+def test_flat_names_bind_the_product_modules():
+    """Importing `trainer` / `asr` / `ASRDataset` the way the reference's scripts do, after `import ss_asr_amd.flat`,
+    yields the product's modules (and the modules of the Seed loop's other legs)."""
     import subprocess
-    code = ("import sys; sys.path.insert(0, %r); import trainer, asr, ASRDataset; "
+    code = ("import ss_asr_amd.flat; import trainer, asr, ASRDataset, discriminator, speech_autoencoder, text_autoencoder; "
             "import ss_asr_amd.trainer as t, ss_asr_amd.asr as a; "
-            "assert trainer.ASRTrainer is t.ASRTrainer and asr.ASR is a.ASR and asr.Listener is a.Listener; "
-            "assert hasattr(ASRDataset, 'load_asr_dataset') and hasattr(trainer, 'Solver'); print('bound')"
-            % os.path.join(ROOT, 'ss_asr_amd', 'flat'))
+            "assert trainer is t and asr is a and trainer.ASRTrainer is t.ASRTrainer and asr.Listener is a.Listener; "
+            "assert hasattr(ASRDataset, 'load_asr_dataset') and hasattr(trainer, 'Solver') and hasattr(trainer, 'AdvTrainer'); "
+            "assert hasattr(discriminator, 'Discriminator') and hasattr(speech_autoencoder, 'SpeechAutoEncoder'); print('bound')")
     res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=120)
     assert res.returncode == 0 and 'bound' in res.stdout, res.stdout[-2000:]
