@@ -336,12 +336,11 @@ def test_trainer_plumbing_without_gpu(tmp_path):
         tr.exec()
 
 
-def test_flat_shims_serve_the_reference_entry_point():
+def test_flat_names_serve_the_reference_entry_point():
     """src/train.py does `import trainer` and getattr(trainer, 'ASRTrainer')."""
-    flat = os.path.join(ROOT, 'ss_asr_amd', 'flat')
-    code = ("import sys; sys.path.insert(0, %r); import trainer, asr, ASRDataset, preprocess;"
+    code = ("import ss_asr_amd.flat; import trainer, asr, ASRDataset, preprocess;"
             "assert trainer.ASRTrainer.__module__ == 'ss_asr_amd.trainer';"
-            "assert asr.ASR and ASRDataset.load_asr_dataset and preprocess.TOKENS == '<>$'" % flat)
+            "assert asr.ASR and ASRDataset.load_asr_dataset and preprocess.TOKENS == '<>$'")
     import subprocess
     subprocess.run([sys.executable, '-c', code], check=True, cwd=ROOT)
 
