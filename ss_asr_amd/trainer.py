@@ -498,7 +498,8 @@ class ADVTrainer(Solver):
     """Adversarial training of the Listener against the text encoder's frames (src/trainer.py:909-1124;
     config 5's second leg).  Generator: the ASR model's Listener; data distribution: the text autoencoder's
     encoder; discriminator: discriminator.Discriminator.  One iteration of exec() is ONE engine.ADVTrainStep
-    call (Adadelta or Adam for G_opt / D_opt; anything else raises).
+    call when G_opt / D_opt are Adadelta or Adam; any other optimizer type takes the reference's sequence with
+    torch optimizers (`_iteration`).
 
     The reference's ADVTrainer cannot run as shipped; what is fixed here, and
     nothing else: `self.loss_metric` (used at :984, never set) is nn.BCELoss -- on the ssasr_bce kernels; the
@@ -533,10 +534,46 @@ class ADVTrainer(Solver):
                                                **self.config['adv']['mdl'])
         self.data_distribution = self.text_autoenc.encoder
         g, d = self.config['adv']['G_opt'], self.config['adv']['D_opt']
-        self.train_step = ADVTrainStep(self.asr_model, self.text_autoenc, self.discriminator,
-                                       g_opt=(g['type'], g['learning_rate']), d_opt=(d['type'], d['learning_rate']),
-                                       label_smoothing=self.config['adv']['label_smoothing'], grad_clip=5.0)
-        self.G_optim, self.D_optim = self.train_step.G_optim, self.train_step.D_optim
+        fused = ('Adadelta', 'Adam')
+        self.train_step = None
+        if g['type'] in fused and d['type'] in fused and self.device.type == 'cuda':
+            self.train_step = ADVTrainStep(self.asr_model, self.text_autoenc, self.discriminator,
+                                           g_opt=(g['type'], g['learning_rate']), d_opt=(d['type'], d['learning_rate']),
+                                           label_smoothing=self.config['adv']['label_smoothing'], grad_clip=5.0)
+            self.G_optim, self.D_optim = self.train_step.G_optim, self.train_step.D_optim
+        else:
+            # any other optimizer type: the reference's sequence with torch optimizers (src/trainer.py:938-948)
+            self.G_optim = getattr(torch.optim, g['type'])(self.asr_model.encoder.parameters(), lr=g['learning_rate'], eps=1e-8)
+            self.D_optim = getattr(torch.optim, d['type'])(self.discriminator.parameters(), lr=d['learning_rate'], eps=1e-8)
+
+    def _frames(self, x, x_lens, y):
+        """(text-encoder frames without a graph, Listener frames with theirs)."""
+        if self.train_step is not None:
+            return self.train_step.frames(x, x_lens, y)
+        if not x.is_cuda:
+            raise RuntimeError('ss_asr_amd computes on the GPU only (no CPU path)')
+        with torch.no_grad():
+            real = self.data_distribution(y)
+        fake, _ = self.asr_model.encoder(x, x_lens)
+        return real, fake
+
+    def _iteration(self, x, x_lens, y):
+        """src/trainer.py:968-1032 with torch optimizers (the fused form is engine.ADVTrainStep)."""
+        from .seed_ops import bce_loss
+        self.discriminator.zero_grad()
+        real, fake = self._frames(x, x_lens, y)
+        D_realloss = bce_loss(self.discriminator(real), 1.0 - self.config['adv']['label_smoothing'])
+        D_realloss.backward()
+        D_fakeloss = bce_loss(self.discriminator(fake.detach()), 0.0)
+        D_fakeloss.backward()
+        self.step(self.discriminator.parameters(), self.D_optim)
+        self.asr_model.encoder.zero_grad()
+        G_loss = bce_loss(self.discriminator(fake, frozen=True), 1.0)
+        G_loss.backward()
+        self.step(self.asr_model.encoder.parameters(), self.G_optim)
+        if self.tr.step % self.logging_step == 0:
+            ops.check_persistent_status()
+        return D_realloss, D_fakeloss, G_loss
 
     def _rank_batches(self):
         from .gpu_loader import rank_batches
@@ -547,7 +584,7 @@ class ADVTrainer(Solver):
 
     def exec(self):
         self.verbose('Training set total {} batches'.format(len(self.train_set)))
-        nan_reported = self.train_step.skipped_steps
+        nan_reported = self.train_step.skipped_steps if self.train_step is not None else 0
         epoch = 0
         while epoch < self.n_epochs:
             self.verbose("Starting epoch {} out of {}".format(epoch + 1, self.n_epochs))
@@ -556,10 +593,13 @@ class ADVTrainer(Solver):
                              progress=True)
                 x, x_lens = prepare_x(x, device=self.device)
                 y, _ = prepare_y(y, device=self.device)
-                D_realloss, D_fakeloss, G_loss = self.train_step(x, x_lens, y)
-                if self.train_step.skipped_steps > nan_reported:
-                    nan_reported = self.train_step.skipped_steps
-                    self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+                if self.train_step is not None:
+                    D_realloss, D_fakeloss, G_loss = self.train_step(x, x_lens, y)
+                    if self.train_step.skipped_steps > nan_reported:
+                        nan_reported = self.train_step.skipped_steps
+                        self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+                else:
+                    D_realloss, D_fakeloss, G_loss = self._iteration(x, x_lens, y)
                 if self.rank == 0 and self.tr.step % self.logging_step == 0:
                     self.lg.scalar('discrim_real_loss_train', D_realloss.item(), self.tr.step)
                     self.lg.scalar('discrim_fake_loss_train', D_fakeloss.item(), self.tr.step)
@@ -568,13 +608,15 @@ class ADVTrainer(Solver):
                 if self.tr.step % self.valid_step == 0:
                     self.valid()
                 if self.rank == 0 and self.tr.step % self.save_step == 0:
-                    self.train_step.finish()           # never checkpoint after a time-out
+                    if self.train_step is not None:
+                        self.train_step.finish()       # never checkpoint after a time-out
                     self.verbose("Model saved at step {}".format(self.tr.step))
                     torch.save(self.discriminator.state_dict(), self.ckppath)
                     torch.save(self.asr_model.state_dict(), self.asrpath_out)
                 self.tr.do_step()
             epoch += 1
-        self.train_step.finish()
+        if self.train_step is not None:
+            self.train_step.finish()
 
     def valid(self):
         """src/trainer.py:1038-1113: the discriminator's two losses (real labels unsmoothed here, :1059) averaged
@@ -591,7 +633,7 @@ class ADVTrainer(Solver):
                              progress=True)
                 x, x_lens = prepare_x(x, device=self.device)
                 y, _ = prepare_y(y, device=self.device)
-                real_data, fake_data = self.train_step.frames(x, x_lens, y)
+                real_data, fake_data = self._frames(x, x_lens, y)
                 real_sum += float(bce_loss(self.discriminator(real_data), 1.0))
                 fake_sum += float(bce_loss(self.discriminator(fake_data), 0.0))
                 n_batches += 1
@@ -617,7 +659,8 @@ class ADVTrainer(Solver):
     def close(self):
         self.verbose("Finished training! The most recent model will" +
                      "be saved at step {} as well as the ASR model".format(self.tr.step))
-        self.train_step.finish()
+        if self.train_step is not None:
+            self.train_step.finish()
         if self.rank == 0:
             torch.save(self.discriminator.state_dict(), self.ckppath)
             torch.save(self.asr_model.state_dict(), self.asrpath_out)
@@ -626,7 +669,8 @@ class ADVTrainer(Solver):
 class SAETrainer(Solver):
     """Trains the speech autoencoder and, through it, the ASR model's Listener on audio alone
     (src/trainer.py:760-907; config 5's third leg).  With Adam (conf/default.yaml:24-26) one iteration of
-    exec() is ONE engine.SAETrainStep call; other optimizer types raise.  The spectrogram figures of valid()
+    exec() is ONE engine.SAETrainStep call; any other optimizer type takes the reference's sequence (zero_grad,
+    forward, backward, Solver.step over the speech autoencoder's parameters) with the torch optimizer.  The spectrogram figures of valid()
     (:871-887, matplotlib + librosa's specshow) are logged as the pair of arrays they would draw."""
 
     def __init__(self, config, paras):
@@ -649,9 +693,28 @@ class SAETrainer(Solver):
         self.speech_autoenc = self.setup_module(SpeechAutoEncoder, self.ckppath, self.asr_model.encoder.out_dim,
                                                 self.config['asr']['mdl']['feature_dim'], **self.config['sae']['mdl'])
         opt = self.config['sae']['opt']
-        self.train_step = SAETrainStep(self.asr_model, self.speech_autoenc, opt=(opt['type'], opt['learning_rate']),
-                                       grad_clip=5.0)
-        self.optim = self.train_step.optim
+        self.train_step = None
+        if opt['type'] == 'Adam' and self.device.type == 'cuda':
+            self.train_step = SAETrainStep(self.asr_model, self.speech_autoenc, opt=(opt['type'], opt['learning_rate']),
+                                           grad_clip=5.0)
+            self.optim = self.train_step.optim
+        else:
+            # any other optimizer type: the reference's sequence (zero_grad, forward, backward, Solver.step over the
+            # speech autoencoder's parameters) with the torch optimizer over both parameter lists (src/trainer.py:789-794)
+            self.optim = getattr(torch.optim, opt['type'])(
+                list(self.speech_autoenc.parameters()) + list(self.asr_model.encoder.parameters()),
+                lr=opt['learning_rate'], eps=1e-8)
+
+    def _forward_loss(self, x, x_lens):
+        """(loss, prediction [B, 8 T', F]) of src/trainer.py:805-818."""
+        if self.train_step is not None:
+            return self.train_step.forward_loss(x, x_lens)
+        from .seed_ops import sae_loss
+        if not x.is_cuda:
+            raise RuntimeError('ss_asr_amd computes on the GPU only (no CPU path)')
+        listener_out, _ = self.asr_model.encoder(x, x_lens)
+        pred = self.speech_autoenc(x, listener_out)
+        return sae_loss(pred, x, max(x_lens)), pred
 
     def _rank_batches(self):
         from .gpu_loader import rank_batches
@@ -662,7 +725,7 @@ class SAETrainer(Solver):
 
     def exec(self):
         self.verbose('Training set total {} batches.'.format(len(self.train_set)))
-        nan_reported = self.train_step.skipped_steps
+        nan_reported = self.train_step.skipped_steps if self.train_step is not None else 0
         epoch = 0
         while epoch < self.n_epochs:
             self.verbose("Starting epoch {} out of {}".format(epoch + 1, self.n_epochs))
@@ -670,22 +733,32 @@ class SAETrainer(Solver):
                 self.verbose('Batch: {}/{}, global step: {}'.format(b_ind, len(self.train_set), self.tr.step),
                              progress=True)
                 x, x_lens = prepare_x(x, device=self.device)
-                loss = self.train_step(x, x_lens)
-                if self.train_step.skipped_steps > nan_reported:
-                    nan_reported = self.train_step.skipped_steps
-                    self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+                if self.train_step is not None:
+                    loss = self.train_step(x, x_lens)
+                    if self.train_step.skipped_steps > nan_reported:
+                        nan_reported = self.train_step.skipped_steps
+                        self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step - 1))
+                else:
+                    self.optim.zero_grad()
+                    loss, _ = self._forward_loss(x, x_lens)
+                    loss.backward()
+                    self.step(self.speech_autoenc.parameters(), self.optim)
+                    if self.tr.step % self.logging_step == 0:
+                        ops.check_persistent_status()
                 if self.rank == 0 and self.tr.step % self.logging_step == 0:
                     self.lg.scalar('train_loss', loss.item(), self.tr.step)
                 if self.tr.step % self.valid_step == 0:
                     self.valid()
                 if self.rank == 0 and self.tr.step % self.save_step == 0:
-                    self.train_step.finish()           # never checkpoint after a time-out
+                    if self.train_step is not None:
+                        self.train_step.finish()       # never checkpoint after a time-out
                     self.verbose("Model saved at step {}".format(self.tr.step))
                     torch.save(self.speech_autoenc.state_dict(), self.ckppath)
                     torch.save(self.asr_model.state_dict(), self.asrpath_out)
                 self.tr.do_step()
             epoch += 1
-        self.train_step.finish()
+        if self.train_step is not None:
+            self.train_step.finish()
 
     def valid(self):
         """src/trainer.py:840-897: the eval-mode loss (running batch-norm statistics) averaged over the
@@ -699,7 +772,7 @@ class SAETrainer(Solver):
                 self.verbose('Validation step - {} ( {} / {} )'.format(self.tr.step, b_idx, len(self.valid_set)),
                              progress=True)
                 x, x_lens = prepare_x(x, device=self.device)
-                loss, pred = self.train_step.forward_loss(x, x_lens)
+                loss, pred = self._forward_loss(x, x_lens)
                 total += float(loss)
                 n_batches += 1
         ops.check_persistent_status()
@@ -726,7 +799,8 @@ class SAETrainer(Solver):
     def close(self):
         self.verbose("Finished training! The most recent model will" +
                      "be saved at step {} as well as the ASR model".format(self.tr.step))
-        self.train_step.finish()
+        if self.train_step is not None:
+            self.train_step.finish()
         if self.rank == 0:
             torch.save(self.speech_autoenc.state_dict(), self.ckppath)
             torch.save(self.asr_model.state_dict(), self.asrpath_out)

@@ -692,3 +692,72 @@ def test_seed_loop_runs_the_three_legs_over_the_checkpoint_chain(tmp_path):
     assert all(torch.equal(a1[k], a2[k]) and torch.equal(a2[k], a3[k]) for k in behind)
     assert not torch.equal(a1['encoder.blstm_2.layer.weight_ih_l0'], a2['encoder.blstm_2.layer.weight_ih_l0'])
     assert not torch.equal(a2['encoder.blstm_2.layer.weight_ih_l0'], a3['encoder.blstm_2.layer.weight_ih_l0'])
+
+
+def test_adv_and_sae_trainers_with_other_optimizer_types_take_the_reference_sequence(tmp_path):
+    """conf/default.yaml names Adam (SAE) and Adadelta (ADV); any other torch.optim type the config names takes the
+    reference's own sequence (zero_grad, passes, Solver.step with clip_grad_norm_) on the same kernels: one
+    iteration of SAETrainer with Adamax and of ADVTrainer with RMSprop / Adamax against the oracle's iteration with
+    the same torch optimizers, from the same initial weights -- losses and the weights both write."""
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_x, prepare_y
+    from ss_asr_amd.trainer import ADVTrainer, SAETrainer
+    root = str(tmp_path)
+    index, _ = make_corpus(root, n=16, t_max=32, feat=80, seed=8)
+    conf = _seed_config(index, n_epochs=1)
+    conf['sae']['opt'] = {'type': 'Adamax', 'learning_rate': 0.001}
+    conf['adv']['G_opt'] = {'type': 'RMSprop', 'learning_rate': 0.0005}
+    conf['adv']['D_opt'] = {'type': 'Adamax', 'learning_rate': 0.001}
+    _, _, loader = load_asr_dataset(index, batch_size=16, n_jobs=0)
+    x, y = next(iter(loader))
+    x, _ = prepare_x(x)
+    y, _ = prepare_y(y)
+    snap = lambda m: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = SAETrainer(conf, _paras(root, 'sae2'))
+    tr.load_data()
+    tr.set_model()
+    assert tr.train_step is None and type(tr.optim).__name__ == 'Adamax'
+    asr0, sae0 = snap(tr.asr_model), snap(tr.speech_autoenc)
+    tr.exec()
+    tr.close()
+    got = [e['value'] for e in _events(root, 'sae2', 'sae') if e['key'] == 'sae_train_loss'][0]
+    ref_asr = lo.OracleASR(50, 256, 256, 128, 80, 1.0)
+    ref_asr.load_state_dict(asr0)
+    ref_sae = lo.OracleSpeechAutoEncoder(512, 80, **conf['sae']['mdl'])
+    ref_sae.load_state_dict(sae0)
+    want, _ = lo.sae_train_step(ref_asr, ref_sae, lo.make_sae_optimizer(ref_sae, ref_asr, lr=0.001, kind='Adamax'), x)
+    assert abs(got - want) < 1e-5, (got, want)
+    asr1 = torch.load(os.path.join(root, 'result', 'sae2', 'asr.cpt'), map_location='cpu')
+    sae1 = torch.load(os.path.join(root, 'result', 'sae2', 'sae.cpt'), map_location='cpu')
+    for k, v in ref_sae.state_dict().items():
+        np.testing.assert_allclose(sae1[k].float().numpy(), v.float().numpy(), atol=2e-5, rtol=0, err_msg=k)
+    for k, v in ref_asr.state_dict().items():
+        np.testing.assert_allclose(asr1[k].numpy(), v.numpy(), atol=2e-5, rtol=0, err_msg=k)
+
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    tr = ADVTrainer(conf, _paras(root, 'adv2'))
+    tr.load_data()
+    tr.set_model()
+    assert tr.train_step is None and type(tr.G_optim).__name__ == 'RMSprop'
+    asr0, tae0, d0 = snap(tr.asr_model), snap(tr.text_autoenc), snap(tr.discriminator)
+    tr.exec()
+    tr.close()
+    ev = _events(root, 'adv2', 'adv')
+    got = [[e['value'] for e in ev if e['key'] == 'adv_' + k][0] for k in
+           ('discrim_real_loss_train', 'discrim_fake_loss_train', 'gen_loss_train')]
+    ref_asr = lo.OracleASR(50, 256, 256, 128, 80, 1.0)
+    ref_asr.load_state_dict(asr0)
+    ref_tae = lo.OracleTextAutoEncoder(50, 128, 256, 2)
+    ref_tae.load_state_dict(tae0)
+    ref_d = lo.OracleDiscriminator(512, 256)
+    ref_d.load_state_dict(d0)
+    G, D = lo.make_adv_optimizers(ref_asr, ref_d, ('RMSprop', 0.0005), ('Adamax', 0.001))
+    want = lo.adv_train_step(ref_asr, ref_tae.encoder, ref_d, G, D, x, y, 0.1)[:3]
+    np.testing.assert_allclose(got, want, atol=1e-5, rtol=0)
+    asr1 = torch.load(os.path.join(root, 'result', 'adv2', 'asr.cpt'), map_location='cpu')
+    d1 = torch.load(os.path.join(root, 'result', 'adv2', 'adv.cpt'), map_location='cpu')
+    for k, v in ref_d.state_dict().items():
+        np.testing.assert_allclose(d1[k].numpy(), v.numpy(), atol=2e-5, rtol=0, err_msg=k)
+    for k, v in ref_asr.state_dict().items():
+        np.testing.assert_allclose(asr1[k].numpy(), v.numpy(), atol=5e-5, rtol=0, err_msg=k)
