@@ -16,10 +16,11 @@ COLUMNS = ['normalized_text', 'path_to_fbank', 's_len', 'unpadded_num_frames', '
 
 
 def load_index(path):
-    """Rows of the index as dicts (ints converted)."""
+    """Rows of the index as dicts (ints converted).  Field quoting follows the reference's reader, pandas'
+    read_csv defaults (src/ASRDataset.py:13-23): minimal quoting with '"', blank lines skipped."""
     rows = []
     with open(path, 'r', encoding='utf-8', newline='') as f:
-        for rec in csv.reader(f, delimiter='\t', quoting=csv.QUOTE_NONE):
+        for rec in csv.reader(f, delimiter='\t', quoting=csv.QUOTE_MINIMAL):
             if not rec:
                 continue
             row = dict(zip(COLUMNS, rec))
@@ -27,6 +28,21 @@ def load_index(path):
             row['unpadded_num_frames'] = int(row['unpadded_num_frames'])
             rows.append(row)
     return rows
+
+
+def sort_rows(rows, key, ascending=True):
+    """The row order of `DataFrame.sort_values(by=[key], ascending=...)` (src/ASRDataset.py:55-57,
+    src/preprocess.py:314), ties included: pandas sorts one column with numpy's default argsort (not a stable
+    sort) and, for a descending order, sorts the reversed column and reverses the result."""
+    vals = [r[key] for r in rows]
+    col = np.array(vals, dtype=np.int64) if isinstance(vals[0], int) else np.array(vals, dtype=object)
+    idx = np.arange(len(rows))
+    if not ascending:
+        col, idx = col[::-1], idx[::-1]
+    order = idx[col.argsort(kind='quicksort')]
+    if not ascending:
+        order = order[::-1]
+    return [rows[int(i)] for i in order]
 
 
 class ASRDataset(Dataset):
@@ -38,7 +54,7 @@ class ASRDataset(Dataset):
         self.idx2char_dict = {i: c for i, c in enumerate(chars)}
         self._rows = load_index(tsv_file)
         if sort_key:
-            self._rows.sort(key=lambda r: r[sort_key], reverse=not sort_ascending)
+            self._rows = sort_rows(self._rows, sort_key, sort_ascending)
         self._feature_dim = self.get_fbank(0).shape[1]
         self.batch_size = batch_size
         self.num_samples = len(self._rows)

@@ -38,3 +38,17 @@ def zero_pad(fbank, max_len, n_dims=None):
     padded = np.zeros([max_len, n_dims])
     padded[:fbank.shape[0], :fbank.shape[1]] = fbank
     return padded
+
+
+def sort_index(index, sort_key, sort_ascending=True, out_index=None):
+    """src/preprocess.py:301-316: rewrites the index sorted by one column (in place unless `out_index`);
+    same row order as the reference's pandas sort, ties included, same file bytes (tab separated, no header,
+    minimal quoting, '\\n' line ends)."""
+    import csv
+
+    from .ASRDataset import COLUMNS, load_index, sort_rows
+    rows = sort_rows(load_index(index), sort_key, sort_ascending)
+    with open(out_index if out_index is not None else index, 'w', encoding='utf-8', newline='') as f:
+        w = csv.writer(f, delimiter='\t', quoting=csv.QUOTE_MINIMAL, lineterminator='\n')
+        for r in rows:
+            w.writerow([r[c] for c in COLUMNS])

@@ -102,6 +102,57 @@ def test_gpu_resident_loader_yields_what_prepare_x_and_prepare_y_yield(tmp_path)
     assert [t[0] for t in GpuResidentLoader(index, 8, dev, rank=1, world=2)] == [1]
 
 
+def test_gpu_loader_and_prepare_x_equal_the_reference_fixture(tmp_path):
+    """Rows a16 / a17 / f2 on the device against the REFERENCE: tests/golden/dataset_ref.npz holds what the
+    reference's DataLoader + prepare_x / prepare_y (src/ASRDataset.py:206-226, :297-340) returned for the corpus
+    of oracle/corpus_recipe.py.  `ssasr_gather_batch` (GpuResidentLoader) and `ssasr_frame_lengths` (prepare_x on
+    the GPU) must give those frames, label rows and lengths bit for bit."""
+    import corpus_recipe as cr
+    from conftest import GOLDEN
+    from ss_asr_amd.ASRDataset import load_asr_dataset, prepare_x, prepare_y
+    from ss_asr_amd.gpu_loader import GpuResidentLoader
+    fx = np.load(os.path.join(GOLDEN, 'dataset_ref.npz'), allow_pickle=False)
+    index = cr.write_corpus(str(tmp_path))
+    dev = torch.device('cuda:0')
+    gl = GpuResidentLoader(index, 8, dev)
+    assert len(gl) == int(fx['len']) and gl.feature_dim == int(fx['feature_dim'])
+    _, _, loader = load_asr_dataset(index, batch_size=8, n_jobs=0)
+    for (b, x, x_lens, y, y_lens), (xl, yl) in zip(list(gl), loader):
+        px, py = torch.from_numpy(fx['b%d_px' % b]), torch.from_numpy(fx['b%d_py' % b])
+        assert x_lens == list(fx['b%d_x_lens' % b]) and y_lens == list(fx['b%d_y_lens' % b])
+        T = x.shape[1]
+        assert T % 8 == 0 and max(x_lens) <= T <= px.shape[1]
+        assert x.dtype == torch.float32 and torch.equal(x.cpu(), px[:, :T])      # the reference's frames
+        assert float(px[:, T:].abs().sum()) == 0.0                               # only padding was cut
+        assert y.dtype == torch.int64 and torch.equal(y.cpu(), py)
+        # the DataLoader path with prepare_x on the GPU (ssasr_frame_lengths) / prepare_y
+        gx, gx_lens = prepare_x(xl, device=dev)
+        gy, gy_lens = prepare_y(yl, device=dev)
+        assert gx_lens == list(fx['b%d_x_lens' % b]) and gy_lens == list(fx['b%d_y_lens' % b])
+        assert torch.equal(gx.cpu(), px) and torch.equal(gy.cpu(), py)
+
+
+def test_a_reference_written_checkpoint_gives_the_reference_logits_on_the_gpu():
+    """`.cpt` (src/trainer.py:451, :545, :164): tests/golden/ref_small_asr.cpt was written by the reference from
+    its own seeded ASR; loaded into the product's ASR it must reproduce the logits, encoder lengths and attention
+    row the reference computed from it on batch 1 of the recipe corpus (eval mode, teacher forced)."""
+    from conftest import GOLDEN
+    from ss_asr_amd.asr import ASR
+    fx = np.load(os.path.join(GOLDEN, 'dataset_ref.npz'), allow_pickle=False)
+    dims = [int(v) for v in fx['cpt_dims']]
+    model = ASR(*dims, 1.0)
+    model.load_state_dict(torch.load(os.path.join(GOLDEN, 'ref_small_asr.cpt'), weights_only=True), strict=True)
+    model = model.to('cuda:0').eval()
+    x, y = torch.from_numpy(fx['b1_px']).cuda(), torch.from_numpy(fx['b1_py']).cuda()
+    ans_len = int(max(fx['b1_y_lens'])) - 1
+    with torch.no_grad():
+        enc_len, logits, att = model(x, ans_len, teacher=y, state_len=[int(v) for v in fx['b1_x_lens']])
+    torch.cuda.synchronize()
+    assert list(enc_len) == list(fx['cpt_enc_len'])
+    assert np.abs(logits.cpu().numpy() - fx['cpt_logits']).max() < 5e-5
+    assert np.abs(att[0].cpu().numpy() - fx['cpt_att_row0']).max() < 2e-6
+
+
 def test_asr_trainer_steps_follow_the_oracle_trajectory(tmp_path):
     """ASRTrainer.exec runs engine.ASRTrainStep fed by the device-resident loader -- the objects
     bench.py times.  Four iterations (two epochs over two batches of 16, Adadelta state carried
