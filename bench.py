@@ -141,9 +141,9 @@ def decode_loop_attention(device, B=32, T=100, U=52, A=128, E=512, D=256):
     all U decode steps; 64 attention workgroups keep their slices of feat in LDS and re-read comp
     from L2).  Live: HIP events around ssasr_decoder_fwd -> us per decode step.  From the in-kernel
     stamps of the diagnostic build (tools/dectrace.py, committed as profiles/r02_dectrace.txt): the
-    attention stage of a step (its h1 seen -> its context published).  `achieved_equivalent` prices
-    the step's ALGORITHMIC bytes (comp + feat + ...) against that stage time; the bytes
-    that actually leave L2 / HBM per step are comp, h1 and the context only."""
+    attention stage of a step (its h1 seen -> its context published).  The stage is LDS-resident: the bytes
+    that actually leave L2 / HBM per step are comp, h1 and the context only (`bytes_moved_per_step`), so no
+    HBM fraction is quoted for it."""
     from ss_asr_amd import ops
     from ss_asr_amd.asr import ASR
     torch.manual_seed(5)
@@ -183,11 +183,12 @@ def decode_loop_attention(device, B=32, T=100, U=52, A=128, E=512, D=256):
     out = dict(kernel='decoder_fwd_persistent_kernel<true> (attention workgroups)', us_per_decode_step=round(us_step, 2),
                note='whole ssasr_decoder_fwd call / U: includes the embedding gather, the workspace fill and the logits GEMM',
                algorithmic_bytes_per_step=nbytes, bytes_moved_per_step=moved, shape=dict(B=B, T=T, U=U))
+    out['bound'] = 'LDS-resident, not HBM-bound: feat stays in the attention workgroups\' LDS for the whole launch, ' \
+                   'bytes_moved_per_step (comp from L2, alpha, h1, context) is what leaves a CU per step; no fraction of ' \
+                   'the HBM peak is claimed for this stage'
     if stage_us:
         out.update(attention_stage_us=round(stage_us, 2),
-                   stage_source='profiles/%s (trace build of the builder\'s box, s1 -> s4; not a measurement of this run)' % os.path.basename(src),
-                   achieved_equivalent=round(nbytes / (stage_us * 1e-6) / 1e9, 1),
-                   frac_equivalent=round(nbytes / (stage_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
+                   stage_source='profiles/%s (trace build of the builder\'s box, s1 -> s4; not a measurement of this run)' % os.path.basename(src))
     return out
 
 
@@ -312,7 +313,7 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
     return out
 
 
-def frontend_roofline(device, n_utts=32, secs=4.5, sr=16000, n_mels=80, reps=20):
+def frontend_roofline(device, n_utts=32, secs=4.5, sr=22050, n_mels=80, reps=20):
     """SURVEY.md 8 f3, the log-mel frontend (src/preprocess.py:187-208) in its batched form: ONE
     ssasr_logmel_batch call (three launches) over `n_utts` utterances of the corpus' mean length
     (src/preprocess.py:318: 4.5 s), waveforms resident on the GPU.  Timed with HIP events around the C call
@@ -553,21 +554,25 @@ def config5_bench(device, steps=20, warmup=3, batch=32):
                 steps=steps, warmup=warmup)
 
 
-def cpu_baseline(batches):
+def cpu_baseline(batches, warm):
     """The oracle (a CPU restatement of the reference, pinned to its golden
     vectors) timed on the host cores for one train step on each of `batches`
-    (bench batches: x, y, lens), optimizer state carried from step to step."""
+    (bench batches: x, y, lens), optimizer state carried from step to step, after ONE untimed
+    full-size warm-up step on `warm` (first steps carry one-time costs --
+    allocator growth, thread pools; the first timed step of round 4 took 3 x its share)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import las_oracle as lo
     cores = host_cores()
     torch.set_num_threads(cores)
-    note('cpu baseline: %d oracle train steps on %d cores ...' % (len(batches), cores))
+    note('cpu baseline: 1 warm-up + %d timed oracle train steps on %d cores ...' % (len(batches), cores))
     torch.manual_seed(1)
     random.seed(1)
     model = lo.OracleASR(**DIMS)
     optim = lo.make_optimizer(model)
-    x0, y0, _ = batches[0]
-    lo.train_step(model, optim, x0[:2, :32].contiguous(), y0[:2])          # thread-pool warm-up
+    t0 = time.perf_counter()
+    lo.train_step(model, optim, warm[0].cpu(), warm[1].cpu())
+    warm_s = time.perf_counter() - t0
+    note('cpu baseline: warm-up %d x %d frames in %.1f s (untimed)' % (warm[0].shape[0], warm[0].shape[1], warm_s))
     utts, secs, losses = 0, [], []
     for x, y, _ in batches:
         t0 = time.perf_counter()
@@ -577,11 +582,15 @@ def cpu_baseline(batches):
         utts += x.shape[0]
         note('cpu baseline: %d x %d frames in %.1f s' % (x.shape[0], x.shape[1], secs[-1]))
     frames = [int(b[0].shape[1]) for b in batches]
-    return dict(value=round(utts / sum(secs), 4), unit='utterances/sec', cores=cores, kind='port',
-                sample='%d train steps (optimizer state carried over) on %d of the bench batches: %d utterances each, '
-                       '%s frames max, fp32, torch %s' % (len(batches), len(batches), batches[0][0].shape[0],
-                                                         '/'.join(str(f) for f in frames), torch.__version__),
-                seconds=[round(v, 2) for v in secs], loss=round(losses[-1], 5))
+    padded = sum(int(b[0].shape[0]) * int(b[0].shape[1]) for b in batches)
+    return dict(value=round(utts / sum(secs), 4), unit='utterances/sec', cores=cores, kind='port', warmup=1,
+                sample='1 untimed warm-up step (%d frames) + %d timed train steps (optimizer state carried over) on every '
+                       'second bucket of the timed region\'s eight-bucket rotation: %d utterances each, %s frames max '
+                       '(mean %.0f; the GPU region\'s rotation: %s), fp32, torch %s'
+                       % (warm[0].shape[1], len(batches), batches[0][0].shape[0], '/'.join(str(f) for f in frames),
+                          sum(frames) / len(frames), '%s', torch.__version__),
+                frames=frames, padded_frames_per_sec=round(padded / sum(secs), 1),
+                seconds=[round(v, 2) for v in secs], warmup_seconds=round(warm_s, 2), loss=round(losses[-1], 5))
 
 
 def self_launch(args):
@@ -904,7 +913,11 @@ def main():
         out['roofline_forward_recurrence'] = fwd_rec
         out['roofline_attention'] = att
         out['roofline_gemm'] = gemm_rl
+        # the reference's own configuration (src/preprocess.py:194-198: 22,050 Hz -> n_fft 551, hop 220); 16 kHz
+        # (n_fft 400, hop 160: a friendlier K for 32-deep MFMA steps) beside it
         out['roofline_frontend'] = frontend_roofline(device)
+        at16 = frontend_roofline(device, sr=16000)
+        out['roofline_frontend']['at_16khz'] = {k: at16[k] for k in ('achieved', 'frac', 'us_per_batch', 'utterances_per_sec', 'shape')}
         note('frontend: %s' % out['roofline_frontend'])
     if world == 1 and not args.no_config4:
         del stepper, loader
@@ -915,7 +928,9 @@ def main():
         out['config5'] = config5_bench(device)
         note('config 5 (Seed loop legs): %s' % out['config5'])
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline([host_batches[k] for k in (2, 4, 6)])
+        cb = cpu_baseline([host_batches[k] for k in (1, 3, 5, 7)], host_batches[7])
+        cb['sample'] = cb['sample'] % ('/'.join(str(int(b[0].shape[1])) for b in host_batches))
+        out['cpu_baseline'] = cb
     print(json.dumps(out), flush=True)
     sdist.shutdown()
 

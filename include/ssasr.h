@@ -105,27 +105,6 @@ int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int6
                      int64_t ys_s, int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
                      int32_t* sync_ws, int armed, float* tsave, void* stream);
 
-/* ssasr_bilstm_fwd in pieces, for a caller that overlaps the NEXT layer's input projection with this layer's
- * recurrence (frames are final in both directions from step S - s on for s in [S - i, i): the middle first):
- *   ssasr_bilstm_fwd_range: the steps [i0, i1) of the layer (i1 = 0: S; persistent form only, else a negative
- *     code).  Consecutive ranges are consecutive calls with the same buffers; the first call (i0 = 0) fills the
- *     exchange image unless armed and computes the input projection unless gates_ready != 0 (`gates` then already
- *     holds the pre-activations of ALL rows); later calls resume from what the earlier ones left in hx / tsave / cs.
- *   ssasr_bilstm_input_projection: gates[d][(s, n)][:] = x[s, n, :] . W_ih[d]^T + b_ih[d] + b_hh[d], both
- *     directions, for the rows with s in [r0, r1) (axis = 0) or n in [r0, r1) (axis = 1): the projection of
- *     ssasr_bilstm_fwd for part of the layer's rows, on any stream. */
-int ssasr_bilstm_fwd_range(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
-                           int64_t H, const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
-                           const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,
-                           const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* y,
-                           int64_t ys_s, int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
-                           int32_t* sync_ws, int armed, float* tsave, int64_t i0, int64_t i1, int gates_ready,
-                           void* stream);
-int ssasr_bilstm_input_projection(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
-                                  int64_t H, const float* w_ih_f, const float* b_ih_f, const float* b_hh_f,
-                                  const float* w_ih_r, const float* b_ih_r, const float* b_hh_r, float* gates,
-                                  int axis, int64_t r0, int64_t r1, void* stream);
-
 /* Backward of ssasr_bilstm_fwd.  `gates` is consumed (overwritten with the
  * gate pre-activation derivatives).  tsave: what the forward call was given (then cs may be NULL).  dx may be NULL.  db_* is the derivative
  * of b_ih and of b_hh alike.  Workspaces: ws_whhT [2][H][4H], ws_dc [2][2][N][H].

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SSASR_LIB') or os.path.join(_HERE, 'libssasr_hip.so')   # SSASR_LIB: A/B builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 P = C.c_void_p
 I64 = C.c_int64
@@ -53,9 +53,6 @@ SIGNATURES = {
                              I64, I64, I64, I64, I32, P]),
     'ssasr_bilstm_fwd': (I32, [P, I64, I64, I64, I64, I64, I64, P] + [P] * 8 +
                          [P, I64, I64, P, P, P, P, P, I32, P, P]),
-    'ssasr_bilstm_fwd_range': (I32, [P, I64, I64, I64, I64, I64, I64, P] + [P] * 8 +
-                               [P, I64, I64, P, P, P, P, P, I32, P, I64, I64, I32, P]),
-    'ssasr_bilstm_input_projection': (I32, [P, I64, I64, I64, I64, I64, I64] + [P] * 7 + [I32, I64, I64, P]),
     'ssasr_bilstm_tsave_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_fwd_hx_floats': (I64, [I64, I64, I64]),
     'ssasr_bilstm_bwd': (I32, [P, I64, I64, P, I64, I64, I64, I64, I64, I64, P] + [P] * 4 +

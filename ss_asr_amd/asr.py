@@ -57,8 +57,7 @@ class pBLSTM(nn.Module):
         super().__init__()
         self.layer = nn.LSTM(in_dim, out_dim, bidirectional=True, batch_first=True)
 
-    def forward(self, input_x, state=None, state_len=None, pack_input=False, len_dev=None, slots=None,
-                pre_gates=None, split=None):
+    def forward(self, input_x, state=None, state_len=None, pack_input=False, len_dev=None, slots=None):
         if state is not None:
             raise NotImplementedError('initial states are always zero on the hot path')
         if pack_input:
@@ -71,8 +70,7 @@ class pBLSTM(nn.Module):
                 len_dev = _dev_i32(state_len, input_x.device)
         else:
             steps, len_dev = input_x.shape[1], None
-        output = ops.bilstm(input_x, len_dev, steps, True, _lstm_weights(self.layer), slots=slots, pre_gates=pre_gates,
-                            split=split)
+        output = ops.bilstm(input_x, len_dev, steps, True, _lstm_weights(self.layer), slots=slots)
         output = self.downsample(output)
         if state_len is not None:
             return output, None, [int(s / 2) for s in state_len]
@@ -129,82 +127,11 @@ class Listener(nn.Module):
                 hx, ring = ops.bilstm_exchange_floats(S, N, H)
                 slots[k] = (arenas[0], arenas[0].reserve(hx) if hx else None,
                             arenas[1], arenas[1].reserve(ring) if ring else None)
-        # Forward overlap (train-step path; ops.fwd_overlap, OFF by default): layer k + 1's input projection for the
-        # frames of layer k that are final in BOTH directions -- the middle half, from step 3 S / 4 on -- starts on
-        # the second stream while layer k's last quarter of steps still recurs; the outer quarters follow on this
-        # stream when the recurrence has ended.  Measured negative: the forward
-        # recurrence keeps every CU, the projection beside it costs it +85 us on the first layer for 213 us of GEMM,
-        # and two quarter launches are less efficient than half a whole one: 5.85 against 5.78 ms per step.
-        plans = [None] * 3
-        if arenas is not None and pack_input and ops.fwd_overlap and x.is_cuda:
-            plans = [self._plan_next_projection(k, lens, x.shape[0], x.device) for k in range(3)]
-        gates_next = None
         for k, layer in enumerate((self.blstm_1, self.blstm_2, self.blstm_3)):
-            plan = plans[k]
             x, _, state_len = layer(x, state_len=state_len, pack_input=pack_input,
-                                    len_dev=len_devs[k] if pack_input else None, slots=slots[k],
-                                    pre_gates=gates_next, split=(plan.split, plan.on_split) if plan else None)
-            gates_next = plan.finish() if plan else None
-        x = ops.bilstm(x, None, x.shape[0], False, _lstm_weights(self.blstm_4), slots=slots[3],
-                       pre_gates=gates_next)                                               # src/asr.py:262
+                                    len_dev=len_devs[k] if pack_input else None, slots=slots[k])
+        x = ops.bilstm(x, None, x.shape[0], False, _lstm_weights(self.blstm_4), slots=slots[3])      # src/asr.py:262
         return x, state_len
-
-    def _plan_next_projection(self, k, lens, B, device):
-        """Plan of layer k + 1's (k = 0..2: blstm_2, blstm_3, blstm_4) input projection, overlapped with layer k's
-        recurrence; None when a shape is too short to be worth two launches."""
-        H = self.state_size
-        S_k, S_next = lens[k][0], lens[k + 1][0]                 # layer k's steps; the next layer's frames (S_k // 2)
-        if S_next < 16:
-            return None
-        q0 = S_next // 4
-        q1 = S_next - q0
-        split = max(2 * q1, S_k - 2 * q0)                        # frames [2 q0, 2 q1) are final in both directions after `split` steps
-        if not 0 < split < S_k:
-            return None
-        if k < 2:       # next = a pBLSTM: time-major rows (t', b), x'[t', b, :] = y_k[b, 2 t' : 2 t' + 2, :]
-            weights, axis, S2, N2 = _lstm_weights((self.blstm_2, self.blstm_3)[k].layer), 0, S_next, B
-            xs_s, xs_n = 4 * H, S_k * 2 * H
-        else:           # next = blstm_4 over the utterance axis: rows (b, t'), x'[b, t', :] = the same memory
-            weights, axis, S2, N2 = _lstm_weights(self.blstm_4), 1, B, S_next
-            xs_s, xs_n = S_k * 2 * H, 4 * H
-        return _NextProjection(weights, axis, S2, N2, 4 * H, H, xs_s, xs_n, q0, q1, split, device)
-
-
-class _NextProjection:
-    """One layer's input projection computed in three pieces around the recurrence of the layer below."""
-
-    def __init__(self, weights, axis, S, N, I, H, xs_s, xs_n, q0, q1, split, device):
-        self.w, self.axis, self.S, self.N, self.I, self.H = weights, axis, S, N, I, H
-        self.xs_s, self.xs_n, self.q0, self.q1, self.split = xs_s, xs_n, q0, q1, split
-        self.gates = torch.empty(2, S * N, 4 * H, device=device, dtype=torch.float32)
-        self.y = None
-        self.side_used = False
-
-    def _project(self, r0, r1, stream=None):
-        ops.bilstm_input_projection(self.y, self.xs_s, self.xs_n, self.S, self.N, self.I, self.H, self.w, self.gates,
-                                    self.axis, r0, r1, stream=stream)
-
-    def on_split(self, event, y):
-        """Called by the layer below between its two step ranges (event) or before its only launch (None)."""
-        self.y = y
-        if event is None:
-            return
-        side = ops.side_stream()
-        side.wait_event(event)
-        self._project(self.q0, self.q1, stream=side)
-        self.gates.record_stream(side)
-        y.record_stream(side)
-        self.side_used = True
-
-    def finish(self):
-        """After the layer below has been enqueued completely: the remaining rows on this stream."""
-        if self.side_used:
-            self._project(0, self.q0)
-            self._project(self.q1, self.S if self.axis == 0 else self.N)
-            torch.cuda.current_stream().wait_stream(ops.side_stream())
-        else:
-            self._project(0, self.S if self.axis == 0 else self.N)
-        return self.gates
 
 
 class Speller(nn.Module):

@@ -16,7 +16,7 @@ __device__ unsigned long long g_dtrace[DTR_WG * DTR_STEPS * DTR_SLOTS];
 #include "decoder_bwd_persistent.h"
 #include <cstdlib>
 
-extern "C" int ssasr_abi_version(void) { return 13; }
+extern "C" int ssasr_abi_version(void) { return 14; }
 #ifdef SSASR_TRACE_BUILD
 extern "C" int ssasr_debug_dtrace(void* dst, size_t bytes) {
   SSASR_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dtrace), bytes));

@@ -28,11 +28,11 @@ constexpr int BK = 32;        // K depth per barrier: two 16-deep MFMA sub-steps
 // their second workgroup per CU to the extra 8 KB -- not the limiter.)
 constexpr int LDK = BK + 4;
 
-template <int BMN, bool T>
+template <int BMN, bool T, int NT = 256>
 struct TileGeom {
   static constexpr int LDM = BMN + 4;                       // MN-contiguous image: [BK][LDM]
   static constexpr int FLOATS = T ? BK * LDM : BMN * LDK;
-  static constexpr int NV = BMN * BK / 4 / 256;             // float4 loads per thread per tile
+  static constexpr int NV = BMN * BK / 4 / NT;              // float4 loads per thread per tile (NT threads)
 };
 
 struct Operand {
@@ -46,9 +46,9 @@ struct Operand {
 // ONCE (the row map may need a 64-bit divide) and then advanced by a constant
 // per K step, so the steady-state loop issues plain 16-byte loads with one
 // pointer add each and no predicates.
-template <int BMN, bool T>
+template <int BMN, bool T, int NT = 256>
 struct TileLoader {
-  static constexpr int NV = TileGeom<BMN, T>::NV;
+  static constexpr int NV = TileGeom<BMN, T, NT>::NV;
   static constexpr int PER_ROW = BMN / 4;        // float4 per k-row of an MN-contiguous tile
   const float* ptr[NV];     // source of this thread's i-th float4 at the current K position
   int64_t kin[NV];          // T with an (outer, inner) map: position inside the inner run
@@ -62,7 +62,7 @@ struct TileLoader {
     m = op.m;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + i * 256;
+      const int f = tid + i * NT;
       if constexpr (!T) {
         const int row = mn0 + f / (BK / 4);
         idx[i] = row;
@@ -101,6 +101,24 @@ struct TileLoader {
         while (in >= m.inner) { in -= m.inner; off += m.so - m.inner * m.si; }
         kin[i] = in;
         ptr[i] += off;
+      }
+    }
+  }
+
+  // advance() without control flow, for loops that must stay one basic block: legal when an MN-contiguous
+  // operand's K rows are dense or their inner run is at least one K step long (at most one wrap per step)
+  __device__ __forceinline__ bool advance_flat_ok() const { return !T || m.inner == 0 || m.inner >= BK; }
+  __device__ __forceinline__ void advance_flat() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if constexpr (!T) {
+        ptr[i] += BK;
+      } else {
+        const int64_t in = kin[i] + BK;
+        const bool wrap = m.inner != 0 && in >= m.inner;
+        kin[i] = wrap ? in - m.inner : in;
+        const int64_t step = m.inner ? (int64_t)BK * m.si : (int64_t)BK * m.ld;
+        ptr[i] += step + (wrap ? m.so - m.inner * m.si : 0);
       }
     }
   }
@@ -452,32 +470,36 @@ __device__ __forceinline__ void x_store4(char* img, int row, int slot, float k0,
 // give a lane its eight consecutive k.  The 32-byte blocks of a row are XOR-ed with a function of k
 // such that the eight rows a 32-lane half reads (k0 .. k0 + 3 and k0 + 8 .. k0 + 11) fall on
 // different banks.
-template <int BMN>
+// W32 (the wide kernel's 32 x 32 x 16 fragments): a 32-lane half reads four k rows of TWO neighbouring 32-byte
+// blocks (mn 0..15 and 16..31 of the fragment), so the block index is XOR-ed with 2 (k & 3): eight distinct
+// bank groups.
+template <int BMN, bool W32 = false>
 __device__ __forceinline__ int xt_swz(int k) {
+  if constexpr (W32) return 2 * (k & 3);
   return BMN >= 128 ? ((k & 3) | (((k >> 3) & 1) << 2)) : ((k & 3) ^ ((k >> 3) & 1));
 }
-template <int BMN>
+template <int BMN, bool W32 = false>
 __device__ __forceinline__ int xt_off(int k, int mn) {       // byte offset of (k, mn) inside a plane
-  return k * (BMN * 2) + ((((mn >> 4) ^ xt_swz<BMN>(k)) << 5) | ((mn & 15) * 2));
+  return k * (BMN * 2) + ((((mn >> 4) ^ xt_swz<BMN, W32>(k)) << 5) | ((mn & 15) * 2));
 }
 
-template <int BMN>
-struct XTLoader : TileLoader<BMN, true> {
-  static constexpr int NV = TileGeom<BMN, true>::NV;
+template <int BMN, int NT = 256, bool W32 = false>
+struct XTLoader : TileLoader<BMN, true, NT> {
+  static constexpr int NV = TileGeom<BMN, true, NT>::NV;
   static constexpr int PER_ROW = BMN / 4;
   int tid_;
   __device__ __forceinline__ void init(const Operand& op, int mn0, int k0, int tid, int) {
-    TileLoader<BMN, true>::init(op, mn0, k0, tid);
+    TileLoader<BMN, true, NT>::init(op, mn0, k0, tid);
     tid_ = tid;
   }
   __device__ __forceinline__ void store(char* img, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid_ + i * 256;
+      const int f = tid_ + i * NT;
       uint32_t a1, a2, a3, b1, b2, b3;
       x_split2(v[i].x, v[i].y, a1, a2, a3);
       x_split2(v[i].z, v[i].w, b1, b2, b3);
-      char* dst = img + xt_off<BMN>(f / PER_ROW, (f % PER_ROW) * 4);
+      char* dst = img + xt_off<BMN, W32>(f / PER_ROW, (f % PER_ROW) * 4);
       *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
       *reinterpret_cast<uint2*>(dst + XGeom<BMN>::PLANE) = make_uint2(a2, b2);
       *reinterpret_cast<uint2*>(dst + 2 * XGeom<BMN>::PLANE) = make_uint2(a3, b3);
@@ -486,25 +508,25 @@ struct XTLoader : TileLoader<BMN, true> {
 };
 
 // K-contiguous operand: the fp32 kernel's loader, stored through the split
-template <int BMN>
-struct XNLoader : TileLoader<BMN, false> {
-  static constexpr int NV = TileGeom<BMN, false>::NV;
+template <int BMN, int NT = 256>
+struct XNLoader : TileLoader<BMN, false, NT> {
+  static constexpr int NV = TileGeom<BMN, false, NT>::NV;
   __device__ __forceinline__ void init(const Operand& op, int mn0, int k0, int tid, int) {
-    TileLoader<BMN, false>::init(op, mn0, k0, tid);
+    TileLoader<BMN, false, NT>::init(op, mn0, k0, tid);
     this->tid_ = tid;
   }
   int tid_;
   __device__ __forceinline__ void store(char* img, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid_ + i * 256;
+      const int f = tid_ + i * NT;
       x_store4<BMN>(img, f / (BK / 4), f % (BK / 4), v[i].x, v[i].y, v[i].z, v[i].w);
     }
   }
 };
 
-template <int BMN, bool T> struct XLoaderOf { using type = XNLoader<BMN>; static constexpr int NV = TileGeom<BMN, false>::NV; };
-template <int BMN> struct XLoaderOf<BMN, true> { using type = XTLoader<BMN>; static constexpr int NV = TileGeom<BMN, true>::NV; };
+template <int BMN, bool T, int NT = 256, bool W32 = false> struct XLoaderOf { using type = XNLoader<BMN, NT>; static constexpr int NV = TileGeom<BMN, false, NT>::NV; };
+template <int BMN, int NT, bool W32> struct XLoaderOf<BMN, true, NT, W32> { using type = XTLoader<BMN, NT, W32>; static constexpr int NV = TileGeom<BMN, true, NT>::NV; };
 
 template <int BMN>
 __device__ __forceinline__ bf16x8 x_frag(const char* img, int plane, int row, int q) {
@@ -680,6 +702,327 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc gin, bool vecA, b
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The wide form of the split-bf16 kernel: 256 x 128 block tile, 512 threads = 8 waves in a 4 (M) x 2 (N)
+// grid of 64 x 64 wave tiles, ONE workgroup per CU, two LDS stages of 72 KB, one barrier per K step.
+//
+// Why: PMC on the 128 x 128 form (profiles/r03_gemm_pmc.txt) counts 2.76 vector instructions per MFMA -- the
+// operand split (global fp32 -> three bf16 planes, ~9 instructions per pair of values) of a 128 x 32 tile of
+// EACH operand per 96 MFMAs of a wave.  A v_mfma_f32_16x16x32_bf16 occupies the matrix pipe for 16 cycles and
+// holds the SIMD's vector issue for 8 of them; 2.76 x 4 + 8 = 19 cycles of issue per MFMA: the 128 x 128
+// kernel is bound by vector issue, not by the matrix pipe.  A 256 x 128 tile splits (256 + 128) x 32 values
+// per 2 x 96 MFMAs of a SIMD's two waves: 1.1 vector instructions per MFMA for the split, and 25 % fewer LDS
+// bytes per MFMA.  The two waves of a SIMD now belong to ONE workgroup and meet at its barrier, so the loop
+// is pipelined by hand: fragments are read plane pair by plane pair in front of the step that needs them,
+// the next tile's split + store goes between the MFMA steps into the OTHER stage, and the global loads of the
+// tile after that are issued as soon as the split has freed their registers.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Fragments of v_mfma_f32_32x32x16_bf16: lane l holds row (mn) base + (l & 31), k = 16 h + 8 (l >> 5) .. + 7 of the
+// K step's half h.  K-contiguous image: one ds_read_b128 (the chunk XOR of x_store4 keeps the 16 lanes of a
+// read group on 16 different 16-byte bank groups).
+template <int BMN>
+__device__ __forceinline__ bf16x8 x32_frag(const char* img, int plane, int base, int h, int lane) {
+  const int row = base + (lane & 31), chunk = 2 * h + (lane >> 5);
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + plane * XGeom<BMN>::PLANE + row * XROW + ((chunk ^ ((row >> 2) & 3)) * 16)));
+}
+// MN-contiguous image (W32 swizzle): two transposing reads; a 16-lane group addresses a 4 (k) x 16 (mn) block
+template <int BMN>
+__device__ __forceinline__ bf16x8 xt32_frag(const char* img, int plane, int base, int h, int lane) {
+  const int i = lane & 15;
+  const int k = 16 * h + 8 * (lane >> 5) + (i >> 2);
+  const int mn = base + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+  const char* p = img + plane * XGeom<BMN>::PLANE;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + xt_off<BMN, true>(k, mn)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + xt_off<BMN, true>(k + 4, mn)));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+template <int BMN, bool T>
+__device__ __forceinline__ bf16x8 x32_operand(const char* img, int plane, int base, int h, int lane) {
+  if constexpr (T) return xt32_frag<BMN>(img, plane, base, h, lane);
+  else return x32_frag<BMN>(img, plane, base, h, lane);
+}
+
+// Epilogue of the wide kernel: acc[i][j] = the wave's 32 x 32 blocks (D layout of v_mfma_f32_32x32x16_bf16: column =
+// lane & 31, row = 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3)).  TR: the products were accumulated transposed, so the
+// lane's column is the output ROW m and four consecutive registers are four consecutive output COLUMNS (16-byte stores).
+// add != 0: the values are ADDED atomically (split-K slices, stream-K parts); lead: this part brings the biases.
+template <int TM, int TN, bool TR>
+__device__ __forceinline__ void gemm_epilogue32(const GemmDesc& g, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                int lane, int bz, bool lead, bool add) {
+  float* C = g.C + (int64_t)bz * g.sc;
+  const float* b1 = g.bias1 ? g.bias1 + (int64_t)bz * g.sbias : nullptr;
+  const float* b2 = g.bias2 ? g.bias2 + (int64_t)bz * g.sbias : nullptr;
+  const int c = lane & 31, hq = lane >> 5;
+  if constexpr (!TR) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int m = m0 + i * 32 + 8 * (rg >> 2) + 4 * hq + (rg & 3);
+        if (m >= g.M) continue;
+        const int64_t rowoff = rm_off(g.mc, m);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + j * 32 + c;
+          if (n >= g.N) continue;
+          float v = g.alpha * acc[i][j][rg];
+          if (lead) {
+            if (b1) v += b1[n];
+            if (b2) v += b2[n];
+          }
+          if (add) {
+            atomicAdd(C + rowoff + n, v);
+          } else {
+            v = gemm_act(g.act, v);
+            if (g.beta != 0.f) v += g.beta * C[rowoff + n];
+            C[rowoff + n] = v;
+          }
+        }
+      }
+    return;
+  }
+  const bool vecC = map_vec_ok_dev(g.mc) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + i * 32 + c;
+    if (m >= g.M) continue;
+    const int64_t rowoff = rm_off(g.mc, m);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int nb = n0 + j * 32 + 8 * g4 + 4 * hq;
+        if (nb >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = g.alpha * acc[i][j][4 * g4 + e];
+          if (lead && nb + e < g.N) {
+            if (b1) v[e] += b1[nb + e];
+            if (b2) v[e] += b2[nb + e];
+          }
+        }
+        if (add) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nb + e < g.N) atomicAdd(C + rowoff + nb + e, v[e]);
+          continue;
+        }
+        if (g.act == 3) {        // (re, im) column pairs -> power (see gemm_epilogue)
+          float* dst = C + rowoff + (nb >> 1);
+          if (nb + 1 < g.N) dst[0] = v[0] * v[0] + v[1] * v[1];
+          if (nb + 3 < g.N) dst[1] = v[2] * v[2] + v[3] * v[3];
+          continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gemm_act(g.act, v[e]);
+        if (vecC && nb + 3 < g.N) {
+          float4* dst = reinterpret_cast<float4*>(C + rowoff + nb);
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (g.beta != 0.f) {
+            const float4 c0 = *dst;
+            o.x += g.beta * c0.x; o.y += g.beta * c0.y; o.z += g.beta * c0.z; o.w += g.beta * c0.w;
+          }
+          *dst = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (nb + e >= g.N) continue;
+            float o = v[e];
+            if (g.beta != 0.f) o += g.beta * C[rowoff + nb + e];
+            C[rowoff + nb + e] = o;
+          }
+        }
+      }
+  }
+}
+
+constexpr int WIDE_BM = 256, WIDE_BN = 128, WIDE_NT = 512;
+constexpr int WIDE_STAGE = XGeom<WIDE_BM>::BYTES + XGeom<WIDE_BN>::BYTES;      // 73,728 bytes
+
+template <bool TA, bool TB, bool TR, bool SEG = false>
+__global__ __launch_bounds__(WIDE_NT, 2) void gemm_x6w_kernel(GemmDesc gin, bool vecA, bool vecB) {
+  constexpr int BM = WIDE_BM, BN = WIDE_BN, NT = WIDE_NT;
+  constexpr int WM = 64, WN = 64, TM = 2, TN = 2;      // per wave: 2 x 2 blocks of 32 x 32
+  extern __shared__ __attribute__((aligned(16))) char xlds[];
+  static_assert(!SEG || (TA && TB), "column segments: both operands MN-contiguous");
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by, bzz;
+  gemm_tile_of_block(bx, by, bzz);
+  GemmDesc g = gin;
+  const int bz = bzz / g.splitk;
+  const int kz = bzz - bz * g.splitk;
+  bool do_colsum = false;
+  if constexpr (SEG) {
+    const int nt0 = (gin.seg[0].N + BN - 1) / BN;
+    const int sidx = bx >= nt0 ? 1 : 0;
+    do_colsum = bx == 0 && gin.colsum[bz] != nullptr;
+    if (sidx) bx -= nt0;
+    g.A = gin.seg[sidx].A[bz]; g.sa = 0;
+    g.B = gin.seg[sidx].B[bz]; g.sb = 0; g.mb = gin.seg[sidx].mb;
+    g.C = gin.seg[sidx].C[bz]; g.sc = 0; g.mc = RowMap{gin.seg[sidx].ldc, 0, 0, 0};
+    g.N = gin.seg[sidx].N; g.K = gin.seg[sidx].K;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+
+  const int ktot = g.kcat > 1 ? g.kcat * g.K : g.K;
+  int kchunk = (ktot + g.splitk - 1) / g.splitk;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  const int kbeg = kz * kchunk;
+  const int kend = min(ktot, kbeg + kchunk);
+  const int64_t jumpA = g.kcat > 1 ? g.ska - (TA ? (int64_t)g.K * g.ma.ld : (int64_t)g.K) : 0;
+  const int64_t jumpB = g.kcat > 1 ? g.skb - (TB ? (int64_t)g.K * g.mb.ld : (int64_t)g.K) : 0;
+
+  Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
+  Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
+  typename XLoaderOf<BM, TA, NT, true>::type la;
+  typename XLoaderOf<BN, TB, NT, true>::type lb;
+  la.init(opA, m0, kbeg, tid, 0);
+  lb.init(opB, n0, kbeg, tid, 128);
+  const bool interior = vecA && vecB && (!TA || g.M % 4 == 0) && (!TB || g.N % 4 == 0);
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto colsum_add = [&](const float4 (&v)[XLoaderOf<BM, TA, NT>::NV]) {
+    if (la.idx[0] < g.M) {
+#pragma unroll
+      for (int i = 0; i < XLoaderOf<BM, TA, NT>::NV; ++i) { csum.x += v[i].x; csum.y += v[i].y; csum.z += v[i].z; csum.w += v[i].w; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ra / rb hold the fp32 values of the tile AFTER the one in LDS
+  float4 ra[XLoaderOf<BM, TA, NT>::NV], rb[XLoaderOf<BN, TB, NT>::NV];
+  auto fetch = [&](int k) {              // global loads of the K step that starts at k (loaders already there)
+    if (interior && k + BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
+    else { la.load_guarded(ra, k, kend, vecA); lb.load_guarded(rb, k, kend, vecB); }
+  };
+  auto step_loaders = [&](int k) {       // move the loaders from the K step before k to k
+    la.advance();
+    lb.advance();
+    if (g.kcat > 1 && k % g.K == 0) { la.jump(jumpA); lb.jump(jumpB); }
+  };
+  if (kbeg < kend) {
+    fetch(kbeg);
+    la.store(xlds, ra);
+    lb.store(xlds + XGeom<BM>::BYTES, rb);
+    if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
+    if (kbeg + BK < kend) { step_loaders(kbeg + BK); fetch(kbeg + BK); }
+  }
+  __syncthreads();
+
+  int stage = 0;
+  int k0 = kbeg;
+#define SSASR_XW_READ_A(P) _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int h = 0; h < 2; ++h) \
+    fa[P][i][h] = x32_operand<BM, TA>(curA, P, wm * WM + i * 32, h, lane)
+#define SSASR_XW_READ_B(P) _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int h = 0; h < 2; ++h) \
+    fb[P][j][h] = x32_operand<BN, TB>(curB, P, wn * WN + j * 32, h, lane)
+#define SSASR_XW_STEP(PA, PB)                                                                      \
+  _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                    \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
+    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][j][h], fa[PA][i][h], acc[i][j], 0, 0, 0)  \
+                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i][h], fb[PB][j][h], acc[i][j], 0, 0, 0)
+  // Steady state: this K step's tile in LDS, the next one's values in registers, the one after that still to be
+  // fetched, all three full steps of the predicate-free path -- ONE basic block (no branch, no loop inside).
+  if (interior && la.advance_flat_ok() && lb.advance_flat_ok()) {
+    for (; k0 + 3 * BK <= kend; k0 += BK) {
+      const char* curA = xlds + stage * WIDE_STAGE;
+      const char* curB = curA + XGeom<BM>::BYTES;
+      char* nxt = xlds + (stage ^ 1) * WIDE_STAGE;
+      bf16x8 fa[3][TM][2], fb[3][TN][2];
+      SSASR_XW_READ_A(2); SSASR_XW_READ_B(0);
+      SSASR_XW_READ_A(0); SSASR_XW_READ_B(2);
+      SSASR_XW_STEP(2, 0);      // smallest terms first
+      SSASR_XW_READ_A(1); SSASR_XW_READ_B(1);
+      SSASR_XW_STEP(0, 2);
+      la.store(nxt, ra);        // the tile after this one: split + store into the other stage
+      if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
+      SSASR_XW_STEP(1, 1);
+      lb.store(nxt + XGeom<BM>::BYTES, rb);
+      SSASR_XW_STEP(1, 0);
+      {                         // the tile after that: its registers are free now
+        la.advance_flat();
+        lb.advance_flat();
+        const bool seg_end = g.kcat > 1 && (k0 + 2 * BK) % g.K == 0;
+        la.jump(seg_end ? jumpA : 0);
+        lb.jump(seg_end ? jumpB : 0);
+        la.load_fast(ra);
+        lb.load_fast(rb);
+      }
+      SSASR_XW_STEP(0, 1);
+      SSASR_XW_STEP(0, 0);
+      __syncthreads();          // the next tile is in place, this one is no longer read
+      stage ^= 1;
+    }
+  }
+  // the last two K steps, partial steps, guarded operands
+  for (; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    const bool more2 = k0 + 2 * BK < kend;
+    const char* curA = xlds + stage * WIDE_STAGE;
+    const char* curB = curA + XGeom<BM>::BYTES;
+    char* nxt = xlds + (stage ^ 1) * WIDE_STAGE;
+    bf16x8 fa[3][TM][2], fb[3][TN][2];
+    SSASR_XW_READ_A(2); SSASR_XW_READ_B(0);
+    SSASR_XW_READ_A(0); SSASR_XW_READ_B(2);
+    SSASR_XW_READ_A(1); SSASR_XW_READ_B(1);
+    SSASR_XW_STEP(2, 0);
+    SSASR_XW_STEP(0, 2);
+    SSASR_XW_STEP(1, 1);
+    if (more) {
+      la.store(nxt, ra);
+      lb.store(nxt + XGeom<BM>::BYTES, rb);
+      if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
+    }
+    if (more2) { step_loaders(k0 + 2 * BK); fetch(k0 + 2 * BK); }
+    SSASR_XW_STEP(1, 0);
+    SSASR_XW_STEP(0, 1);
+    SSASR_XW_STEP(0, 0);
+    __syncthreads();
+    stage ^= 1;
+  }
+#undef SSASR_XW_STEP
+#undef SSASR_XW_READ_A
+#undef SSASR_XW_READ_B
+  gemm_epilogue32<TM, TN, TR>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, bz, kz == 0, g.splitk > 1);
+  if constexpr (SEG) {
+    if (do_colsum) {          // (workgroup-uniform) the NT / (BM / 4) threads of a column quad meet in LDS
+      constexpr int PER_ROW = BM / 4;
+      float4* red = reinterpret_cast<float4*>(xlds);          // the operand images are no longer read
+      red[tid] = csum;
+      __syncthreads();
+      if (tid < PER_ROW) {
+        float4 v = red[tid];
+#pragma unroll
+        for (int k = 1; k < NT / PER_ROW; ++k) {
+          const float4 a = red[tid + k * PER_ROW];
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        const int m = m0 + 4 * tid;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (m + e < g.M) {
+            atomicAdd(gin.colsum[bz] + m + e, g.alpha * vv[e]);
+            if (gin.colsum2[bz]) atomicAdd(gin.colsum2[bz] + m + e, g.alpha * vv[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool map_vec_ok(const RowMap& m) {
   return m.inner ? (m.so % 4 == 0 && m.si % 4 == 0) : (m.ld % 4 == 0);
@@ -746,6 +1089,42 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
   return SSASR_OK;
 }
 
+int launch_wide(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
+  GemmDesc g = gin;
+  dim3 grid((g.N + WIDE_BN - 1) / WIDE_BN, (g.M + WIDE_BM - 1) / WIDE_BM, g.batch * g.splitk);
+  dim3 block(WIDE_NT);
+  constexpr size_t lds = 2 * WIDE_STAGE;
+#define SSASR_XW_LAUNCH(...)                                                                                \
+  do {                                                                                                      \
+    auto fn = gemm_x6w_kernel<__VA_ARGS__>;                                                                 \
+    static bool once = false;                                                                               \
+    if (!once) {                                                                                            \
+      SSASR_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      once = true;                                                                                          \
+    }                                                                                                       \
+    hipLaunchKernelGGL(fn, grid, block, lds, st, g, vecA, vecB);                                            \
+  } while (0)
+  if (g.nseg > 0) {
+    int nt = 0;
+    for (int k = 0; k < g.nseg; ++k) nt += (g.seg[k].N + WIDE_BN - 1) / WIDE_BN;
+    grid.x = (unsigned)nt;
+    SSASR_XW_LAUNCH(true, true, false, true);
+  } else if (g.splitk > 1) {
+    if (!g.ta && !g.tb) SSASR_XW_LAUNCH(false, false, false);
+    else if (!g.ta && g.tb) SSASR_XW_LAUNCH(false, true, false);
+    else if (g.ta && !g.tb) SSASR_XW_LAUNCH(true, false, false);
+    else SSASR_XW_LAUNCH(true, true, false);
+  } else {
+    if (!g.ta && !g.tb) SSASR_XW_LAUNCH(false, false, true);
+    else if (!g.ta && g.tb) SSASR_XW_LAUNCH(false, true, true);
+    else if (g.ta && !g.tb) SSASR_XW_LAUNCH(true, false, true);
+    else SSASR_XW_LAUNCH(true, true, true);
+  }
+#undef SSASR_XW_LAUNCH
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
 }  // namespace
 
 size_t ssasr_gemm_min_lds_bytes() {
@@ -800,7 +1179,9 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
   if (g.tile == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
   if (g.tile == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
+  if (g.tile == 256 && ssasr_options().gemm_x6) return launch_wide(g, vecA, vecB, st);
   if (const int forced = ssasr_options().gemm_tile) {       // diagnostic: force a tile shape
+    if (forced == 256 && ssasr_options().gemm_x6) return launch_wide(g, vecA, vecB, st);
     if (forced == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
     if (forced == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
   }

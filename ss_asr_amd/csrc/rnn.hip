@@ -89,45 +89,6 @@ extern "C" int64_t ssasr_bilstm_fwd_hx_floats(int64_t S, int64_t N, int64_t H) {
 // ---------------------------------------------------------------------------
 // C-ABI: bidirectional LSTM layer over a logical time-major [S, N, I] input.
 // ---------------------------------------------------------------------------
-// The input projection of a layer for PART of its rows: gates[d][(s, n)] = x[s, n, :] . W_ih[d]^T + b_ih[d] + b_hh[d]
-// for s in [r0, r1) (axis = 0) or n in [r0, r1) (axis = 1), both directions.  What ssasr_bilstm_fwd computes for all
-// rows before its recurrence; a caller that overlaps the projection of the frames that are already final with the
-// recurrence of the layer below (ssasr_bilstm_fwd_range) computes it piecewise and passes gates_ready = 1.
-extern "C" int ssasr_bilstm_input_projection(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N, int64_t I,
-                                             int64_t H, const float* w_ih_f, const float* b_ih_f, const float* b_hh_f,
-                                             const float* w_ih_r, const float* b_ih_r, const float* b_hh_r, float* gates,
-                                             int axis, int64_t r0, int64_t r1, void* stream) {
-  if (!x || !gates || !w_ih_f || !w_ih_r || S <= 0 || N <= 0 || I <= 0 || H <= 0 || axis < 0 || axis > 1 || r0 < 0 ||
-      r1 > (axis ? N : S))
-    return SSASR_EARG;
-  if (r1 <= r0) return SSASR_OK;
-  const float* wih[2] = {w_ih_f, w_ih_r};
-  const float* bih[2] = {b_ih_f, b_ih_r};
-  const float* bhh[2] = {b_hh_f, b_hh_r};
-  const int64_t rows = S * N;
-  const bool paired = bih[0] && bhh[0] && bih[1] && bhh[1] && (wih[1] - wih[0]) % 4 == 0 && (bih[1] - bih[0]) == (bhh[1] - bhh[0]);
-  for (int d = 0; d < (paired ? 1 : 2); ++d) {
-    GemmDesc g{};
-    if (axis == 0) {           // rows (s, n), s in [r0, r1): a contiguous run of the time-major rows
-      g.A = x + r0 * xs_s; g.ma = RowMap{0, N, xs_s, xs_n};
-      g.C = gates + d * rows * 4 * H + r0 * N * 4 * H; g.mc = rm_dense(4 * H);
-      g.M = (int)((r1 - r0) * N);
-    } else {                   // rows (s, n), n in [r0, r1), every s: row index s * (r1 - r0) + j <-> (s, r0 + j)
-      g.A = x + r0 * xs_n; g.ma = RowMap{0, r1 - r0, xs_s, xs_n};
-      g.C = gates + d * rows * 4 * H + r0 * 4 * H; g.mc = RowMap{0, r1 - r0, N * 4 * H, 4 * H};
-      g.M = (int)((r1 - r0) * S);
-    }
-    g.B = wih[d]; g.mb = rm_dense(I);
-    g.N = (int)(4 * H); g.K = (int)I;
-    g.ta = 0; g.tb = 0; g.bias1 = bih[d]; g.bias2 = bhh[d];
-    g.alpha = 1.f; g.beta = 0.f; g.splitk = 1; g.batch = 1;
-    if (paired) { g.batch = 2; g.sa = 0; g.sb = wih[1] - wih[0]; g.sc = rows * 4 * H; g.sbias = bih[1] - bih[0]; }
-    const int rc = ssasr_launch_gemm(g, (hipStream_t)stream);
-    if (rc) return rc;
-  }
-  return SSASR_OK;
-}
-
 extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N,
                                 int64_t I, int64_t H, const int32_t* lens,
                                 const float* w_ih_f, const float* w_hh_f, const float* b_ih_f,
@@ -135,27 +96,8 @@ extern "C" int ssasr_bilstm_fwd(const float* x, int64_t xs_s, int64_t xs_n, int6
                                 const float* b_ih_r, const float* b_hh_r, float* y, int64_t ys_s,
                                 int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
                                 int32_t* sync_ws, int armed, float* tsave, void* stream) {
-  return ssasr_bilstm_fwd_range(x, xs_s, xs_n, S, N, I, H, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r,
-                                b_hh_r, y, ys_s, ys_n, gates, cs, hs, hx, sync_ws, armed, tsave, 0, 0, 0, stream);
-}
-
-// ssasr_bilstm_fwd for the steps [i0, i1) of the layer (i1 = 0: S) -- persistent form only -- and, with
-// gates_ready != 0, on pre-activations the caller has already put into `gates` (ssasr_bilstm_input_projection).
-// Consecutive ranges of one layer are consecutive calls with the same buffers (armed = 1 from the second on: the
-// exchange image keeps what the earlier ranges published); only the first call projects / fills.
-extern "C" int ssasr_bilstm_fwd_range(const float* x, int64_t xs_s, int64_t xs_n, int64_t S, int64_t N,
-                                      int64_t I, int64_t H, const int32_t* lens,
-                                      const float* w_ih_f, const float* w_hh_f, const float* b_ih_f,
-                                      const float* b_hh_f, const float* w_ih_r, const float* w_hh_r,
-                                      const float* b_ih_r, const float* b_hh_r, float* y, int64_t ys_s,
-                                      int64_t ys_n, float* gates, float* cs, float* hs, float* hx,
-                                      int32_t* sync_ws, int armed, float* tsave, int64_t i0, int64_t i1,
-                                      int gates_ready, void* stream) {
   const SsasrOptions& opt = ssasr_options();
   if (S <= 0 || N <= 0 || I <= 0 || H <= 0 || H % 16 != 0) return SSASR_EARG;
-  if (i1 <= 0) i1 = S;
-  if (i0 < 0 || i0 >= i1 || i1 > S) return SSASR_EARG;
-  const bool ranged = i0 != 0 || i1 != S;
   if (!x || !y || !gates || (!cs && !tsave) || !hs) return SSASR_EARG;
   if (tsave && !aligned16(tsave)) return SSASR_EARG;
   hipStream_t st = (hipStream_t)stream;
@@ -220,13 +162,12 @@ extern "C" int ssasr_bilstm_fwd_range(const float* x, int64_t xs_s, int64_t xs_n
     // tile-major saves exist in the persistent form only: a caller that passes the buffer was told
     // by ssasr_bilstm_tsave_floats that this shape takes it
     if (tsave && !fits) return SSASR_EARG;
-    if (ranged && !fits) return SSASR_EARG;          // step ranges exist in the persistent form only
-    if (!fuse_in && !gates_ready && i0 == 0) {
+    if (!fuse_in) {
       const int rc = input_projection();
       if (rc) return rc;
     }
     if (fits) {
-      if (!armed && i0 == 0)
+      if (!armed)
         SSASR_HIP(hipMemsetD32Async((hipDeviceptr_t)hx, (int)PERSIST_SENTINEL, (size_t)ssasr_bilstm_fwd_hx_floats(S, N, H), st));
       float* hxw = hx;
       for (int64_t w = 0; w < nwin; ++w) {
@@ -246,7 +187,6 @@ extern "C" int ssasr_bilstm_fwd_range(const float* x, int64_t xs_s, int64_t xs_n
         p.delay = persist_delay(opt.delay_fwd, 24);
         p.ys_s = (int)ys_s; p.ys_n = (int)ys_n; p.S = (int)S; p.N = (int)Nw; p.H = (int)H;
         p.nt = nwin > 1 ? (int)N : 0;
-        p.i0 = (int)i0; p.i1 = (int)i1;
         fwd_launch(kpw, nb, fuse_in, dim3((unsigned)(H / 4), 2, (unsigned)chunks), st, p);   // 4 recurrence waves + the helper
         hxw += fwd_hx_floats_window(S, Nw, H);
       }

@@ -383,11 +383,6 @@ struct EncPersist {
   // every pointer (gates, cs, hs, y, lens, tsave, x) has been advanced to the window's first column by the host.
   // The exchange image hx is the window's own.  0: the launch covers the whole layer (nt = N).
   int nt;
-  // Steps [i0, i1) of the S steps in this launch (i1 = 0: S).  A launch that does not start at 0 resumes from what
-  // its predecessor left in memory: h_{i0-1} in the exchange image, c_{i0-1} in tsave / cs.  Lets the caller put an
-  // event between two ranges of one layer (the next layer's input projection for the frames that are final in both
-  // directions can start beside the second range: ops.py, forward overlap).
-  int i0, i1;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -613,7 +608,7 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
       }
     };
     // KI > 0: the recurrence waves form the input projection themselves (below): nothing to stream here
-    const int i0 = e.i0, i1 = e.i1 > 0 ? e.i1 : S;      // this launch's steps
+    const int i0 = 0, i1 = S;
     if (KI == 0) {
       fetch(i0); publish(i0);
       if (i0 + 1 < i1) fetch(i0 + 1);
@@ -621,7 +616,7 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
     for (int i = i0; i < i1; ++i) {
       if (i > 0) {
         SSASR_PTRACE_H(i, 8);
-        if (i > i0) pacer.sleep();                    // (a resumed launch's first step: its operands are long there)
+        pacer.sleep();
         SSASR_PTRACE_H(i, 9);
         __syncthreads();                              // operand loads released
       }
@@ -649,14 +644,8 @@ __global__ __launch_bounds__(FWD_THREADS) void lstm_enc_fwd_persistent_kernel(En
   const int bt = wave;                          // epilogue role of waves 0 and 1
   const int n = n0 + 16 * bt + r;
   const bool epi = bt < NB && n < N;
-  const int i0 = e.i0, i1 = e.i1 > 0 ? e.i1 : S;        // this launch's steps
+  const int i0 = 0, i1 = S;
   float cstate = 0.f;
-  if (i0 > 0 && epi) {
-    // resume: c of the step before, which the previous launch's helper wave left tile-major in tsave or row-major in cs
-    const int spv = d ? S - i0 : i0 - 1;
-    cstate = e.tsave ? e.tsave[tsave_index(d, spv, n >> 4, tile >> 2, 4, S, (NT + 15) >> 4, H >> 4) + ((tile & 3) * 16 + (n & 15)) * 4 + q]
-                     : e.cs[((int64_t)d * rows + (int64_t)spv * NT + n) * H + u];
-  }
   // KI > 0 (narrow input, the 80 mel bins of the first layer): W_ih x_s is part of the SAME K-split
   // product.  Wave w multiplies the features 16 j + 4 q + w (one MFMA per j) into its accumulators
   // while its exchange loads are in flight -- the matrix pipe is idle then -- so the pre-activations

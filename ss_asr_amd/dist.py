@@ -86,6 +86,39 @@ def broadcast_flat(flat_data):
         dist.broadcast(flat_data, src=0)
 
 
+def barrier():
+    """Every rank waits here for every other (no-op without a process group).  The trainers call it after rank
+    0 has written a checkpoint: the next leg of the Seed loop reads that file on EVERY rank."""
+    if is_active():
+        dist.barrier()
+
+
+def broadcast_module(module):
+    """Rank 0's parameters AND buffers of `module` on every rank -- for modules that are read but not trained
+    by a step object (ADVTrainStep's text encoder) and for batch-norm running statistics, which no flat
+    parameter buffer holds."""
+    if not is_active():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=0)
+
+
+def broadcast_buffers(*modules):
+    """Rank 0's buffers (batch-norm running statistics) of the modules on every rank."""
+    if is_active():
+        for m in modules:
+            for b in m.buffers():
+                dist.broadcast(b.data, src=0)
+
+
+def save_atomic(obj, path):
+    """torch.save through a temporary file in the same directory + os.replace: a reader never sees a
+    half-written archive (torch.save writes in place)."""
+    tmp = '%s.tmp.%d' % (path, os.getpid())
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
 def allreduce_grad(flat_grad):
     """SUM all-reduce of the flat gradient; returns the scale (1/world) the
     optimizer kernel must apply."""
@@ -123,10 +156,23 @@ class GradReducer:
         # a no-op"), never a training mode
         self.overlap = not os.environ.get('SSASR_DDP_NO_OVERLAP')
         self.skip = False
-        self.pending = None            # deferred tail gradients (data_ptr) still awaited this step
+        self.pending = None            # deferred tail gradients (float offsets in flat.grad) still awaited this step
         self.learned = None            # the set of deferred tail gradients, observed in the first step
         self.seen = set()
         self.work = None
+        self._grad_ptr = flat.grad.data_ptr()      # the flat buffers are allocated once (checked every step)
+
+    def _offsets(self, sinks):
+        """Float offsets inside flat.grad of those gradient tensors `sinks` that are views of it."""
+        base, n = self.flat.grad.data_ptr(), self.flat.grad.numel()
+        if base != self._grad_ptr:
+            raise RuntimeError('GradReducer: the flat gradient buffer was reallocated after the step object was built')
+        offs = []
+        for t in sinks:
+            o = (t.data_ptr() - base) // 4
+            if 0 <= o < n:             # (gradients of another model's buffer: another step object's business)
+                offs.append(o)
+        return offs
 
     def begin(self):
         self.work = None
@@ -140,7 +186,7 @@ class GradReducer:
         second stream.  Which gradients arrive that way is learned from the first step;
         from then on, when the last of the tail's has arrived, the tail is reduced
         right behind it."""
-        ptrs = [t.data_ptr() for t in sinks]
+        ptrs = self._offsets(sinks)
         self.seen.update(ptrs)
         if self.pending is None:
             return
@@ -182,7 +228,6 @@ class GradReducer:
             self.work = None
             dist.all_reduce(self.flat.grad[:self.split], op=dist.ReduceOp.SUM)
         if self.learned is None and self.split:
-            head_end = self.flat.grad.data_ptr() + 4 * self.split
-            self.learned = frozenset(p for p in self.seen if p >= head_end)
+            self.learned = frozenset(o for o in self.seen if o >= self.split)
         self.pending = None
         return 1.0 / dist.get_world_size()

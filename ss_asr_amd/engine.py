@@ -175,6 +175,10 @@ class ADVTrainStep:
         self.span = self.asr_flat.range_of(list(asr_model.encoder.parameters()))
         sdist.broadcast_flat(self.asr_flat.data)
         sdist.broadcast_flat(self.d_flat.data)
+        # the text autoencoder is only READ here (its encoder's frames are the discriminator's real data): every
+        # rank must read the same one; buffers (none today) ride along
+        sdist.broadcast_module(tae_model)
+        sdist.broadcast_buffers(asr_model, discriminator)
         self.G_optim = _fused_optimizer(g_opt[0], self.asr_flat, self.span, g_opt[1])
         self.D_optim = _fused_optimizer(d_opt[0], self.d_flat, None, d_opt[1])
         if self.G_optim is None or self.D_optim is None:
@@ -261,6 +265,7 @@ class SAETrainStep:
         self.lo, self.hi = self.asr_flat.range_of(list(asr_model.encoder.parameters()))
         sdist.broadcast_flat(self.sae_flat.data)
         sdist.broadcast_flat(self.asr_flat.data)
+        sdist.broadcast_buffers(sae_model)     # batch-norm running statistics start from rank 0's (then evolve per rank)
         self.optim = FusedAdam([(self.sae_flat.data, self.sae_flat.grad, True),
                                 (self.asr_flat.data[self.lo:self.hi], self.asr_flat.grad[self.lo:self.hi], False)],
                                lr=opt[1], eps=1e-8)

@@ -105,11 +105,6 @@ def _track_status(sync, index):
 _events = None
 # step ranges per BiLSTM layer whose weight gradients overlap the recurrence (1..8)
 bptt_segments = int(os.environ.get('SSASR_BPTT_SEGMENTS', '4'))
-# forward pass: the next layer's input projection for the frames that are final in both directions starts on the
-# second stream while the layer's last quarter of steps still recurs (asr.Listener.forward).  OFF by default: a
-# measured negative (5.85 against 5.78 ms per 470-frame step -- the forward recurrence keeps every
-# CU, so the projection beside it lengthens each of its steps by about what it saves)
-fwd_overlap = int(os.environ.get('SSASR_FWD_OVERLAP', '0'))
 
 
 def _overlap_events():
@@ -281,7 +276,7 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, act=0, alpha=1.0, beta=0
 # ---------------------------------------------------------------------------
 class _BiLSTM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, lens, steps, batch_first, sinks, slots, pre_gates, split, *w):
+    def forward(ctx, x, lens, steps, batch_first, sinks, slots, *w):
         lib = _lib.load()
         _need_gpu(x, *w)
         ctx.sinks = sinks
@@ -300,10 +295,7 @@ class _BiLSTM(torch.autograd.Function):
             xs_s, xs_n = N * I, I
             y = torch.empty(S, N, 2 * H, device=x.device, dtype=torch.float32)
             ys_s, ys_n = N * 2 * H, 2 * H
-        # pre_gates: the pre-activations of ALL rows, already computed (the layer below overlapped this layer's input
-        # projection with its own recurrence: bilstm_input_projection)
-        gates = pre_gates if pre_gates is not None else torch.empty(2, S * N, 4 * H, device=x.device, dtype=torch.float32)
-        assert gates.shape == (2, S * N, 4 * H) and gates.is_contiguous()
+        gates = torch.empty(2, S * N, 4 * H, device=x.device, dtype=torch.float32)
         hs = torch.empty(2, S * N, H, device=x.device, dtype=torch.float32)
         # what the BPTT streams back (activated gates, cell states): tile-major when the layer takes
         # both persistent forms (include/ssasr.h, tsave), else row-major in gates / cs
@@ -320,25 +312,9 @@ class _BiLSTM(torch.autograd.Function):
         else:
             hx = torch.empty(hx_floats, device=x.device, dtype=torch.float32) if hx_floats else None
         sync = _status_words(x.device) if hx is not None else None
-        ready = 1 if pre_gates is not None else 0
-
-        def run(i0, i1, arm):
-            check(lib.ssasr_bilstm_fwd_range(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
-                                             _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
-                                             arm, _p(tsave), i0, i1, ready, _stream()), 'ssasr_bilstm_fwd_range')
-        if split is not None and ts_floats and hx is not None and 0 < split[0] < S:
-            # two step ranges with an event between them: split[1](event, y) may enqueue work on another stream that
-            # reads the frames of y which are final after the first range (step ranges exist in the persistent form,
-            # which a layer with tile-major saves takes)
-            run(0, split[0], armed)
-            ev = torch.cuda.Event()
-            ev.record()
-            split[1](ev, y)
-            run(split[0], S, 1)
-        else:
-            if split is not None:
-                split[1](None, y)                       # (no ranges: the callback still learns where y lives)
-            run(0, 0, armed)
+        check(lib.ssasr_bilstm_fwd(_p(x), xs_s, xs_n, S, N, I, H, _p(lens), *[_p(t) for t in w],
+                                   _p(y), ys_s, ys_n, _p(gates), _p(cs), _p(hs), _p(hx), _p(sync),
+                                   armed, _p(tsave), _stream()), 'ssasr_bilstm_fwd')
         if sync is not None:
             _track_status(sync, 4)
         ctx.save_for_backward(x, lens, gates, cs, hs, tsave, *w)
@@ -397,38 +373,25 @@ class _BiLSTM(torch.autograd.Function):
             for t in (gates, x, hs):
                 t.record_stream(side)
             _notify_wgrad(sinks)
-            return (dx,) + (None,) * 15
+            return (dx,) + (None,) * 13
         check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
                                    _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
                                    _p(ws_dc), _p(gx), _p(sync), int(armed), _p(tsave), _stream()), 'ssasr_bilstm_bwd')
-        # inputs: x, lens, steps, batch_first, sinks, slots, pre_gates, split, then w_ih,w_hh,b_ih,b_hh per direction
-        return (dx, None, None, None, None, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
+        # inputs: x, lens, steps, batch_first, sinks, slots, then w_ih,w_hh,b_ih,b_hh per direction
+        return (dx, None, None, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
                 dw[3], dw[4], dw[5], dw[5].clone())
 
 
-def bilstm_input_projection(x_mem, xs_s, xs_n, S, N, I, H, weights, gates, axis, r0, r1, stream=None):
-    """gates[d][(s, n)] = x[s, n, :] . W_ih[d]^T + b_ih[d] + b_hh[d] for s in [r0, r1) (axis 0) or n in [r0, r1)
-    (axis 1), both directions (include/ssasr.h, ssasr_bilstm_input_projection).  x_mem: the tensor whose memory
-    holds the logical [S, N, I] input with element strides (xs_s, xs_n); weights as for bilstm()."""
-    lib = _lib.load()
-    st = _stream() if stream is None else C.c_void_p(stream.cuda_stream)
-    check(lib.ssasr_bilstm_input_projection(_p(x_mem), xs_s, xs_n, S, N, I, H, _p(weights[0]), _p(weights[2]), _p(weights[3]),
-                                            _p(weights[4]), _p(weights[6]), _p(weights[7]), _p(gates), axis, r0, r1, st),
-          'ssasr_bilstm_input_projection')
-
-
-def bilstm(x, lens, steps, batch_first, weights, slots=None, pre_gates=None, split=None):
+def bilstm(x, lens, steps, batch_first, weights, slots=None):
     """weights = (w_ih, w_hh, b_ih, b_hh) forward then the same four reverse.
     batch_first: x [N, T, I], the first ``steps`` frames are processed and the
     result is [N, steps, 2H]; otherwise x is [S, N, I] -> [S, N, 2H].
     lens: int32 device tensor [N] or None.
     slots: (forward ExchangeArena, slot, backward ExchangeArena, slot) reserved with the sizes of
     bilstm_exchange_floats, or None (the layer allocates and arms its own workspaces).
-    pre_gates: [2, S * N, 4H] pre-activations already computed for all rows (bilstm_input_projection), or None.
-    split: (i, fn) or None: the recurrence is launched as steps [0, i) and [i, S) with an event between them,
-    fn(event, y) is called after the first launch (event None when the layer has no step ranges)."""
-    return _BiLSTM.apply(x, lens, steps, batch_first, _grad_sinks(weights), slots, pre_gates, split, *weights)
+    """
+    return _BiLSTM.apply(x, lens, steps, batch_first, _grad_sinks(weights), slots, *weights)
 
 
 # ---------------------------------------------------------------------------

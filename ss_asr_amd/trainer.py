@@ -19,6 +19,7 @@ Differences, all inside the same call surface:
   * valid() no longer dies on the undefined names of src/trainer.py:531.
 """
 import math
+import warnings
 import os
 
 import numpy as np
@@ -109,12 +110,23 @@ class Solver:
             scale = sdist.allreduce_grad(optim._grad)
             optim.clip_and_step(max_norm=float(grad_clip), grad_scale=scale)
             return
+        # Any other torch.optim type a config names (conf/default.yaml selects none): the reference's own sequence on
+        # torch's optimizer -- NOT the MI355X-native step (no fused clip + update kernel, no overlapped all-reduce).
         params = list(params)
+        if not getattr(self, '_warned_torch_optim', False):
+            self._warned_torch_optim = True
+            warnings.warn('%s has no fused MI355X form here: Solver.step runs torch.optim and clip_grad_norm_ '
+                          '(Adadelta and Adam are the native ones)' % type(optim).__name__, RuntimeWarning)
         if sdist.is_active():
-            for p in params:
-                if p.grad is not None:
-                    torch.distributed.all_reduce(p.grad)
-                    p.grad.div_(sdist.world_size())
+            # every parameter the optimizer updates is averaged, not only the list the norm is clipped over
+            # (TAETrainer / SAETrainer hand `params` of ONE module to an optimizer over two: src/trainer.py:633-641, :676)
+            seen = set()
+            for grp in optim.param_groups:
+                for p in grp['params']:
+                    if p.grad is not None and id(p) not in seen:
+                        seen.add(id(p))
+                        torch.distributed.all_reduce(p.grad)
+                        p.grad.div_(sdist.world_size())
         grad_norm = nn.utils.clip_grad_norm_(params, grad_clip)
         if math.isnan(grad_norm):
             self.verbose('Error : grad norm is NaN @ step {}'.format(self.tr.step))
@@ -262,7 +274,7 @@ class ASRTrainer(Solver):
                         if self.train_step is not None:
                             self.train_step.finish()   # this step's verdict first: never checkpoint after a time-out
                         self.verbose("Model saved at step {}".format(self.tr.step))
-                        torch.save(self.asr_model.state_dict(), self.ckppath)
+                        sdist.save_atomic(self.asr_model.state_dict(), self.ckppath)
                 if self.tr.step % self.valid_step == 0:
                     self.valid()
                 self.tr.do_step()
@@ -332,7 +344,7 @@ class ASRTrainer(Solver):
                 self.verbose('Best validation loss for ASR : {:.4f} @ global step {}'.format(
                     self.tr.get_best(), self.tr.step))
                 self.verbose('Saving best model.')
-                torch.save(self.asr_model.state_dict(), self.best_ckppath)
+                sdist.save_atomic(self.asr_model.state_dict(), self.best_ckppath)
                 with open(os.path.join(self.ckpdir, 'best_hyp.txt'), 'w') as f:
                     for hyp, txt in zip(val_hyp, val_txt):
                         f.write(hyp + ',' + txt + '\n')
@@ -347,7 +359,8 @@ class ASRTrainer(Solver):
         if getattr(self, 'train_step', None) is not None:
             self.train_step.finish()
         if self.rank == 0:
-            torch.save(self.asr_model.state_dict(), self.ckppath)
+            sdist.save_atomic(self.asr_model.state_dict(), self.ckppath)
+        sdist.barrier()        # the next reader of these files (the Seed loop's next leg) runs on every rank
 
 
 class TAETrainer(Solver):
@@ -441,8 +454,8 @@ class TAETrainer(Solver):
                     if self.train_step is not None:
                         self.train_step.finish()       # never checkpoint after a time-out
                     self.verbose("Model saved at step {}".format(self.tr.step))
-                    torch.save(self.text_autoenc.state_dict(), self.ckppath)
-                    torch.save(self.asr_model.state_dict(), self.asrpath_out)
+                    sdist.save_atomic(self.text_autoenc.state_dict(), self.ckppath)
+                    sdist.save_atomic(self.asr_model.state_dict(), self.asrpath_out)
                 self.tr.do_step()
             epoch += 1
         if self.train_step is not None:
@@ -479,7 +492,7 @@ class TAETrainer(Solver):
         if avg_loss < self.tr.get_best():
             self.tr.set_best(avg_loss)
             self.verbose('Best validation loss : {:.4f} @ global step {}'.format(self.tr.get_best(), self.tr.step))
-            torch.save(self.text_autoenc.state_dict(), self.best_ckppath)
+            sdist.save_atomic(self.text_autoenc.state_dict(), self.best_ckppath)
             self.verbose("Both the text autoencoder and ASR have been saved")
         else:
             self.verbose("Validation metric worse : ({:.4f} vs. {:.4f})".format(avg_loss, self.tr.get_best()))
@@ -490,8 +503,9 @@ class TAETrainer(Solver):
         if getattr(self, 'train_step', None) is not None:
             self.train_step.finish()
         if self.rank == 0:
-            torch.save(self.text_autoenc.state_dict(), self.ckppath)
-            torch.save(self.asr_model.state_dict(), self.asrpath_out)
+            sdist.save_atomic(self.text_autoenc.state_dict(), self.ckppath)
+            sdist.save_atomic(self.asr_model.state_dict(), self.asrpath_out)
+        sdist.barrier()        # the next reader of these files (the Seed loop's next leg) runs on every rank
 
 
 class ADVTrainer(Solver):
@@ -611,8 +625,8 @@ class ADVTrainer(Solver):
                     if self.train_step is not None:
                         self.train_step.finish()       # never checkpoint after a time-out
                     self.verbose("Model saved at step {}".format(self.tr.step))
-                    torch.save(self.discriminator.state_dict(), self.ckppath)
-                    torch.save(self.asr_model.state_dict(), self.asrpath_out)
+                    sdist.save_atomic(self.discriminator.state_dict(), self.ckppath)
+                    sdist.save_atomic(self.asr_model.state_dict(), self.asrpath_out)
                 self.tr.do_step()
             epoch += 1
         if self.train_step is not None:
@@ -653,7 +667,7 @@ class ADVTrainer(Solver):
         if avg_loss < self.tr.get_best():
             self.tr.set_best(avg_loss)
             self.verbose('Best validation loss : {:.4f} @ global step {}'.format(self.tr.get_best(), self.tr.step))
-            torch.save(self.discriminator.state_dict(), self.best_ckppath)
+            sdist.save_atomic(self.discriminator.state_dict(), self.best_ckppath)
             self.verbose("Both the discriminator and ASR have been saved")
 
     def close(self):
@@ -662,8 +676,9 @@ class ADVTrainer(Solver):
         if self.train_step is not None:
             self.train_step.finish()
         if self.rank == 0:
-            torch.save(self.discriminator.state_dict(), self.ckppath)
-            torch.save(self.asr_model.state_dict(), self.asrpath_out)
+            sdist.save_atomic(self.discriminator.state_dict(), self.ckppath)
+            sdist.save_atomic(self.asr_model.state_dict(), self.asrpath_out)
+        sdist.barrier()        # the next reader of these files (the Seed loop's next leg) runs on every rank
 
 
 class SAETrainer(Solver):
@@ -753,8 +768,8 @@ class SAETrainer(Solver):
                     if self.train_step is not None:
                         self.train_step.finish()       # never checkpoint after a time-out
                     self.verbose("Model saved at step {}".format(self.tr.step))
-                    torch.save(self.speech_autoenc.state_dict(), self.ckppath)
-                    torch.save(self.asr_model.state_dict(), self.asrpath_out)
+                    sdist.save_atomic(self.speech_autoenc.state_dict(), self.ckppath)
+                    sdist.save_atomic(self.asr_model.state_dict(), self.asrpath_out)
                 self.tr.do_step()
             epoch += 1
         if self.train_step is not None:
@@ -792,7 +807,7 @@ class SAETrainer(Solver):
         if avg_loss < self.tr.get_best():
             self.tr.set_best(avg_loss)
             self.verbose('Best validation loss : {:.4f} @ global step {}'.format(self.tr.get_best(), self.tr.step))
-            torch.save(self.speech_autoenc.state_dict(), self.best_ckppath)
+            sdist.save_atomic(self.speech_autoenc.state_dict(), self.best_ckppath)
         else:
             self.verbose("Validation metric worse : ({:.4f} vs. {:.4f})".format(avg_loss, self.tr.get_best()))
 
@@ -802,8 +817,9 @@ class SAETrainer(Solver):
         if self.train_step is not None:
             self.train_step.finish()
         if self.rank == 0:
-            torch.save(self.speech_autoenc.state_dict(), self.ckppath)
-            torch.save(self.asr_model.state_dict(), self.asrpath_out)
+            sdist.save_atomic(self.speech_autoenc.state_dict(), self.ckppath)
+            sdist.save_atomic(self.asr_model.state_dict(), self.asrpath_out)
+        sdist.barrier()        # the next reader of these files (the Seed loop's next leg) runs on every rank
 
 
 # src/train.py:19-20 offers the choice 'AdvTrainer' and resolves it with getattr(trainer, ...); the reference's

@@ -442,3 +442,72 @@ def test_two_ranks_run_the_seed_loops_other_legs_as_plain_data_parallelism(tmp_p
             assert max(abs(a - b) for a, b in zip(ranks[r]['probe'][n], want)) < 5e-5, (r, n)
         assert max(abs(a - b) for a, b in zip(ranks[r]['other_probe'], single['other_probe'])) < 5e-5
     assert ranks[0]['probe'] == ranks[1]['probe'] and ranks[0]['other_probe'] == ranks[1]['other_probe']
+
+
+# --- the Seed loop's checkpoint hand-off under two ranks (rank 0 alone writes asr_1/2/3.cpt and tae.cpt in
+# close(); every rank reads them in the next leg's set_model) ---------------------------------------------------
+SEED_LOOP_RANK = r'''
+import json, os, random, sys, types
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'oracle')); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+from test_gpu_trainer import _seed_config, _paras
+from ss_asr_amd import dist as sdist, trainer as T
+root = os.environ['SSASR_TEST_ROOT']
+index = os.path.join(root, 'index.tsv')
+conf = _seed_config(index, n_epochs=1)
+conf['seed_train'] = {'super_its': 1}
+random.seed(1); np.random.seed(1); torch.manual_seed(1 + int(os.environ['RANK']))      # ranks would build DIFFERENT fresh models
+ends = []
+for cls in (T.TAETrainer, T.ADVTrainer, T.SAETrainer):
+    def wrap(orig, name):
+        def close(self):
+            mods = [self.asr_model] + [getattr(self, a) for a in ('text_autoenc', 'discriminator', 'speech_autoenc') if hasattr(self, a)]
+            torch.cuda.synchronize()
+            ends.append([name] + [float(sum(p.double().abs().sum() for p in m.parameters())) for m in mods] +
+                        [float(sum(b.double().abs().sum() for b in m.buffers())) for m in mods])
+            return orig(self)
+        return close
+    cls.close = wrap(cls.close, cls.__name__)
+T.asr_seed_train(conf, _paras(root, 'seed2'))
+print('RESULT ' + json.dumps(dict(rank=int(os.environ['RANK']), ends=ends)))
+sdist.shutdown()
+'''
+
+
+@pytest.mark.timeout(1200)
+def test_two_ranks_hand_the_seed_loops_model_from_leg_to_leg_through_rank_zeros_checkpoints(tmp_path):
+    """One super-iteration of trainer.asr_seed_train on two ranks (gloo between them, both on the one GPU), each
+    rank seeded differently: without the barrier after rank 0's save and the broadcasts of what a step object only
+    reads (the text autoencoder, batch-norm buffers), rank 1 would build fresh models or read half-written files.
+    At the end of every leg both ranks hold the same parameters and started from the same buffers."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_host_cpu import make_corpus
+    root = str(tmp_path)
+    make_corpus(root, n=32, t_max=32, feat=80, seed=7)
+    base = dict(os.environ, SSASR_TEST_ROOT=root)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND', 'SSASR_DDP_NO_OVERLAP'):
+        base.pop(k, None)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = [_child(SEED_LOOP_RANK, dict(base, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                                         MASTER_PORT=str(port), SSASR_DIST_BACKEND='gloo')) for r in range(2)]
+    try:
+        ranks = [_result(p, 900) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    ranks.sort(key=lambda d: d['rank'])
+    a, b = ranks[0]['ends'], ranks[1]['ends']
+    assert [e[0] for e in a] == ['TAETrainer', 'ADVTrainer', 'SAETrainer'] == [e[0] for e in b]
+    for ea, eb in zip(a, b):
+        n = (len(ea) - 1) // 2
+        for va, vb in zip(ea[1:1 + n], eb[1:1 + n]):            # parameters: equal on both ranks after the leg
+            assert abs(va - vb) <= 1e-9 * max(1.0, abs(va)), (ea, eb)
+    ckpdir = os.path.join(root, 'result', 'seed2')
+    for f in ('asr_1.cpt', 'asr_2.cpt', 'asr_3.cpt', 'tae.cpt', 'adv.cpt', 'sae.cpt'):
+        assert os.path.isfile(os.path.join(ckpdir, f)), f
+        torch.load(os.path.join(ckpdir, f), map_location='cpu')                     # whole archives
+    assert not [f for f in os.listdir(ckpdir) if '.tmp.' in f]

@@ -164,35 +164,6 @@ def test_backward_matches_reference_on_the_fp32_mfma_instruction(golden):
         _lib.set_option('SSASR_GEMM_X6', old)
 
 
-def test_forward_overlap_equals_the_plain_forward(golden, monkeypatch):
-    """ops.fwd_overlap (SSASR_FWD_OVERLAP=1; off by default, a measured negative): layer k + 1's input projection in three pieces -- the middle half of the
-    frames on the second stream, beside the last quarter of layer k's recurrence (launched as two step ranges
-    with an event between them), the outer quarters afterwards -- against the plain order (one projection per
-    layer after the recurrence below it) on the bench's median batch: the same products in the same order per
-    output element, so logits, attention and loss must be bit-identical, and the gradients equal to the
-    rounding of their atomically accumulated weight gradients."""
-    from ss_asr_amd import ops
-    from ss_asr_amd.optim import FlatParameters
-    fx = golden('bench_b32_median')
-    res = []
-    for overlap in (1, 0):
-        monkeypatch.setattr(ops, 'fwd_overlap', overlap)
-        model = build(fx)
-        flat = FlatParameters(model)
-        flat.zero_grad()
-        _, logits, att, loss = forward(fx, model)
-        loss.backward()
-        ops.join_side_stream()
-        torch.cuda.synchronize()
-        ops.check_persistent_status()
-        res.append((logits.detach().clone(), att.clone(), float(loss), flat.grad.clone()))
-    a, b = res
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
-    scale = float(b[3].abs().max())
-    assert float((a[3] - b[3]).abs().max()) < 5e-5 * scale
-    np.testing.assert_allclose(a[0].cpu().numpy(), fx['logits'], atol=5e-5, rtol=0)
-
-
 def test_module_level_loop_equals_fused_loop(golden):
     """Driving Attention / Speller step by step (the way TextAutoEncoder does,
     src/text_autoencoder.py:55-88) gives the fused decode loop's result."""

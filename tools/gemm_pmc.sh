@@ -1,11 +1,12 @@
 #!/bin/bash
-# PMC passes over tools/gemm_one.py (4096^3 NT on the default GEMM kernel): one counter group per run.
+# PMC passes over tools/gemm_one.py (4096^3 NT by default; GEMM_ARGS="M N K ta tb batch" another shape; SSASR_GEMM_TILE
+# in the environment forces a tile shape): one counter group per run.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS" "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rm -rf $R/gpurun_out/gpmc_$tag
-  timeout -k 10 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/gpmc_$tag -- python3 $R/tools/gemm_one.py > $R/gpurun_out/gpmc_$tag.log 2>&1 || echo "group failed: $grp"
+  timeout -k 10 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/gpmc_$tag -- python3 $R/tools/gemm_one.py $GEMM_ARGS > $R/gpurun_out/gpmc_$tag.log 2>&1 || echo "group failed: $grp"
 done
 python3 - <<PY
 import csv, glob, collections
