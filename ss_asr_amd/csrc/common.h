@@ -36,6 +36,14 @@ struct RowMap {
 __device__ __forceinline__ int64_t rm_off(const RowMap& m, int64_t i) {
   return m.inner ? (i / m.inner) * m.so + (i % m.inner) * m.si : i * m.ld;
 }
+// the same for a non-negative 32-bit row index (what the GEMM loaders have): one 32-bit division instead of a
+// 64-bit division and a 64-bit remainder (~500 instructions on this ISA) whenever the inner count fits 32 bits
+__device__ __forceinline__ int64_t rm_off(const RowMap& m, int i) {
+  if (!m.inner) return (int64_t)i * m.ld;
+  if (m.inner >> 32) return rm_off(m, (int64_t)i);
+  const unsigned n = (unsigned)m.inner, q = (unsigned)i / n, r = (unsigned)i - q * n;
+  return (int64_t)q * m.so + (int64_t)r * m.si;
+}
 
 static inline RowMap rm_dense(int64_t ld) { return RowMap{ld, 0, 0, 0}; }
 
@@ -198,7 +206,10 @@ struct SsasrOptions {
   int no_persistent_decoder;      // SSASR_NO_PERSISTENT_DECODER
   int no_persistent_decoder_bwd;  // SSASR_NO_PERSISTENT_DECODER_BWD
   int delay_fwd, delay_bwd, delay_bwd_ksplit;   // SSASR_PERSIST_DELAY_FWD / _BWD (initial pacing, x 64 cycles; -1 = default)
-  int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 forced
+  int gemm_tile;                  // SSASR_GEMM_TILE: 0 model, 64 | 128 | 256 (wide, stream-K) | 255 (wide, whole tiles) forced
+  int gemm_trace_lo, gemm_trace_hi;   // SSASR_GEMM_TRACE_LO / _HI (set_option only): device address of a uint64 buffer that the wide
+                                  // GEMM kernel's workgroups stamp their phases into (tools/gemm_trace.py); 0 = off
+  int gemm_wide;                  // SSASR_GEMM_WIDE (1): products of >= 256 wide tiles take the 256 x 128 stream-K kernel when its model is cheaper (0: A/B)
   int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs (0: on v_mfma_f32_16x16x4_f32)
   int gemm_kcat;                  // SSASR_GEMM_KCAT (1): a layer's input gradient as ONE launch over both directions' K segments
   int no_windows;                 // SSASR_NO_WINDOWS: layers wider than 128 columns take one launch per step instead of column windows (A/B)

@@ -16,6 +16,7 @@
 // one 16-deep K step MFMA j (j = 0..3) consumes k = 4 * (lane >> 4) + j from
 // both operands, which lets a K-contiguous operand be fetched with a single
 // ds_read_b128 per 16x16 fragment.
+#include <atomic>
 #include <cstdlib>
 #include "../../include/ssasr.h"
 #include "common.h"
@@ -744,16 +745,27 @@ __device__ __forceinline__ bf16x8 x32_operand(const char* img, int plane, int ba
   else return x32_frag<BMN>(img, plane, base, h, lane);
 }
 
+// What an epilogue of the wide kernel needs of its tile's descriptor (a part's values may leave after the loaders of
+// the NEXT part have been set up, so the few fields are copied out)
+struct EpiDesc {
+  float* C;
+  RowMap mc;
+  const float* b1;
+  const float* b2;
+  float alpha, beta;
+  int act, M, N;
+};
+
 // Epilogue of the wide kernel: acc[i][j] = the wave's 32 x 32 blocks (D layout of v_mfma_f32_32x32x16_bf16: column =
 // lane & 31, row = 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3)).  TR: the products were accumulated transposed, so the
 // lane's column is the output ROW m and four consecutive registers are four consecutive output COLUMNS (16-byte stores).
 // add != 0: the values are ADDED atomically (split-K slices, stream-K parts); lead: this part brings the biases.
 template <int TM, int TN, bool TR>
-__device__ __forceinline__ void gemm_epilogue32(const GemmDesc& g, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                                int lane, int bz, bool lead, bool add) {
-  float* C = g.C + (int64_t)bz * g.sc;
-  const float* b1 = g.bias1 ? g.bias1 + (int64_t)bz * g.sbias : nullptr;
-  const float* b2 = g.bias2 ? g.bias2 + (int64_t)bz * g.sbias : nullptr;
+__device__ __forceinline__ void gemm_epilogue32(const EpiDesc& g, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                int lane, bool lead, bool add) {
+  float* C = g.C;
+  const float* b1 = g.b1;
+  const float* b2 = g.b2;
   const int c = lane & 31, hq = lane >> 5;
   if constexpr (!TR) {
 #pragma unroll
@@ -784,6 +796,25 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmDesc& g, const f32x16 
     return;
   }
   const bool vecC = map_vec_ok_dev(g.mc) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  if (!add && g.act == 0 && g.beta == 0.f && vecC && g.mc.inner == 0 && m0 + 32 * TM <= g.M && n0 + 32 * TN <= g.N) {
+    // the common case as straight-line code (see gemm_epilogue32_rows)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int nb = n0 + j * 32 + 8 * g4 + 4 * hq;
+        float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lead && b1) bs = *reinterpret_cast<const float4*>(b1 + nb);
+        if (lead && b2) { const float4 t2 = *reinterpret_cast<const float4*>(b2 + nb); bs.x += t2.x; bs.y += t2.y; bs.z += t2.z; bs.w += t2.w; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float* dst = C + (int64_t)(m0 + i * 32 + c) * g.mc.ld + nb;
+          *reinterpret_cast<float4*>(dst) = make_float4(g.alpha * acc[i][j][4 * g4] + bs.x, g.alpha * acc[i][j][4 * g4 + 1] + bs.y,
+                                                        g.alpha * acc[i][j][4 * g4 + 2] + bs.z, g.alpha * acc[i][j][4 * g4 + 3] + bs.w);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + i * 32 + c;
@@ -842,185 +873,410 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmDesc& g, const f32x16 
 constexpr int WIDE_BM = 256, WIDE_BN = 128, WIDE_NT = 512;
 constexpr int WIDE_STAGE = XGeom<WIDE_BM>::BYTES + XGeom<WIDE_BN>::BYTES;      // 73,728 bytes
 
+// Stream-K plan of one launch of the wide kernel: the launch's work is `units` = tiles x K steps, cut into `G` equal
+// runs of consecutive units, one per workgroup (tiles in n-fastest order, a tile's K steps consecutive) -- every
+// workgroup runs the same number of K steps whatever the tile count is (800 tiles of the layer-2 input
+// projection on 256 CUs are 3.125 rounds of tiles: as whole tiles they cost 4).  A tile whose K steps lie in
+// one run is stored as always.  A tile cut between runs is finished through memory:
+//   acc = 0: its parts take a ticket.  A part that is not the last to arrive writes its accumulators to a slab of the
+//            workspace (write-through 16-byte stores, whole lines) and counts itself done; the part that arrives
+//            LAST waits until the others are done -- they hold tickets, so they are running: no wait on a
+//            workgroup that may not be resident -- adds their slabs to its own accumulators and runs the normal
+//            epilogue (biases, activation, beta), then clears the tile's two words.  Sums are formed in ticket
+//            order: with two parts (all there are while tiles >= workgroups) the result does not depend on it.
+//   acc = 1: every part is added atomically (the caller's C accumulates: split-K products, weight gradients).
+struct WidePlan {
+  int tiles_x, tiles_y;      // column / row tiles per batch
+  int ksteps;                // K steps per tile (K segments concatenated)
+  int G;                     // workgroups = runs
+  int acc;
+  int units;                 // tiles x ksteps (< 2^31: checked by the launcher)
+  int per, rem;              // units / G, units % G: run r is [r per + min(r, rem), ...), the first `rem` runs one unit longer
+  unsigned* ws;              // [G][2]: ticket, done (zero between launches)
+  float* slabs;              // [G][SK_SLABS][512 threads x 64 floats]: accumulators of the parts that were not last
+  int epi;                   // diagnostic: 1 = store-mode epilogue without the LDS staging
+  unsigned long long* trace; // diagnostic (tools/gemm_trace.py): [G][8 parts][8 stamps] of s_memtime, or NULL
+};
+
+constexpr int SK_REGIONS = 4, SK_MAX_G = 512, SK_SLABS = 2;
+constexpr size_t SK_SLAB_FLOATS = (size_t)WIDE_NT * 64;
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int sk_begin(const WidePlan& p, int g) { return g * p.per + min(g, p.rem); }
+__device__ __forceinline__ int sk_owner(const WidePlan& p, int u) {
+  const int big = p.rem * (p.per + 1);                      // units in the longer runs
+  return u < big ? (int)((unsigned)u / (unsigned)(p.per + 1)) : p.rem + (int)((unsigned)(u - big) / (unsigned)p.per);
+}
+
+// Store-mode epilogue of a transposed accumulation through LDS: the D layout gives a lane four consecutive columns of
+// ONE row, 32 rows per store instruction (32 bytes of each); staged through a wave-private 64 x 64 image (row stride
+// 68 floats: the 8 lanes a 16-byte LDS store handles together fall on different banks) a store instruction writes
+// four rows of 256 contiguous bytes instead.  `st`: this wave's 17,408 bytes of LDS.
+__device__ __forceinline__ void gemm_epilogue32_rows(const EpiDesc& e, const f32x16 (&acc)[2][2], int m0, int n0, int lane,
+                                                     float* st) {
+  constexpr int LDW = 68;
+  const int c = lane & 31, hq = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(st + (i * 32 + c) * LDW + j * 32 + 8 * g4 + 4 * hq) =
+            make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
+  const bool vecC = map_vec_ok_dev(e.mc) && ((reinterpret_cast<uintptr_t>(e.C) & 15) == 0);
+  const int nb = n0 + 4 * (lane & 15);
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (nb + k < e.N) bias[k] = (e.b1 ? e.b1[nb + k] : 0.f) + (e.b2 ? e.b2[nb + k] : 0.f);
+  // the common case as straight-line code: interior tile, dense rows, no activation, beta = 0 (the general loop below
+  // takes several scalar branches per element: 20 us per 256 x 128 tile, measured with the kernel's phase stamps)
+  if (e.act == 0 && e.beta == 0.f && vecC && e.mc.inner == 0 && m0 + 64 <= e.M && n0 + 64 <= e.N) {
+    float* dst = e.C + (int64_t)(m0 + (lane >> 4)) * e.mc.ld + nb;
+    const int64_t step = 4 * e.mc.ld;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const float4 a = *reinterpret_cast<const float4*>(st + (4 * it + (lane >> 4)) * LDW + 4 * (lane & 15));
+      *reinterpret_cast<float4*>(dst) = make_float4(e.alpha * a.x + bias[0], e.alpha * a.y + bias[1], e.alpha * a.z + bias[2],
+                                                    e.alpha * a.w + bias[3]);
+      dst += step;
+    }
+    return;
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = 4 * it + (lane >> 4);
+    const float4 a = *reinterpret_cast<const float4*>(st + row * LDW + 4 * (lane & 15));
+    const int m = m0 + row;
+    if (m >= e.M || nb >= e.N) continue;
+    float v[4] = {e.alpha * a.x + bias[0], e.alpha * a.y + bias[1], e.alpha * a.z + bias[2], e.alpha * a.w + bias[3]};
+    float* dst = e.C + rm_off(e.mc, m);
+    if (e.act == 3) {        // (re, im) column pairs -> power (see gemm_epilogue)
+      if (nb + 1 < e.N) dst[nb >> 1] = v[0] * v[0] + v[1] * v[1];
+      if (nb + 3 < e.N) dst[(nb >> 1) + 1] = v[2] * v[2] + v[3] * v[3];
+      continue;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = gemm_act(e.act, v[k]);
+    if (vecC && nb + 3 < e.N) {
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (e.beta != 0.f) {
+        const float4 c0 = *reinterpret_cast<const float4*>(dst + nb);
+        o.x += e.beta * c0.x; o.y += e.beta * c0.y; o.z += e.beta * c0.z; o.w += e.beta * c0.w;
+      }
+      *reinterpret_cast<float4*>(dst + nb) = o;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (nb + k >= e.N) continue;
+        float o = v[k];
+        if (e.beta != 0.f) o += e.beta * dst[nb + k];
+        dst[nb + k] = o;
+      }
+    }
+  }
+}
+
 template <bool TA, bool TB, bool TR, bool SEG = false>
-__global__ __launch_bounds__(WIDE_NT, 2) void gemm_x6w_kernel(GemmDesc gin, bool vecA, bool vecB) {
+__global__ __launch_bounds__(WIDE_NT, 2) void gemm_x6w_kernel(GemmDesc gin, bool vecA, bool vecB, WidePlan plan) {
   constexpr int BM = WIDE_BM, BN = WIDE_BN, NT = WIDE_NT;
   constexpr int WM = 64, WN = 64, TM = 2, TN = 2;      // per wave: 2 x 2 blocks of 32 x 32
   extern __shared__ __attribute__((aligned(16))) char xlds[];
+  __shared__ unsigned sk_old;
   static_assert(!SEG || (TA && TB), "column segments: both operands MN-contiguous");
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
-  int bx, by, bzz;
-  gemm_tile_of_block(bx, by, bzz);
-  GemmDesc g = gin;
-  const int bz = bzz / g.splitk;
-  const int kz = bzz - bz * g.splitk;
-  bool do_colsum = false;
-  if constexpr (SEG) {
-    const int nt0 = (gin.seg[0].N + BN - 1) / BN;
-    const int sidx = bx >= nt0 ? 1 : 0;
-    do_colsum = bx == 0 && gin.colsum[bz] != nullptr;
-    if (sidx) bx -= nt0;
-    g.A = gin.seg[sidx].A[bz]; g.sa = 0;
-    g.B = gin.seg[sidx].B[bz]; g.sb = 0; g.mb = gin.seg[sidx].mb;
-    g.C = gin.seg[sidx].C[bz]; g.sc = 0; g.mc = RowMap{gin.seg[sidx].ldc, 0, 0, 0};
-    g.N = gin.seg[sidx].N; g.K = gin.seg[sidx].K;
+  // workgroups are dealt to the XCDs round-robin: the 1/8 of the runs that one XCD's workgroups take is contiguous
+  int run;
+  {
+    const int lin = blockIdx.x, xcd = lin & 7, j = lin >> 3;
+    const int per = plan.G >> 3, rem = plan.G & 7;
+    run = xcd * per + min(xcd, rem) + j;
   }
-  const int m0 = by * BM, n0 = bx * BN;
+  int u = sk_begin(plan, run);
+  const int u_end = sk_begin(plan, run + 1);
+  if (u >= u_end) return;
 
-  const int ktot = g.kcat > 1 ? g.kcat * g.K : g.K;
-  int kchunk = (ktot + g.splitk - 1) / g.splitk;
-  kchunk = (kchunk + BK - 1) / BK * BK;
-  const int kbeg = kz * kchunk;
-  const int kend = min(ktot, kbeg + kchunk);
-  const int64_t jumpA = g.kcat > 1 ? g.ska - (TA ? (int64_t)g.K * g.ma.ld : (int64_t)g.K) : 0;
-  const int64_t jumpB = g.kcat > 1 ? g.skb - (TB ? (int64_t)g.K * g.mb.ld : (int64_t)g.K) : 0;
-
-  Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
-  Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
+  // ---- state of the part being computed (the loaders are opened one part AHEAD of the epilogue: see the loop's end)
+  GemmDesc g = gin;
   typename XLoaderOf<BM, TA, NT, true>::type la;
   typename XLoaderOf<BN, TB, NT, true>::type lb;
-  la.init(opA, m0, kbeg, tid, 0);
-  lb.init(opB, n0, kbeg, tid, 128);
-  const bool interior = vecA && vecB && (!TA || g.M % 4 == 0) && (!TB || g.N % 4 == 0);
-  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto colsum_add = [&](const float4 (&v)[XLoaderOf<BM, TA, NT>::NV]) {
-    if (la.idx[0] < g.M) {
-#pragma unroll
-      for (int i = 0; i < XLoaderOf<BM, TA, NT>::NV; ++i) { csum.x += v[i].x; csum.y += v[i].y; csum.z += v[i].z; csum.w += v[i].w; }
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // ra / rb hold the fp32 values of the tile AFTER the one in LDS
-  float4 ra[XLoaderOf<BM, TA, NT>::NV], rb[XLoaderOf<BN, TB, NT>::NV];
-  auto fetch = [&](int k) {              // global loads of the K step that starts at k (loaders already there)
-    if (interior && k + BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
-    else { la.load_guarded(ra, k, kend, vecA); lb.load_guarded(rb, k, kend, vecB); }
-  };
+  float4 ra[XLoaderOf<BM, TA, NT>::NV], rb[XLoaderOf<BN, TB, NT>::NV];     // values of the tile AFTER the one in LDS
+  int t = 0, ks0 = 0, ks1 = 0, bz = 0, m0 = 0, n0 = 0, kbeg = 0, kend = 0;
+  int64_t jumpA = 0, jumpB = 0;
+  bool do_colsum = false;
+  // The launcher sends this kernel only products whose every load takes the predicate-free path (16-byte aligned
+  // operands, whole K steps, row maps that advance without a loop: wide_eligible): no guarded loads in here -- with
+  // them inlined at three places the kernel was 240 KB of code and its first part's prologue 23 us (phase stamps).
+  auto fetch = [&]() { la.load_fast(ra); lb.load_fast(rb); };        // global loads of the K step the loaders stand at
   auto step_loaders = [&](int k) {       // move the loaders from the K step before k to k
-    la.advance();
-    lb.advance();
-    if (g.kcat > 1 && k % g.K == 0) { la.jump(jumpA); lb.jump(jumpB); }
+    la.advance_flat();
+    lb.advance_flat();
+    const bool seg_end = g.kcat > 1 && k % g.K == 0;
+    la.jump(seg_end ? jumpA : 0);
+    lb.jump(seg_end ? jumpB : 0);
   };
-  if (kbeg < kend) {
-    fetch(kbeg);
-    la.store(xlds, ra);
-    lb.store(xlds + XGeom<BM>::BYTES, rb);
-    if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
-    if (kbeg + BK < kend) { step_loaders(kbeg + BK); fetch(kbeg + BK); }
-  }
-  __syncthreads();
+  // the part that starts at unit u: tile, K range, descriptor, loaders; its first K step's loads are issued
+  auto open_part = [&]() {
+    t = (int)((unsigned)u / (unsigned)plan.ksteps);
+    ks0 = u - t * plan.ksteps;
+    ks1 = min(plan.ksteps, ks0 + (u_end - u));
+    u += ks1 - ks0;
+    int bx = t % plan.tiles_x;
+    const int tq = t / plan.tiles_x;
+    const int by = tq % plan.tiles_y;
+    bz = tq / plan.tiles_y;
+    g = gin;
+    do_colsum = false;
+    if constexpr (SEG) {
+      // which segment this column tile belongs to; from here on the descriptor is that segment's product
+      const int nt0 = (gin.seg[0].N + BN - 1) / BN;
+      const int sidx = bx >= nt0 ? 1 : 0;
+      do_colsum = bx == 0 && gin.colsum[bz] != nullptr;
+      if (sidx) bx -= nt0;
+      g.A = gin.seg[sidx].A[bz]; g.sa = 0;
+      g.B = gin.seg[sidx].B[bz]; g.sb = 0; g.mb = gin.seg[sidx].mb;
+      g.C = gin.seg[sidx].C[bz]; g.sc = 0; g.mc = RowMap{gin.seg[sidx].ldc, 0, 0, 0};
+      g.N = gin.seg[sidx].N; g.K = gin.seg[sidx].K;
+    }
+    m0 = by * BM; n0 = bx * BN;
+    const int ktot = g.kcat > 1 ? g.kcat * g.K : g.K;
+    kbeg = ks0 * BK;
+    kend = min(ktot, ks1 * BK);
+    jumpA = g.kcat > 1 ? g.ska - (TA ? (int64_t)g.K * g.ma.ld : (int64_t)g.K) : 0;
+    jumpB = g.kcat > 1 ? g.skb - (TB ? (int64_t)g.K * g.mb.ld : (int64_t)g.K) : 0;
+    Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
+    Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
+    if (g.kcat > 1 && kbeg >= g.K) {          // a run that starts inside a later K segment
+      const int sgm = kbeg / g.K;
+      opA.p += (int64_t)sgm * g.ska; opB.p += (int64_t)sgm * g.skb;
+      la.init(opA, m0, kbeg - sgm * g.K, tid, 0);
+      lb.init(opB, n0, kbeg - sgm * g.K, tid, 128);
+    } else {
+      la.init(opA, m0, kbeg, tid, 0);
+      lb.init(opB, n0, kbeg, tid, 128);
+    }
+    if (kbeg < kend) fetch();
+  };
+  int part_no = 0;
+#define SSASR_XW_STAMP(K) do { if (plan.trace && tid == 0 && part_no < 8) plan.trace[((size_t)run * 8 + part_no) * 8 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
+  SSASR_XW_STAMP(0);
+  open_part();
+  SSASR_XW_STAMP(6);                      // (first part only) loaders open, first loads issued
 
-  int stage = 0;
-  int k0 = kbeg;
+  while (true) {
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto colsum_add = [&](const float4 (&v)[XLoaderOf<BM, TA, NT>::NV]) {
+      if (la.idx[0] < g.M) {
+#pragma unroll
+        for (int i = 0; i < XLoaderOf<BM, TA, NT>::NV; ++i) { csum.x += v[i].x; csum.y += v[i].y; csum.z += v[i].z; csum.w += v[i].w; }
+      }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (kbeg < kend) {                     // (its loads were issued by open_part)
+      la.store(xlds, ra);
+      lb.store(xlds + XGeom<BM>::BYTES, rb);
+      if (part_no == 0) SSASR_XW_STAMP(7);  // (first part only) first loads landed, split, stored
+      if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
+      if (kbeg + BK < kend) { step_loaders(kbeg + BK); fetch(); }
+    }
+    __syncthreads();
+    SSASR_XW_STAMP(1);                    // prologue done
+
+    int stage = 0;
+    int k0 = kbeg;
 #define SSASR_XW_READ_A(P) _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int h = 0; h < 2; ++h) \
-    fa[P][i][h] = x32_operand<BM, TA>(curA, P, wm * WM + i * 32, h, lane)
+      fa[P][i][h] = x32_operand<BM, TA>(curA, P, wm * WM + i * 32, h, lane)
 #define SSASR_XW_READ_B(P) _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int h = 0; h < 2; ++h) \
-    fb[P][j][h] = x32_operand<BN, TB>(curB, P, wn * WN + j * 32, h, lane)
+      fb[P][j][h] = x32_operand<BN, TB>(curB, P, wn * WN + j * 32, h, lane)
 #define SSASR_XW_STEP(PA, PB)                                                                      \
-  _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                    \
-  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
-  _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
-    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][j][h], fa[PA][i][h], acc[i][j], 0, 0, 0)  \
-                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i][h], fb[PB][j][h], acc[i][j], 0, 0, 0)
-  // Steady state: this K step's tile in LDS, the next one's values in registers, the one after that still to be
-  // fetched, all three full steps of the predicate-free path -- ONE basic block (no branch, no loop inside).
-  if (interior && la.advance_flat_ok() && lb.advance_flat_ok()) {
-    for (; k0 + 3 * BK <= kend; k0 += BK) {
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
+      acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][j][h], fa[PA][i][h], acc[i][j], 0, 0, 0)  \
+                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i][h], fb[PB][j][h], acc[i][j], 0, 0, 0)
+    // Steady state: this K step's tile in LDS, the next one's values in registers, the one after that still to be
+    // fetched, all three full steps of the predicate-free path -- ONE basic block (no branch, no loop inside).
+    {
+#pragma nounroll
+      for (; k0 + 3 * BK <= kend; k0 += BK) {
+        const char* curA = xlds + stage * WIDE_STAGE;
+        const char* curB = curA + XGeom<BM>::BYTES;
+        char* nxt = xlds + (stage ^ 1) * WIDE_STAGE;
+        bf16x8 fa[3][TM][2], fb[3][TN][2];
+        SSASR_XW_READ_A(2); SSASR_XW_READ_B(0);
+        SSASR_XW_READ_A(0); SSASR_XW_READ_B(2);
+        SSASR_XW_STEP(2, 0);      // smallest terms first
+        SSASR_XW_READ_A(1); SSASR_XW_READ_B(1);
+        SSASR_XW_STEP(0, 2);
+        la.store(nxt, ra);        // the tile after this one: split + store into the other stage
+        if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
+        SSASR_XW_STEP(1, 1);
+        lb.store(nxt + XGeom<BM>::BYTES, rb);
+        SSASR_XW_STEP(1, 0);
+        step_loaders(k0 + 2 * BK);  // the tile after that: its registers are free now
+        fetch();
+        SSASR_XW_STEP(0, 1);
+        SSASR_XW_STEP(0, 0);
+        __syncthreads();          // the next tile is in place, this one is no longer read
+        stage ^= 1;
+      }
+    }
+    SSASR_XW_STAMP(2);                    // steady state done
+    // the last two K steps
+#pragma nounroll
+    for (; k0 < kend; k0 += BK) {
+      const bool more = k0 + BK < kend;
+      const bool more2 = k0 + 2 * BK < kend;
       const char* curA = xlds + stage * WIDE_STAGE;
       const char* curB = curA + XGeom<BM>::BYTES;
       char* nxt = xlds + (stage ^ 1) * WIDE_STAGE;
       bf16x8 fa[3][TM][2], fb[3][TN][2];
       SSASR_XW_READ_A(2); SSASR_XW_READ_B(0);
       SSASR_XW_READ_A(0); SSASR_XW_READ_B(2);
-      SSASR_XW_STEP(2, 0);      // smallest terms first
       SSASR_XW_READ_A(1); SSASR_XW_READ_B(1);
+      SSASR_XW_STEP(2, 0);
       SSASR_XW_STEP(0, 2);
-      la.store(nxt, ra);        // the tile after this one: split + store into the other stage
-      if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
       SSASR_XW_STEP(1, 1);
-      lb.store(nxt + XGeom<BM>::BYTES, rb);
-      SSASR_XW_STEP(1, 0);
-      {                         // the tile after that: its registers are free now
-        la.advance_flat();
-        lb.advance_flat();
-        const bool seg_end = g.kcat > 1 && (k0 + 2 * BK) % g.K == 0;
-        la.jump(seg_end ? jumpA : 0);
-        lb.jump(seg_end ? jumpB : 0);
-        la.load_fast(ra);
-        lb.load_fast(rb);
+      if (more) {
+        la.store(nxt, ra);
+        lb.store(nxt + XGeom<BM>::BYTES, rb);
+        if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
       }
+      if (more2) { step_loaders(k0 + 2 * BK); fetch(); }
+      SSASR_XW_STEP(1, 0);
       SSASR_XW_STEP(0, 1);
       SSASR_XW_STEP(0, 0);
-      __syncthreads();          // the next tile is in place, this one is no longer read
+      __syncthreads();
       stage ^= 1;
     }
-  }
-  // the last two K steps, partial steps, guarded operands
-  for (; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    const bool more2 = k0 + 2 * BK < kend;
-    const char* curA = xlds + stage * WIDE_STAGE;
-    const char* curB = curA + XGeom<BM>::BYTES;
-    char* nxt = xlds + (stage ^ 1) * WIDE_STAGE;
-    bf16x8 fa[3][TM][2], fb[3][TN][2];
-    SSASR_XW_READ_A(2); SSASR_XW_READ_B(0);
-    SSASR_XW_READ_A(0); SSASR_XW_READ_B(2);
-    SSASR_XW_READ_A(1); SSASR_XW_READ_B(1);
-    SSASR_XW_STEP(2, 0);
-    SSASR_XW_STEP(0, 2);
-    SSASR_XW_STEP(1, 1);
-    if (more) {
-      la.store(nxt, ra);
-      lb.store(nxt + XGeom<BM>::BYTES, rb);
-      if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
-    }
-    if (more2) { step_loaders(k0 + 2 * BK); fetch(k0 + 2 * BK); }
-    SSASR_XW_STEP(1, 0);
-    SSASR_XW_STEP(0, 1);
-    SSASR_XW_STEP(0, 0);
-    __syncthreads();
-    stage ^= 1;
-  }
 #undef SSASR_XW_STEP
 #undef SSASR_XW_READ_A
 #undef SSASR_XW_READ_B
-  gemm_epilogue32<TM, TN, TR>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, bz, kz == 0, g.splitk > 1);
-  if constexpr (SEG) {
-    if (do_colsum) {          // (workgroup-uniform) the NT / (BM / 4) threads of a column quad meet in LDS
-      constexpr int PER_ROW = BM / 4;
-      float4* red = reinterpret_cast<float4*>(xlds);          // the operand images are no longer read
-      red[tid] = csum;
+
+    // ---- this part's values leave for C.  First the NEXT part is opened: its first global loads are in flight while
+    // the stores below drain (a part is 32 K steps at K = 1,024: the two dependent load latencies of a prologue
+    // and the 128 KB of an epilogue were a fifth of it)
+    EpiDesc ed{g.C + (int64_t)bz * g.sc, g.mc, g.bias1 ? g.bias1 + (int64_t)bz * g.sbias : nullptr,
+               g.bias2 ? g.bias2 + (int64_t)bz * g.sbias : nullptr, g.alpha, g.beta, g.act, g.M, g.N};
+    const bool lead = ks0 == 0;                         // the part with the tile's first K step brings the biases
+    const bool whole = ks0 == 0 && ks1 == plan.ksteps;
+    const int em0 = m0 + wm * WM, en0 = n0 + wn * WN;
+    const int cur_t = t, cur_bz = bz, cur_m0 = m0;
+    const bool cur_colsum = do_colsum;
+    const bool has_next = u < u_end;
+    SSASR_XW_STAMP(3);                    // K loop done
+    if (has_next) open_part();
+    SSASR_XW_STAMP(4);                    // next part opened
+    float* stg = reinterpret_cast<float*>(xlds + wave * 17408);
+    if (plan.acc) {
+      gemm_epilogue32<TM, TN, TR>(ed, acc, em0, en0, lane, lead, true);
+    } else if (whole) {
+      if (plan.epi == 2 || plan.epi == 3) {     // diagnostic: the same stores into this run's slab instead of C
+        EpiDesc e2 = ed;
+        e2.C = plan.slabs + (size_t)run * SK_SLABS * SK_SLAB_FLOATS; e2.mc = RowMap{128, 0, 0, 0}; e2.M = 256; e2.N = 128;
+        e2.b1 = e2.b2 = nullptr;
+        if (plan.epi == 2) gemm_epilogue32<TM, TN, TR>(e2, acc, wm * WM, wn * WN, lane, true, false);
+        else gemm_epilogue32_rows(e2, acc, wm * WM, wn * WN, lane, stg);
+      } else
+      if (TR && !plan.epi) gemm_epilogue32_rows(ed, acc, em0, en0, lane, stg);
+      else gemm_epilogue32<TM, TN, TR>(ed, acc, em0, en0, lane, true, false);
+    } else {
+      const int tu = cur_t * plan.ksteps;
+      const int first = sk_owner(plan, tu), parts = sk_owner(plan, tu + plan.ksteps - 1) - first + 1;
+      unsigned* w = plan.ws + 2 * first;
+      if (tid == 0) sk_old = atomicAdd(w + 0, 1u);
       __syncthreads();
-      if (tid < PER_ROW) {
-        float4 v = red[tid];
+      const unsigned old = sk_old;
+      float* slab0 = plan.slabs + (size_t)first * SK_SLABS * SK_SLAB_FLOATS;
+      if (old + 1 < (unsigned)parts) {
+        // not the last part: accumulators -> slab `old` (lane-contiguous 16-byte pieces: a store instruction writes 1 KB)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab0 + (size_t)old * SK_SLAB_FLOATS, 0,
+                                                                            (int)(SK_SLAB_FLOATS * 4), 0x00020000);
 #pragma unroll
-        for (int k = 1; k < NT / PER_ROW; ++k) {
-          const float4 a = red[tid + k * PER_ROW];
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4g, v), rs,
+                                                     (((i * TN + j) * 4 + q4) * NT + tid) * 16, 0, 16);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                // every wave's stores have left
+        if (tid == 0) atomicAdd(w + 1, 1u);
+      } else {
+        if (tid == 0) {
+          while (__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 < (unsigned)parts) __builtin_amdgcn_s_sleep(4);
         }
-        const int m = m0 + 4 * tid;
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+        __syncthreads();
+        for (int pp = 0; pp + 1 < parts; ++pp) {
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab0 + (size_t)pp * SK_SLAB_FLOATS, 0,
+                                                                              (int)(SK_SLAB_FLOATS * 4), 0x00020000);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (m + e < g.M) {
-            atomicAdd(gin.colsum[bz] + m + e, g.alpha * vv[e]);
-            if (gin.colsum2[bz]) atomicAdd(gin.colsum2[bz] + m + e, g.alpha * vv[e]);
-          }
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (((i * TN + j) * 4 + q4) * NT + tid) * 16, 0, 16));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q4 + e] += v[e];
+              }
+        }
+        if (TR && !plan.epi) gemm_epilogue32_rows(ed, acc, em0, en0, lane, stg);
+        else gemm_epilogue32<TM, TN, TR>(ed, acc, em0, en0, lane, true, false);
+        if (tid == 0) {                                 // the tile is complete: leave its words clean
+          __hip_atomic_store(w + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
+    __syncthreads();            // the staged rows have been read (and sk_old): the next part's prologue may write LDS
+    SSASR_XW_STAMP(5);                    // epilogue done
+    ++part_no;
+    if (has_next) SSASR_XW_STAMP(0);
+    if constexpr (SEG) {
+      if (cur_colsum) {         // (workgroup-uniform) the NT / (BM / 4) threads of a column quad meet in LDS
+        constexpr int PER_ROW = BM / 4;
+        float4* red = reinterpret_cast<float4*>(xlds);          // the operand images are no longer read
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < PER_ROW) {
+          float4 v = red[tid];
+#pragma unroll
+          for (int k = 1; k < NT / PER_ROW; ++k) {
+            const float4 a = red[tid + k * PER_ROW];
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+          const int m = cur_m0 + 4 * tid;
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (m + e < ed.M) {
+              atomicAdd(gin.colsum[cur_bz] + m + e, ed.alpha * vv[e]);
+              if (gin.colsum2[cur_bz]) atomicAdd(gin.colsum2[cur_bz] + m + e, ed.alpha * vv[e]);
+            }
+          }
+        }
+        __syncthreads();        // the next part's prologue rewrites the image
+      }
+    }
+    if (!has_next) break;
   }
+#undef SSASR_XW_STAMP
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1089,10 +1345,91 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
   return SSASR_OK;
 }
 
-int launch_wide(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
+// What the wide kernel takes (it has no guarded loads): 16-byte loads legal everywhere, whole K steps, K-side row maps
+// that advance without a loop.
+static bool flat_map(const RowMap& m) { return m.inner == 0 || m.inner >= BK; }
+static bool wide_eligible(const GemmDesc& g, bool vecA, bool vecB) {
+  if (!vecA || !vecB || (g.ta && g.M % 4) || (g.ta && !flat_map(g.ma))) return false;
+  if (g.nseg > 0) {
+    for (int k = 0; k < g.nseg; ++k)
+      if (g.seg[k].K % BK || g.seg[k].N % 4 || !flat_map(g.seg[k].mb)) return false;
+    return true;
+  }
+  return g.K > 0 && g.K % BK == 0 && !(g.tb && g.N % 4) && !(g.tb && !flat_map(g.mb));
+}
+
+// most runs a tile's K steps can touch
+static int parts_bound(long long units, long long G, int ksteps) {
+  const long long per = units / G;            // a run is `per` or `per + 1` units long
+  return per <= 0 ? ksteps + 1 : (int)((ksteps + per - 2) / per + 1);
+}
+
+// Launch of the wide kernel as a stream-K grid.  streamk = false: one run per tile and K slice (the classic
+// grid: whole tiles, split-K slices added atomically), for A/B.
+int launch_wide(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st, bool streamk) {
   GemmDesc g = gin;
-  dim3 grid((g.N + WIDE_BN - 1) / WIDE_BN, (g.M + WIDE_BM - 1) / WIDE_BM, g.batch * g.splitk);
-  dim3 block(WIDE_NT);
+  WidePlan p{};
+  p.tiles_x = (g.N + WIDE_BN - 1) / WIDE_BN;
+  if (g.nseg > 0) {
+    p.tiles_x = 0;
+    for (int k = 0; k < g.nseg; ++k) p.tiles_x += (g.seg[k].N + WIDE_BN - 1) / WIDE_BN;
+  }
+  p.tiles_y = (g.M + WIDE_BM - 1) / WIDE_BM;
+  const int kmax = g.nseg > 0 ? (g.nseg > 1 && g.seg[1].K > g.seg[0].K ? g.seg[1].K : g.seg[0].K) : (g.kcat > 1 ? g.kcat * g.K : g.K);
+  p.ksteps = (kmax + BK - 1) / BK;
+  if (p.ksteps < 1) p.ksteps = 1;
+  const long long tiles = (long long)p.tiles_x * p.tiles_y * g.batch;
+  if (tiles * p.ksteps > 0x7fffffffll) return SSASR_EARG;
+  p.units = (int)(tiles * p.ksteps);
+  p.acc = (g.splitk > 1 || g.nseg > 0) ? 1 : 0;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SSASR_EARG;
+    cus = prop.multiProcessorCount;
+  }
+  long long G;
+  if (!streamk) {
+    G = tiles * (g.splitk > 1 ? g.splitk : 1);      // classic: every run = the same share of one tile's K steps
+  } else if (p.acc) {
+    G = p.units / 8 < cus ? p.units / 8 : cus;      // at least 8 K steps per run
+  } else {
+    G = tiles < cus ? tiles : cus;                  // whole tiles when they do not fill the chip
+    if (g.act != 0 || g.beta != 0.f) G = tiles;     // cut tiles are finished by plain adds: no epilogue function
+  }
+  if (G < 1) G = 1;
+  // tickets exist for the cut tiles of the store mode only, one set per run
+  if (!p.acc && G != tiles && G > SK_MAX_G) return SSASR_EARG;
+  if (G > 0x7fffffffll) return SSASR_EARG;
+  p.G = (int)G;
+  p.per = p.units / p.G; p.rem = p.units % p.G;
+  // Workspace of the cut tiles (tickets + slabs), allocated once per process on first use: SK_REGIONS regions taken in
+  // turn, so that launches in flight on different streams never share one (the one allocation this library makes).
+  static std::atomic<unsigned> region{0};
+  static unsigned* ws_base = nullptr;
+  static float* slab_base = nullptr;
+  if (!p.acc && G != tiles) {
+    if (g.splitk > 1 || parts_bound(p.units, G, p.ksteps) > SK_SLABS + 1) return SSASR_EARG;
+    if (!ws_base) {
+      unsigned* w = nullptr;
+      float* sl = nullptr;
+      SSASR_HIP(hipMalloc((void**)&w, (size_t)SK_REGIONS * SK_MAX_G * 2 * sizeof(unsigned)));
+      SSASR_HIP(hipMemset(w, 0, (size_t)SK_REGIONS * SK_MAX_G * 2 * sizeof(unsigned)));
+      SSASR_HIP(hipMalloc((void**)&sl, (size_t)SK_REGIONS * SK_MAX_G * SK_SLABS * SK_SLAB_FLOATS * sizeof(float)));
+      slab_base = sl;
+      ws_base = w;
+    }
+    const unsigned r = region.fetch_add(1) % SK_REGIONS;
+    p.ws = ws_base + (size_t)r * SK_MAX_G * 2;
+    p.slabs = slab_base + (size_t)r * SK_MAX_G * SK_SLABS * SK_SLAB_FLOATS;
+  }
+  {
+    const SsasrOptions& o = ssasr_options();
+    p.epi = getenv("SSASR_GEMM_EPI") ? atoi(getenv("SSASR_GEMM_EPI")) : 0;
+    p.trace = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)o.gemm_trace_hi << 32) | (unsigned)o.gemm_trace_lo);
+  }
+  dim3 grid((unsigned)G), block(WIDE_NT);
   constexpr size_t lds = 2 * WIDE_STAGE;
 #define SSASR_XW_LAUNCH(...)                                                                                \
   do {                                                                                                      \
@@ -1102,14 +1439,11 @@ int launch_wide(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
       SSASR_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       once = true;                                                                                          \
     }                                                                                                       \
-    hipLaunchKernelGGL(fn, grid, block, lds, st, g, vecA, vecB);                                            \
+    hipLaunchKernelGGL(fn, grid, block, lds, st, g, vecA, vecB, p);                                         \
   } while (0)
   if (g.nseg > 0) {
-    int nt = 0;
-    for (int k = 0; k < g.nseg; ++k) nt += (g.seg[k].N + WIDE_BN - 1) / WIDE_BN;
-    grid.x = (unsigned)nt;
     SSASR_XW_LAUNCH(true, true, false, true);
-  } else if (g.splitk > 1) {
+  } else if (p.acc) {
     if (!g.ta && !g.tb) SSASR_XW_LAUNCH(false, false, false);
     else if (!g.ta && g.tb) SSASR_XW_LAUNCH(false, true, false);
     else if (g.ta && !g.tb) SSASR_XW_LAUNCH(true, false, false);
@@ -1179,9 +1513,10 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
   if (g.tile == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
   if (g.tile == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
-  if (g.tile == 256 && ssasr_options().gemm_x6) return launch_wide(g, vecA, vecB, st);
+  if (g.tile == 256 && ssasr_options().gemm_x6 && wide_eligible(g, vecA, vecB)) return launch_wide(g, vecA, vecB, st, true);
   if (const int forced = ssasr_options().gemm_tile) {       // diagnostic: force a tile shape
-    if (forced == 256 && ssasr_options().gemm_x6) return launch_wide(g, vecA, vecB, st);
+    if (forced == 256 && ssasr_options().gemm_x6 && wide_eligible(g, vecA, vecB)) return launch_wide(g, vecA, vecB, st, true);     // wide, stream-K
+    if (forced == 255 && ssasr_options().gemm_x6 && wide_eligible(g, vecA, vecB)) return launch_wide(g, vecA, vecB, st, false);    // wide, classic grid
     if (forced == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
     if (forced == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
   }
@@ -1204,6 +1539,21 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
     } else {
       t128 = n == 1 ? 0.63 : 1.0 * (double)(n / 2) + 0.9 * (double)(n % 2);
       t64 = 0.133 + 0.00052 * (double)small * (256.0 / (double)cus);
+    }
+    if (ssasr_options().gemm_x6 && ssasr_options().gemm_wide) {
+      // The wide kernel as a stream-K grid (gemm_x6w_kernel): every CU runs units / 256 K steps at 2.4 us each plus
+      // ~16 us per part (prologue, epilogue, hand-off of a cut tile) -- tools/gemm_wide.py on the products of the
+      // 32 x 800-frame step: 100 K steps per run in 307 us, 50 in 163, 25 in 89, 256 of 4096^3 in 624.  The tile
+      // models above are at K = 1,024 and scale with K.
+      const int64_t wide = (int64_t)((g.M + WIDE_BM - 1) / WIDE_BM) * ((g.N + WIDE_BN - 1) / WIDE_BN) * g.batch;
+      const int ktot = g.kcat > 1 ? g.kcat * g.K : g.K;
+      const double ksteps = (double)((ktot + BK - 1) / BK);
+      if (wide >= cus && ktot >= 4 * BK && wide_eligible(g, vecA, vecB)) {
+        const double per = (double)wide * ksteps / (double)cus;
+        const double twide = 2.4 * per + 16.0 * (per / ksteps + 1.0);
+        const double scale = (double)ktot / 1024.0;
+        if (twide < 0.97 * scale * (t64 < t128 ? t64 : t128)) return launch_wide(g, vecA, vecB, st, true);
+      }
     }
     if (t64 < t128) return launch_tiles<64, 64>(g, vecA, vecB, st);
   }

@@ -30,6 +30,8 @@ void init_options() {
   g_opt.delay_bwd_ksplit = g_opt.delay_bwd;
   g_opt.gemm_tile = env_int("SSASR_GEMM_TILE", 0);
   g_opt.gemm_x6 = env_int("SSASR_GEMM_X6", 1);
+  g_opt.gemm_wide = env_int("SSASR_GEMM_WIDE", 1);
+  g_opt.gemm_trace_lo = g_opt.gemm_trace_hi = 0;
   g_opt.gemm_kcat = env_int("SSASR_GEMM_KCAT", 1);
   g_opt.wgrad_fused = env_int("SSASR_WGRAD_FUSED", 1);
   g_opt.no_windows = env_flag("SSASR_NO_WINDOWS");
@@ -55,7 +57,10 @@ const Named kNames[] = {
     {"SSASR_PERSIST_DELAY_FWD", &SsasrOptions::delay_fwd},
     {"SSASR_PERSIST_DELAY_BWD", &SsasrOptions::delay_bwd},
     {"SSASR_GEMM_TILE", &SsasrOptions::gemm_tile},
+    {"SSASR_GEMM_TRACE_LO", &SsasrOptions::gemm_trace_lo},
+    {"SSASR_GEMM_TRACE_HI", &SsasrOptions::gemm_trace_hi},
     {"SSASR_GEMM_X6", &SsasrOptions::gemm_x6},
+    {"SSASR_GEMM_WIDE", &SsasrOptions::gemm_wide},
     {"SSASR_GEMM_KCAT", &SsasrOptions::gemm_kcat},
     {"SSASR_WGRAD_FUSED", &SsasrOptions::wgrad_fused},
     {"SSASR_NO_WINDOWS", &SsasrOptions::no_windows},

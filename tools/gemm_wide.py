@@ -26,7 +26,8 @@ shapes = [  # name, ta, tb, batch, M, N, K, splitk
     ('dW_hh TT x2 sk8', 1, 1, 2, 1024, 256, 3200, 8),
     ('big NT 4096^3', 0, 0, 1, 4096, 4096, 4096, 1), ('big NN 4096^3', 0, 1, 1, 4096, 4096, 4096, 1),
     ('big TT 4096^3', 1, 1, 1, 4096, 4096, 4096, 1)]
-want = sys.argv[2].split(',') if len(sys.argv) > 2 else None
+want = sys.argv[2].split(',') if len(sys.argv) > 2 and sys.argv[2] != '-' else None
+TILES = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0, 128, 255, 256]
 for name, ta, tb, nb, M, N, K, sk in shapes:
     if want and not any(w in name for w in want):
         continue
@@ -37,17 +38,22 @@ for name, ta, tb, nb, M, N, K, sk in shapes:
         a, b, out = a[0], b[0], out[0]
     row = []
     ref = None
-    for tile in (0, 128, 256):
-        assert lib.ssasr_set_option(b'SSASR_GEMM_TILE', tile) == 0
-        if sk > 1:
-            out.zero_()
-        us = t(lambda: ops.gemm(a, b, ta=bool(ta), tb=bool(tb), out=out, splitk=sk))
-        if sk == 1:
-            cur = out.clone()
-            if ref is None:
-                ref = cur
-            else:
-                assert (cur - ref).abs().max().item() <= 1e-3 * ref.abs().max().item(), name
-        row.append('%s %7.1f us %6.1f TF' % ({0: 'auto', 128: '128', 256: 'wide'}[tile], us, 2.0 * nb * M * N * K / us / 1e6))
+    best = {}
+    for rnd in range(3):                 # the variants in turn, three rounds: the chip's clock drifts with its load history
+        for tile in (TILES if rnd % 2 == 0 else TILES[::-1]):
+            assert lib.ssasr_set_option(b'SSASR_GEMM_TILE', tile) == 0
+            if sk > 1:
+                out.zero_()
+            us = t(lambda: ops.gemm(a, b, ta=bool(ta), tb=bool(tb), out=out, splitk=sk))
+            best[tile] = min(best.get(tile, 1e30), us)
+            if sk == 1 and rnd == 0:
+                cur = out.clone()
+                if ref is None:
+                    ref = cur
+                else:
+                    assert (cur - ref).abs().max().item() <= 1e-3 * ref.abs().max().item(), name
+    for tile in TILES:
+        us = best[tile]
+        row.append('%s %7.1f us %6.1f TF' % ({0: 'auto', 128: '128', 256: 'wideSK', 255: 'wide'}[tile], us, 2.0 * nb * M * N * K / us / 1e6))
     lib.ssasr_set_option(b'SSASR_GEMM_TILE', 0)
     print('%-18s %2d x %5dx%5dx%5d | %s' % (name, nb, M, N, K, ' | '.join(row)), flush=True)
