@@ -652,6 +652,7 @@ def main():
     if (args.gpus > 1 or args.self_launch) and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))            # no GPU call has been made in this process
     from ss_asr_amd import dist as sdist
+    os.environ.setdefault('SSASR_RCCL_INFO', '1')      # RCCL's init report -> collective.rccl_channels_granted
     rank, world, local = sdist.init_from_env()
     if world != args.gpus:
         if rank == 0:
@@ -843,6 +844,7 @@ def main():
         extras['collective'] = dict(backend=tdist.get_backend(), world_size=tdist.get_world_size(),
                                     bytes_per_step=4 * g.numel(), buckets=red.buckets(), overlap=bool(red.overlap),
                                     fallback=fallback, nccl_max_nchannels=os.environ.get('NCCL_MAX_NCHANNELS'),
+                                    rccl_channels_granted=sdist.rccl_channels(),
                                     allreduce_alone_ms=dict(median=round(ar[len(ar) // 2], 4), min=round(ar[0], 4),
                                                             max=round(ar[-1], 4), reps=len(ar),
                                                             bytes=4 * g.numel(),

@@ -63,8 +63,31 @@ def init_from_env(backend=None):
             # tuner would pick (a 41 MB all-reduce hidden behind ~1 ms of recurrence does not need more); an
             # explicit NCCL_MAX_NCHANNELS in the environment wins.
             os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
+            if os.environ.get('SSASR_RCCL_INFO'):
+                # bench.py: let RCCL write its init report to a file of this rank's, so that the channel count it
+                # GRANTED (not the cap asked for above) can be put into the bench line: rccl_channels()
+                os.environ.setdefault('NCCL_DEBUG', 'INFO')
+                os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH')
+                os.environ.setdefault('NCCL_DEBUG_FILE', '/tmp/ssasr_rccl_%d.log' % os.getpid())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def rccl_channels():
+    """The channel count RCCL set this rank's communicator up with, read from the init report that
+    SSASR_RCCL_INFO=1 made it write ('Channel 00/32 : ...' lines, or 'N coll channels'); None when no report
+    exists (gloo, no SSASR_RCCL_INFO) or it names no channels.  Call after the first collective."""
+    import re
+    path = os.environ.get('NCCL_DEBUG_FILE', '')
+    try:
+        text = open(path).read()
+    except OSError:
+        return None
+    m = re.findall(r'(\d+) coll channels', text)
+    if m:
+        return int(m[-1])
+    m = re.findall(r'Channel \d+/(\d+)', text)
+    return int(m[-1]) if m else None
 
 
 def is_active():

@@ -157,6 +157,10 @@ from ss_asr_amd.gpu_loader import rank_batches
 from ss_asr_amd.synthetic import make_batch
 DIMS = (50, 256, 256, 128, 80)
 def batch(k):
+    if os.environ.get('SSASR_TEST_LONG'):
+        # BASELINE.json configs[3]'s shape: T' = 375 encoder frames -> blstm_4 runs as three column windows, the decode
+        # loop takes its long-encoder form
+        return make_batch(np.array([3000 - 160 * k, 2400, 1800 + 80 * k, 1520]), np.array([24, 18 + k, 12, 9]), 80, seed=170 + k)
     return make_batch(np.array([216 - 16 * k, 160, 96 + 8 * k, 40]), np.array([14, 9 + k, 6, 3]), 80, seed=70 + k)
 def model():
     m = ASR(*DIMS, 1.0)
@@ -248,11 +252,14 @@ def _result(proc, timeout):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('overlap', [True, False])
-def test_two_ranks_on_one_gpu_follow_the_section_8e_statement_on_the_real_step(tmp_path, overlap):
+@pytest.mark.parametrize('overlap,long_shape', [(True, False), (False, False), (True, True)])
+def test_two_ranks_on_one_gpu_follow_the_section_8e_statement_on_the_real_step(tmp_path, overlap, long_shape):
     base = dict(os.environ)
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND', 'SSASR_DDP_NO_OVERLAP'):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SSASR_DIST_SINGLE', 'SSASR_DIST_BACKEND', 'SSASR_DDP_NO_OVERLAP',
+              'SSASR_TEST_LONG'):
         base.pop(k, None)
+    if long_shape:              # configs[3] under DDP: column windows + the long-encoder decode loop
+        base['SSASR_TEST_LONG'] = '1'
     single = _result(_child(DDP_SINGLE, base), 420)
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
