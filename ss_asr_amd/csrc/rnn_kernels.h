@@ -1279,6 +1279,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
 #pragma unroll
       for (int t = 0; t < SPW; ++t) part += __builtin_bit_cast(f32x4, raw[t]);
     }
+    SSASR_PTRACE(i, 1);
     {
       // the four 16-lane groups hold the sums of sources = 0, 1, 2, 3 (mod 4): add them on the permlane
       // network (rows 0<->1, 2<->3, then the two halves) -- every lane ends with the same bits -- and run
@@ -1317,11 +1318,13 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
       SSASR_PTRACE(i, 6);
     }
     __syncthreads();        // gate derivatives in LDS
+    SSASR_PTRACE(i, 8);
     if (i + 1 < S) {
       // partial dh tiles of all units from this workgroup's 64 gate-derivative rows
       float4 b[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) b[g] = sG[i % NG][g][lane];
+      SSASR_PTRACE(i, 9);
       // Split level by level, each level's MFMAs issued as soon as its pieces exist, so that the
       // vector work of the next level runs beside them: b1 (a convert) -> a1 b1, a2 b1, a3 b1;
       // b2 -> a1 b2, a2 b2; b3 -> a1 b3.  One accumulator per (tile, K block): four chains.
@@ -1357,6 +1360,7 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
           }
         }
       }
+      SSASR_PTRACE(i, 10);
       const unsigned base = (unsigned)(i % BWD_RS_RING) * SLOT_B + (unsigned)tile * TILE_B;   // source = this tile
 #pragma unroll
       for (int t = 0; t < OT; ++t) {

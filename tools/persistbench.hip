@@ -32,7 +32,7 @@ static int report(const char* name, int nwg, double us_per_tick, int group_size)
   std::vector<unsigned long long> h(TR_WG * TR_N * TR_SLOTS);
   CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_trace), h.size() * sizeof(unsigned long long)));
   printf("%s: median over %d workgroups x %d steps, us since step start (slot 0):\n ", name, nwg, TR_N);
-  for (int k = 1; k < 10; ++k) {
+  for (int k = 1; k < 12; ++k) {
     std::vector<double> d;
     for (int w = 0; w < nwg; ++w)
       for (int i = 0; i < TR_N; ++i) {
