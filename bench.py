@@ -259,7 +259,14 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
         return e0.elapsed_time(e1) * 1e3 / n             # us per call
 
     us_i2h = timed(i2h, reps)
-    us_fwd = timed(fwd, reps) - us_i2h
+    # the forward recurrence = ssasr_bilstm_fwd minus its input projection, BOTH timed with the projection on the tile
+    # kernels of rounds 2-4 (SSASR_GEMM_WIDE 0): the stream-K projection that the launcher picks for this shape runs
+    # differently back to back with itself (warm instruction cache, its own workspace) than in front of the recurrence,
+    # which made the difference read 0.2 us per step high
+    lib.ssasr_set_option(b'SSASR_GEMM_WIDE', 0)
+    us_i2h_tiles = timed(i2h, reps)
+    us_fwd = timed(fwd, reps) - us_i2h_tiles
+    lib.ssasr_set_option(b'SSASR_GEMM_WIDE', 1)
     # The BPTT launch is timed DIRECTLY: HIP events on the launching stream around bwd() alone, per repetition
     # (the forward that refills `gates` / `tsave` runs before the first event of each pair), median over the
     # repetitions -- not a difference of three timings.  Inside the pair: the 8 MB ring fill and
@@ -921,6 +928,7 @@ def main():
         # the reference's own configuration (src/preprocess.py:194-198: 22,050 Hz -> n_fft 551, hop 220); 16 kHz
         # (n_fft 400, hop 160: a friendlier K for 32-deep MFMA steps) beside it
         out['roofline_frontend'] = frontend_roofline(device)
+        frontend_roofline(device, sr=16000, reps=3)           # (first use of another sample rate: bases built, buffers grown)
         at16 = frontend_roofline(device, sr=16000)
         out['roofline_frontend']['at_16khz'] = {k: at16[k] for k in ('achieved', 'frac', 'us_per_batch', 'utterances_per_sec', 'shape')}
         note('frontend: %s' % out['roofline_frontend'])
@@ -933,7 +941,9 @@ def main():
         out['config5'] = config5_bench(device)
         note('config 5 (Seed loop legs): %s' % out['config5'])
     if world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline([host_batches[k] for k in (1, 3, 5, 7)], host_batches[7])
+        # warm-up on the longest of the timed buckets (allocator growth and thread pools are paid there), then every second
+        # bucket from it down: ~13 s untimed + ~18 s timed on 16 cores
+        cb = cpu_baseline([host_batches[k] for k in (3, 5, 7)], host_batches[3])
         cb['sample'] = cb['sample'] % ('/'.join(str(int(b[0].shape[1])) for b in host_batches))
         out['cpu_baseline'] = cb
     print(json.dumps(out), flush=True)
