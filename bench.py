@@ -617,7 +617,7 @@ def self_launch(args):
         # stdout carries ONE JSON line (rank 0's); anything else the ranks' libraries print there goes to
         # stderr.  stderr is passed through AND scanned for the hand-off time-out message.
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
-        timed_out, got_line = False, False
+        timed_out, got_line, tail = False, False, []
         for line in proc.stdout:
             if line.startswith('{'):
                 sys.stdout.write(line)
@@ -626,19 +626,31 @@ def self_launch(args):
             else:
                 sys.stderr.write(line)
                 timed_out = timed_out or TIMEOUT_MARK in line
-        return proc.wait(), timed_out, got_line
+                tail.append(line)
+                del tail[:-400]
+        return proc.wait(), timed_out, got_line, tail
 
-    rc, timed_out, got_line = attempt(dict(os.environ))
+    rc, timed_out, got_line, tail = attempt(dict(os.environ))
     if rc != 0 and timed_out and not got_line and not os.environ.get('SSASR_DDP_NO_OVERLAP'):
         # A persistent hand-off timed out beside the overlapped all-reduce and the ranks could not recover
         # in-process: ONE more set of FRESH ranks (this process has never touched a GPU) with the tail's
         # collective issued after the backward pass instead of beside the first layer's BPTT.  The line
         # they print says so (config.ddp_overlap = false, config.ddp_fallback).
         note('ranks exited with a persistent time-out: starting fresh ranks with SSASR_DDP_NO_OVERLAP=1')
+        # the evidence of the first attempt (the time-out's kernel / workgroup / step message and what the ranks printed
+        # around it) is kept and named in the line the second attempt prints: a fallback must not erase its cause
+        log = os.path.abspath(os.environ.get('SSASR_DDP_FALLBACK_LOG') or 'bench_ddp_first_attempt.log')
+        try:
+            with open(log, 'w') as f:
+                f.write('first attempt: exit status %d, command %s\n' % (rc, ' '.join(cmd)))
+                f.writelines(tail)
+        except OSError:
+            log = 'unwritable: ' + log
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
             cmd[cmd.index('--master-port') + 1] = str(sk.getsockname()[1])
-        rc, _, _ = attempt(dict(os.environ, SSASR_DDP_NO_OVERLAP='1', SSASR_DDP_FALLBACK='parent'))
+        rc, _, _, _ = attempt(dict(os.environ, SSASR_DDP_NO_OVERLAP='1', SSASR_DDP_FALLBACK='parent',
+                                   SSASR_DDP_FALLBACK_LOG=log))
     return rc
 
 
@@ -879,7 +891,8 @@ def main():
                                'LAS 256/256/128, tf_rate 0.9, Adadelta' % (args.max_frames, args.batch),
                    'global_batch': world * args.batch, 'max_frames': args.max_frames,
                    'parallelism': 'dp%d' % world, 'ddp_overlap': bool(stepper.reducer.overlap) if dist_on else None,
-                   'ddp_fallback': fallback, 'mean_frames_per_utt': round(frames / (args.batch * args.steps), 1),
+                   'ddp_fallback': fallback, 'ddp_fallback_evidence': os.environ.get('SSASR_DDP_FALLBACK_LOG') if fallback else None,
+                   'mean_frames_per_utt': round(frames / (args.batch * args.steps), 1),
                    # fp32 tensors, fp32 accumulation; where a product runs on the matrix cores it is formed as six
                    # bf16 MFMAs over the exact three-way split of both fp32 operands unless
                    # SSASR_GEMM_X6=0 -- same results to fp32 rounding, checked against float64 in tests/

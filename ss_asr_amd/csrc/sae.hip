@@ -249,8 +249,10 @@ __global__ void pool_fwd_small_kernel(const float* y, const float* save, int64_t
         ldv<V>(base + ((int64_t)i * W + j) * C, v);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const float z = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
-          if (z > best[e]) { best[e] = z; bi[e] = i * pw + j; }
+          // ReLU, then max: a NaN stays a NaN through both, as in nn.ReLU / nn.MaxPool2d (the loss must show it)
+          const float a = fmaf(v[e], sc[e], sh[e]);
+          const float z = a > 0.f ? a : (a != a ? a : 0.f);
+          if (z > best[e] || z != z) { best[e] = z; bi[e] = i * pw + j; }
         }
       }
     stv<V>(p + pos * C + c, best);
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void pool_fwd_large_kernel(const float* y, con
     for (int e = e0 + wl; e < e1; e += WL) {
       const int i = e / pw, j = e - i * pw;
       float v = fmaf(base[((int64_t)i * W + j) * C], sc, sh);
-      v = v > 0.f ? v : 0.f;
+      v = v > 0.f ? v : (v != v ? v : 0.f);          // a NaN keeps its bits: as an unsigned key it beats every finite value
       const unsigned long long k = pool_key(v, e);
       best = k > best ? k : best;
     }

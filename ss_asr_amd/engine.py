@@ -282,7 +282,8 @@ class SAETrainStep:
         encoder runs on the second stream -- 1: its forward still AFTER the Listener's, its backward (autograd runs a
         node on its forward's stream; created after the Listener's nodes it comes first in autograd's order) beside the
         Listener's BPTT; 2: its forward beside the Listener's too (measured: the first layer's recurrence then takes
-        2.42 instead of 1.44 ms -- a loss).  The frame decoder waits for both."""
+        2.42 instead of 1.44 ms -- a loss).  The frame decoder waits for both.  A caller that runs forward_loss + backward by
+        itself with overlap on must call ops.join_side_stream() before it reads sae_flat.grad (__call__ does)."""
         from .seed_ops import sae_loss
         if not (self.overlap and x.is_cuda):
             listener_out, _ = self.asr.encoder(x, x_lens)
@@ -315,6 +316,9 @@ class SAETrainStep:
         with ops.shared_status_row(self.optim.status_row):
             loss, self.last_pred = self.forward_loss(x, x_lens)
             loss.backward(self._one)
+        # the speech encoder's backward ran on the second stream and wrote its parameter gradients through sinks
+        # (autograd's end-of-backward stream sync does not cover them): joined HERE, not left to the next reader
+        ops.join_side_stream()
         scale = sdist.allreduce_grad(self.sae_flat.grad)
         sdist.allreduce_grad(self.asr_flat.grad[self.lo:self.hi])
         self.optim.clip_and_step(self.grad_clip, grad_scale=scale, zero_grad=True)

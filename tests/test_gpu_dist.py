@@ -105,6 +105,7 @@ def _bench(extra_env, *flags):
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     env.update(SSASR_DIST_SINGLE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), **extra_env)
+    env.setdefault('SSASR_DDP_FALLBACK_LOG', os.path.join(os.environ.get('TMPDIR', '/tmp'), 'ssasr_bench_first_attempt_%d.log' % os.getpid()))
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-roofline',
                           '--no-config4', '--no-cpu-baseline', '--no-epoch'] + list(flags), env=env, cwd=ROOT,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -136,6 +137,11 @@ def test_bench_falls_back_to_the_late_all_reduce_after_a_persistent_time_out():
     parent, err = _bench({'SSASR_TEST_DROP_TILE_IF_OVERLAP': '3', 'SSASR_TEST_BENCH_DIE_ON_TIMEOUT': '1'}, '--self-launch')
     assert parent['config']['ddp_overlap'] is False and parent['config']['ddp_fallback'] == 'parent', parent['config']
     assert err.count('starting 1 ranks') == 2 and 'starting fresh ranks with SSASR_DDP_NO_OVERLAP=1' in err
+    # the first attempt's evidence survives the fallback and the line names it
+    ev = parent['config']['ddp_fallback_evidence']
+    assert ev and os.path.isfile(ev) and 'timed out' in open(ev).read()
+    assert clean['config']['ddp_fallback_evidence'] is None
+    assert clean['collective']['rccl_channels_granted'] is None or clean['collective']['rccl_channels_granted'] >= 1
 
 
 # ---- two ranks on the one GPU, gloo between them, the REAL train step -------------

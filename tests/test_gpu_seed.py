@@ -173,6 +173,35 @@ def test_batch_norm_relu_pool_matches_torch(B, T, W, C, ph, pw, border):
     assert float((pg.cpu().double() - pe.detach()).abs().max()) < 3e-6 * max(1.0, float(pe.detach().abs().max()))
 
 
+@pytest.mark.parametrize('ph,pw', [(2, 2), (50, 8)])
+def test_batch_norm_relu_pool_lets_a_nan_through(ph, pw):
+    """nn.ReLU and nn.MaxPool2d propagate NaN (the reference's loss is NaN when an activation is, and Solver.step then
+    skips the update, src/trainer.py:131-148); the fused kernels -- the small-window form and the chunked large-window
+    form -- must not turn it into 0.  Eval mode: with running statistics the NaN stays in its own value."""
+    lib, p, st = _lib_call()
+    g = torch.Generator().manual_seed(3)
+    B, T, W, C = 2, 100, 16, 8
+    y = torch.randn(B, T, W, C, generator=g)
+    y[1, 57, 9, 3] = float('nan')
+    gamma, beta = 0.5 + torch.rand(C, generator=g), torch.randn(C, generator=g)
+    rm0, rv0 = torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+        want = F.max_pool2d(torch.relu(bn(y.permute(0, 3, 1, 2))), (ph, pw)).permute(0, 2, 3, 1)
+    yg, gam, bet, rm, rv = (t.cuda() for t in (y, gamma, beta, rm0.clone(), rv0.clone()))
+    ws = torch.empty(max(int(lib.ssasr_bn_ws_floats(C)), int(lib.ssasr_pool_ws_floats(B, T, W, C, ph, pw))), device='cuda')
+    save = torch.empty(4 * C, device='cuda')
+    assert lib.ssasr_bn_stats(p(yg), B * T * W, C, p(gam), p(bet), p(rm), p(rv), 0.1, 1e-5, 0, p(ws), p(save), st()) == 0
+    pg = torch.empty(B, T // ph, W // pw, C, device='cuda')
+    idx = torch.empty(B, T // ph, W // pw, C, device='cuda', dtype=torch.int32)
+    assert lib.ssasr_bn_relu_pool_fwd(p(yg), p(save), B, T, W, C, ph, pw, p(pg), p(idx), p(ws), st()) == 0
+    got = pg.cpu()
+    assert int(torch.isnan(want).sum()) == 1 and torch.equal(torch.isnan(got), torch.isnan(want))
+    ok = ~torch.isnan(want)
+    assert float((got[ok] - want[ok]).abs().max()) < 1e-5
+
+
 def test_frame_decoder_input_and_smooth_l1_match_torch():
     """ssasr_sae_concat_* and ssasr_smooth_l1_* against torch: [listener frame | global encoding] rows with the
     broadcast's sum in backward; the loss of src/trainer.py:811-818 with its zero padding up to batch_t (R < bt:
