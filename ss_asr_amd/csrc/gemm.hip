@@ -1548,12 +1548,14 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
       const int64_t wide = (int64_t)((g.M + WIDE_BM - 1) / WIDE_BM) * ((g.N + WIDE_BN - 1) / WIDE_BN) * g.batch;
       const int ktot = g.kcat > 1 ? g.kcat * g.K : g.K;
       const double ksteps = (double)((ktot + BK - 1) / BK);
-      if (wide >= cus / 2 && ktot >= 4 * BK && wide_eligible(g, vecA, vecB)) {
-        // fewer tiles than CUs: whole tiles, one per workgroup (launch_wide), i.e. ksteps per run
-        const double per = wide >= cus ? (double)wide * ksteps / (double)cus : ksteps;
+      // (With 128..255 tiles -- whole tiles, one per workgroup -- the kernel is faster than the tile kernels back to back
+      // with itself, but alternating on the 470-frame train step the step was 0.4 % SLOWER: 5.681 against 5.659 ms,
+      // tools/ab_option.py.  Only products that fill the chip take it, and only on a clear margin.)
+      if (wide >= cus && ktot >= 4 * BK && wide_eligible(g, vecA, vecB)) {
+        const double per = (double)wide * ksteps / (double)cus;
         const double twide = 2.4 * per + 16.0 * (per / ksteps + 1.0);
         const double scale = (double)ktot / 1024.0;
-        if (twide < 0.97 * scale * (t64 < t128 ? t64 : t128)) return launch_wide(g, vecA, vecB, st, true);
+        if (twide < 0.92 * scale * (t64 < t128 ? t64 : t128)) return launch_wide(g, vecA, vecB, st, true);
       }
     }
     if (t64 < t128) return launch_tiles<64, 64>(g, vecA, vecB, st);
