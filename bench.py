@@ -259,14 +259,20 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
         return e0.elapsed_time(e1) * 1e3 / n             # us per call
 
     us_i2h = timed(i2h, reps)
-    # the forward recurrence = ssasr_bilstm_fwd minus its input projection, BOTH timed with the projection on the tile
-    # kernels of rounds 2-4 (SSASR_GEMM_WIDE 0): the stream-K projection that the launcher picks for this shape runs
-    # differently back to back with itself (warm instruction cache, its own workspace) than in front of the recurrence,
-    # which made the difference read 0.2 us per step high
-    lib.ssasr_set_option(b'SSASR_GEMM_WIDE', 0)
-    us_i2h_tiles = timed(i2h, reps)
-    us_fwd = timed(fwd, reps) - us_i2h_tiles
-    lib.ssasr_set_option(b'SSASR_GEMM_WIDE', 1)
+    # the forward recurrence = ssasr_bilstm_fwd minus its input projection, the two timed IN TURN (projection, whole call,
+    # projection, ...: HIP events around each, medians): inside the call the projection runs behind a recurrence, so the
+    # stand-alone one is timed behind a recurrence too -- back to back with itself the stream-K projection is 5-10 % faster
+    # than there (warm instruction cache, the chip's clock), and a difference of two separate loops read up to 0.35 us per
+    # step wrong in either direction
+    n_alt = max(reps, 5)
+    alt = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_alt)]
+    fwd()
+    torch.cuda.synchronize()
+    for e in alt:
+        e[0].record(); i2h(); e[1].record(); fwd(); e[2].record()
+    torch.cuda.synchronize()
+    med = lambda v: sorted(v)[len(v) // 2]
+    us_fwd = (med([e[1].elapsed_time(e[2]) for e in alt]) - med([e[0].elapsed_time(e[1]) for e in alt])) * 1e3
     # The BPTT launch is timed DIRECTLY: HIP events on the launching stream around bwd() alone, per repetition
     # (the forward that refills `gates` / `tsave` runs before the first event of each pair), median over the
     # repetitions -- not a difference of three timings.  Inside the pair: the 8 MB ring fill and
@@ -301,7 +307,7 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
                         shape=dict(S=S, N=N, H=H, directions=2),
                         timing=('HIP events around the launch alone, median of %d (min %.1f, max %.1f us)'
                                 % (len(bwd_samples), bwd_samples[0], bwd_samples[-1])) if name.startswith('lstm_enc_bwd')
-                        else 'HIP events around ssasr_bilstm_fwd minus the input projection timed the same way',
+                        else 'HIP events around ssasr_bilstm_fwd minus HIP events around its input projection, launched in turn, medians',
                         note='latency bound: one cross-XCD exchange per time step; see DESIGN.md 4.2'))
     # The input projection of that layer (one launch, both directions): the one true dense contraction
     # of the path.  fp32 operands and accumulation; products run as six bf16 MFMAs on the exact

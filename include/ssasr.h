@@ -46,7 +46,9 @@ int ssasr_abi_version(void);
  * used -- entry points never read the environment -- and may be changed by tools between
  * calls.  Names: SSASR_NO_PERSISTENT, SSASR_NO_FUSED_INPUT, SSASR_BPTT_HALVES_OFF, SSASR_BPTT_RESERVE_KB,
  * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
- * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE, SSASR_GEMM_X6, SSASR_GEMM_KCAT, SSASR_WGRAD_FUSED, SSASR_NO_WINDOWS,
+ * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE (0 the launcher's cost model, 64 | 128 tile kernels, 256 the wide stream-K kernel,
+ * 255 the wide kernel on whole tiles), SSASR_GEMM_WIDE (1; 0: the cost model never picks the wide kernel), SSASR_GEMM_X6, SSASR_GEMM_KCAT,
+ * SSASR_GEMM_TRACE_LO / _HI (set_option only: device address of a phase-stamp buffer, tools/gemm_trace.py), SSASR_WGRAD_FUSED, SSASR_NO_WINDOWS,
  * SSASR_LAST_SEG_PCT, SSASR_TAIL_INLINE, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
  * SSASR_TEST_DROP_TILE / SSASR_TEST_DROP_ATTN_SLICE / SSASR_TEST_DROP_DEC_SLICE (fault injection for the
  * time-out tests, one per kernel family, -1 = off).  Unknown name: -1. */
@@ -60,7 +62,9 @@ int ssasr_events_destroy(void* handle);
 
 /* C[b] = act(alpha * op(A[b]) . op(B[b]) + bias) + beta * C[b]; fp32 operands, fp32 accumulation on
  * the matrix cores (products as six bf16 MFMAs on the exact three-way operand split, or the fp32
- * MFMA instruction with SSASR_GEMM_X6=0: the same results to fp32 rounding).
+ * MFMA instruction with SSASR_GEMM_X6=0: the same results to fp32 rounding).  Large products (>= 256 tiles of 256 x 128, 16-byte
+ * aligned operands, K a multiple of 32) run as a stream-K grid whose cut tiles are finished through a workspace the LIBRARY allocates on
+ * first use (4 x 64 MB, kept for the life of the process): the one buffer of this ABI that is not the caller's.
  * ta = 0: A is [M][K] (ld = lda); ta = 1: A is [K][M].
  * tb = 0: B is [N][K] (torch Linear weight layout); tb = 1: B is [K][N].
  * act: 0 none, 1 tanh, 4 relu, 5 leaky relu (slope 0.01), 6 sigmoid.  splitk > 1 adds partial products atomically into a
