@@ -192,7 +192,8 @@ int ssasr_launch_bptt_persistent(const float* whhT, float* gates, const float* c
                                  int64_t ys_n, const int32_t* lens, float* gx, int32_t* sync_ws, int64_t S,
                                  int64_t N, int64_t H, int dirs, hipStream_t st, int64_t i0 = 0, int64_t i1 = 0,
                                  float* dc_state = nullptr, const float* whh_f = nullptr, const float* whh_r = nullptr,
-                                 bool armed = false, const float* tsave = nullptr, void* stop_event = nullptr);
+                                 bool armed = false, const float* tsave = nullptr, void* stop_event = nullptr,
+                                 const void* progress = nullptr);
 // stop_event (a hipEvent_t): recorded by the kernel's OWN completion signal
 // (hipExtLaunchKernel) -- no barrier packet of its own between this launch and the next on the stream
 // Process-wide diagnostic switches (include/ssasr.h, ssasr_set_option): read from the environment
@@ -213,6 +214,7 @@ struct SsasrOptions {
   int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs (0: on v_mfma_f32_16x16x4_f32)
   int gemm_kcat;                  // SSASR_GEMM_KCAT (1): a layer's input gradient as ONE launch over both directions' K segments
   int no_windows;                 // SSASR_NO_WINDOWS: layers wider than 128 columns take one launch per step instead of column windows (A/B)
+  int bptt_one_launch;            // SSASR_BPTT_ONE_LAUNCH (1): a layer's BPTT ranges as ONE launch, the second stream released by progress words (0: one launch per range)
   int wgrad_fused;                // SSASR_WGRAD_FUSED (1): a range's dW_ih, dW_hh and bias gradients as ONE launch, one pass over dG
   int last_seg_pct;               // SSASR_LAST_SEG_PCT (60): length of the LAST recurrence range of a segmented BPTT, in percent of an equal share
   int tail_inline;                // SSASR_TAIL_INLINE (1): the first layer's last range of weight-gradient products on the main stream

@@ -1219,7 +1219,11 @@ __global__ __launch_bounds__(WIDE_NT, 2) void gemm_x6w_kernel(GemmDesc gin, bool
         if (tid == 0) atomicAdd(w + 1, 1u);
       } else {
         if (tid == 0) {
-          while (__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 < (unsigned)parts) __builtin_amdgcn_s_sleep(4);
+          // (bounded: the other parts hold tickets, i.e. they are running and only have a slab to write -- but a wait
+          // inside a kernel gets an exit every wave reaches whatever happens: ~0.5 s of polling, then on with what is there)
+          for (unsigned spins = 0; spins < (1u << 21) &&
+                                   __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 < (unsigned)parts; ++spins)
+            __builtin_amdgcn_s_sleep(4);
         }
         __syncthreads();
         for (int pp = 0; pp + 1 < parts; ++pp) {

@@ -34,6 +34,7 @@ void init_options() {
   g_opt.gemm_trace_lo = g_opt.gemm_trace_hi = 0;
   g_opt.gemm_kcat = env_int("SSASR_GEMM_KCAT", 1);
   g_opt.wgrad_fused = env_int("SSASR_WGRAD_FUSED", 1);
+  g_opt.bptt_one_launch = env_int("SSASR_BPTT_ONE_LAUNCH", 1);
   g_opt.no_windows = env_flag("SSASR_NO_WINDOWS");
   g_opt.last_seg_pct = env_int("SSASR_LAST_SEG_PCT", 60);
   g_opt.tail_inline = env_int("SSASR_TAIL_INLINE", 1);
@@ -63,6 +64,7 @@ const Named kNames[] = {
     {"SSASR_GEMM_WIDE", &SsasrOptions::gemm_wide},
     {"SSASR_GEMM_KCAT", &SsasrOptions::gemm_kcat},
     {"SSASR_WGRAD_FUSED", &SsasrOptions::wgrad_fused},
+    {"SSASR_BPTT_ONE_LAUNCH", &SsasrOptions::bptt_one_launch},
     {"SSASR_NO_WINDOWS", &SsasrOptions::no_windows},
     {"SSASR_LAST_SEG_PCT", &SsasrOptions::last_seg_pct},
     {"SSASR_TAIL_INLINE", &SsasrOptions::tail_inline},

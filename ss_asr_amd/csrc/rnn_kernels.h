@@ -975,6 +975,13 @@ struct EncPersistBwd {
   // or null (then `gates` / `cs` hold them row-major and `gates` is overwritten in place)
   const float* tsave;
   int nt;                // column window of a wider layer, as EncPersist::nt (0: nt = N); dc_state rows follow it
+  // Progress words (ssasr_bilstm_bwd_overlapped, one launch per layer): when the helper wave of a workgroup that
+  // writes gate-derivative rows has stored -- and written back -- the rows of iteration bound[k] - 1, it adds 1 to
+  // progress[k]; the second stream's weight-gradient launches for iterations < bound[k] wait for the word with
+  // hipStreamWaitValue32 instead of for the end of a launch.  nbound = 0: no words.
+  unsigned* progress;
+  int nbound;
+  int bound[7];
 };
 
 // ----------- persistent backward recurrence, K split (reduce-scatter) -----------
@@ -1158,12 +1165,26 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
     const u32x4 fill = {PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL, PERSIST_SENTINEL};
     // the waves read this launch's first coefficients before the first per-step barrier
     __syncthreads();
+    // Progress words (EncPersistBwd::progress).  The rows of a range's last iteration must have left this XCD's L2
+    // before the range's word counts this workgroup (the weight-gradient GEMMs read them on every XCD).  A release
+    // fence would hold this wave -- and with it the workgroup's next barrier -- for the 2-6 us of the write-back, so it
+    // is taken apart over the wait this loop makes anyway: the iteration after the range's last, its stores are acknowledged
+    // (vmcnt(0) below) and the L2 write-back is ISSUED; one iteration later the same wait has covered the write-back and
+    // the word is counted.  Nothing of it is on the step's critical path; the signal comes two steps (~4 us) late.
+    int sig_k = -1, sig_stage = 0;
     for (int i = i0; i < i1; ++i) {
       if (i > 0) {
         if (i > i0) pacer.sleep();
         // the re-arm stores of the previous step must have landed before this
         // workgroup publishes again (see the ring argument above)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (sig_stage == 2) {
+          asm volatile("buffer_wbl2 sc1" ::: "memory");
+          sig_stage = 1;
+        } else if (sig_stage == 1) {
+          if (lane == 0) __hip_atomic_fetch_add(e.progress + sig_k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          sig_stage = 0;
+        }
         __syncthreads();    // operand loads released
       }
       if (col_ok && i + 2 < S) {
@@ -1177,6 +1198,12 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
         float* g0 = gbase + ((int64_t)sr * NT + n) * 4 * H + u0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[i % NG][g][lane]);
+      }
+      if (e.nbound > 0 && half == 0) {
+        // a range of iterations ends here: sig_k / sig_stage carry it to the loop's top (see there)
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+          if (k < e.nbound && i + 1 == e.bound[k]) { sig_k = k; sig_stage = 2; }
       }
       if (i > i0) {
         pacer.update(missed != 0);
@@ -1200,6 +1227,12 @@ __global__ __launch_bounds__(320) void lstm_enc_bwd_rs_kernel(EncPersistBwd e) {
           for (int g = 0; g < 4; ++g) st4(g0 + (int64_t)g * H, sG[(i0 + k) % NG][g][lane]);
         }
       }
+    }
+    if (sig_stage) {               // (a range that ended within the launch's last two iterations: the plain way)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (sig_stage == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(e.progress + sig_k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return;
   }
