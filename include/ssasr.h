@@ -48,15 +48,16 @@ int ssasr_abi_version(void);
  * SSASR_NO_PERSISTENT_DECODER, SSASR_NO_PERSISTENT_DECODER_BWD, SSASR_PERSIST_DELAY_FWD,
  * SSASR_PERSIST_DELAY_BWD, SSASR_GEMM_TILE (0 the launcher's cost model, 64 | 128 tile kernels, 256 the wide stream-K kernel,
  * 255 the wide kernel on whole tiles), SSASR_GEMM_WIDE (1; 0: the cost model never picks the wide kernel), SSASR_GEMM_X6, SSASR_GEMM_KCAT,
- * SSASR_GEMM_TRACE_LO / _HI (set_option only: device address of a phase-stamp buffer, tools/gemm_trace.py), SSASR_WGRAD_FUSED, SSASR_NO_WINDOWS,
+ * SSASR_GEMM_TRACE_LO / _HI (set_option only: device address of a phase-stamp buffer, tools/gemm_trace.py), SSASR_WGRAD_FUSED, SSASR_BPTT_ONE_LAUNCH (1: a layer's BPTT ranges as one launch, the second stream released by in-kernel progress words), SSASR_NO_WINDOWS,
  * SSASR_LAST_SEG_PCT, SSASR_TAIL_INLINE, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
  * SSASR_TEST_DROP_TILE / SSASR_TEST_DROP_ATTN_SLICE / SSASR_TEST_DROP_DEC_SLICE (fault injection for the
  * time-out tests, one per kernel family, -1 = off).  Unknown name: -1. */
 int ssasr_set_option(const char* name, int value);
 int ssasr_get_option(const char* name, int* value);
 
-/* A caller-owned set of events with which ssasr_bilstm_bwd_overlapped orders its second stream
- * behind the first.  One set serves all calls of its owner (one thread at a time). */
+/* A caller-owned set of events (and 64 progress words of device memory, allocated here) with which
+ * ssasr_bilstm_bwd_overlapped orders its second stream behind the first.  One set serves all calls of its
+ * owner (one thread at a time). */
 int ssasr_events_create(void** handle);
 int ssasr_events_destroy(void* handle);
 
@@ -134,10 +135,12 @@ int ssasr_bilstm_bwd(const float* dy, int64_t ys_s, int64_t ys_n, const float* x
 
 /* ssasr_bilstm_bwd with the weight gradients accumulated (+=) into dw_* / db* (db2_*: optional
  * second copy, b_ih and b_hh share theirs) on `side_stream`, overlapped with the recurrence:
- * for layers that take the persistent K-split BPTT, the recurrence runs as `segments` (1..8)
- * launches over consecutive step ranges and each range's weight-gradient products start on
- * side_stream as soon as that launch has been enqueued.  The caller joins side_stream before
- * it reads the gradients.  events: from ssasr_events_create. */
+ * for layers that take the persistent K-split BPTT, the recurrence is cut into `segments` (1..8)
+ * consecutive step ranges and each range's weight-gradient products start on side_stream as soon
+ * as the range is done -- the whole layer is ONE launch that counts its progress into words of the
+ * events object, for which side_stream waits (hipStreamWaitValue32); where the device cannot do that,
+ * or with SSASR_BPTT_ONE_LAUNCH=0, one launch per range with an event behind each.  The caller joins
+ * side_stream before it reads the gradients.  events: from ssasr_events_create. */
 int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_t ys_n, const float* x, int64_t xs_s,
                                 int64_t xs_n, int64_t S, int64_t N, int64_t I, int64_t H,
                                 const int32_t* lens, const float* w_ih_f, const float* w_hh_f,
