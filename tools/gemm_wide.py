@@ -54,6 +54,6 @@ for name, ta, tb, nb, M, N, K, sk in shapes:
                     assert (cur - ref).abs().max().item() <= 1e-3 * ref.abs().max().item(), name
     for tile in TILES:
         us = best[tile]
-        row.append('%s %7.1f us %6.1f TF' % ({0: 'auto', 128: '128', 256: 'wideSK', 255: 'wide'}[tile], us, 2.0 * nb * M * N * K / us / 1e6))
+        row.append('%s %7.1f us %6.1f TF' % ({0: 'auto', 64: '64', 128: '128', 256: 'wideSK', 255: 'wide'}[tile], us, 2.0 * nb * M * N * K / us / 1e6))
     lib.ssasr_set_option(b'SSASR_GEMM_TILE', 0)
     print('%-18s %2d x %5dx%5dx%5d | %s' % (name, nb, M, N, K, ' | '.join(row)), flush=True)
