@@ -53,6 +53,39 @@ def test_gemm_is_exact_fp32_fma_chain():
     assert torch.equal(got.cpu(), b.t())
 
 
+@pytest.mark.parametrize('ta,tb,M,N,K,nb', [(0, 0, 9000, 512, 1024, 2),      # 288 wide tiles on 256 runs: 32 tiles cut in two
+                                            (0, 1, 8192, 1280, 512, 1),     # NN, 320 tiles
+                                            (1, 1, 4608, 1024, 288, 2),     # TT, 288 tiles of 9 K steps
+                                            (0, 0, 5000, 1000, 992, 3)])    # edge tiles in M and N, 480 tiles
+def test_gemm_wide_stream_k_grid_equals_the_tile_kernels(ta, tb, M, N, K, nb):
+    """The wide kernel's stream-K grid (csrc/gemm.hip, gemm_x6w_kernel: equal runs of K steps per CU; a tile cut between two
+    runs goes through a slab and is finished by the part that arrives last) against float64 and against the tile kernels,
+    at shapes whose tile count is not a multiple of the CU count -- with a bias, which the last arriver's epilogue adds once.
+    Then the same product with its parts ADDED atomically (split-K callers: every part an atomic add)."""
+    from ss_asr_amd import _lib, ops
+    lib = _lib.load()
+    a = rnd(nb, K, M, seed=11) if ta else rnd(nb, M, K, seed=11)
+    b = rnd(nb, K, N, seed=12) if tb else rnd(nb, N, K, seed=12)
+    bias = rnd(N, seed=13)
+    want = (a.transpose(1, 2) if ta else a) @ (b if tb else b.transpose(1, 2)) + bias
+    ad, bd, biasd = a.float().to(dev()), b.float().to(dev()), bias.float().to(dev())
+    try:
+        assert lib.ssasr_set_option(b'SSASR_GEMM_TILE', 256) == 0
+        wide = ops.gemm(ad, bd, ta=bool(ta), tb=bool(tb), bias=biasd)
+        again = ops.gemm(ad, bd, ta=bool(ta), tb=bool(tb), bias=biasd)
+        acc = torch.zeros(nb, M, N, device=dev())
+        ops.gemm(ad, bd, ta=bool(ta), tb=bool(tb), out=acc, splitk=4)
+        assert lib.ssasr_set_option(b'SSASR_GEMM_TILE', 128) == 0
+        tiles = ops.gemm(ad, bd, ta=bool(ta), tb=bool(tb), bias=biasd)
+    finally:
+        lib.ssasr_set_option(b'SSASR_GEMM_TILE', 0)
+    tol = 2e-4 * max(1.0, K ** 0.5 / 4)
+    close(wide, want, tol, 'wide stream-K %d%d %dx%dx%d' % (ta, tb, M, N, K))
+    assert torch.equal(wide, again)                       # two parts per cut tile: the sum does not depend on who arrives last
+    close(acc, want - bias, tol, 'wide stream-K, parts added')
+    assert float((wide - tiles).abs().max()) < 1e-4 * float(tiles.abs().max())
+
+
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_on_bf16_pieces_is_as_exact_as_the_fp32_instruction(ta, tb):
     """The fp32 product as six bf16 MFMAs on the exact three-way split of both operands
