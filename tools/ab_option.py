@@ -1,6 +1,6 @@
 """In-process alternating A/B of one library option on the fixed train step: blocks of `n` steps with the option at
 A, then at B, in turn, `rounds` times (one process, one box, one thermal state: what ab_env.sh cannot give).
-python tools/ab_option.py NAME A B [frames] [n] [rounds]"""
+python tools/ab_option.py NAME|env:VAR A B [frames] [n] [rounds]"""
 import os, sys, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,6 +14,14 @@ frames = int(sys.argv[4]) if len(sys.argv) > 4 else 470
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 rounds = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 lib = _lib.load()
+
+
+def set_option(v):
+    """NAME is a library option, or env:VAR for a switch the host code reads per call"""
+    if name.startswith('env:'):
+        os.environ[name[4:]] = str(v)
+    else:
+        assert lib.ssasr_set_option(name.encode(), v) == 0
 dev = torch.device('cuda', 0)
 random.seed(1); np.random.seed(1); torch.manual_seed(1)
 model = ASR(**bench.DIMS).to(dev); model.train()
@@ -26,13 +34,13 @@ x, y, lens = best
 _, ans_len = label_geometry(y)
 x, y = x.to(dev), y.to(dev)
 for v in (A, B):
-    assert lib.ssasr_set_option(name.encode(), v) == 0
+    set_option(v)
     for _ in range(4): stepper(x, y, lens, ans_len)
 torch.cuda.synchronize()
 res = {A: [], B: []}
 for r in range(rounds):
     for v in ((A, B) if r % 2 == 0 else (B, A)):
-        lib.ssasr_set_option(name.encode(), v)
+        set_option(v)
         stepper(x, y, lens, ans_len)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(n): stepper(x, y, lens, ans_len)
