@@ -51,7 +51,13 @@ int ssasr_abi_version(void);
  * SSASR_GEMM_TRACE_LO / _HI (set_option only: device address of a phase-stamp buffer, tools/gemm_trace.py), SSASR_WGRAD_FUSED, SSASR_BPTT_ONE_LAUNCH (1: a layer's BPTT ranges as one launch, the second stream released by in-kernel progress words), SSASR_NO_WINDOWS,
  * SSASR_LAST_SEG_PCT, SSASR_TAIL_INLINE, SSASR_NO_RESIDENCY_CHECK, SSASR_NO_TSAVE, SSASR_ATTN_RPH,
  * SSASR_TEST_DROP_TILE / SSASR_TEST_DROP_ATTN_SLICE / SSASR_TEST_DROP_DEC_SLICE (fault injection for the
- * time-out tests, one per kernel family, -1 = off).  Unknown name: -1. */
+ * time-out tests, one per kernel family, -1 = off).  Unknown name: -1.
+ * The ONE switch that changes results: SSASR_GEMM_BF16 (0; 1 = the products of ssasr_gemm_f32 and of every GEMM the
+ * library launches for the encoder -- input projections, input gradients, weight gradients -- take their operands
+ * ROUNDED to bf16, one MFMA per block instead of six, fp32 accumulation, tile kernels only; tensors stay fp32, the
+ * recurrences, the decode loop, the loss and the optimizer are untouched).  It is the bf16-storage variant of
+ * BASELINE.json configs[1], not the reference's fp32 arithmetic (/root/reference/src/trainer.py:46-53 has no
+ * autocast): 1.06-1.08 x the step rate, |d loss| < 4e-5 over 60 steps (bench.py "bf16_variant"). */
 int ssasr_set_option(const char* name, int value);
 int ssasr_get_option(const char* name, int* value);
 

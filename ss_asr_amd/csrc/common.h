@@ -211,6 +211,7 @@ struct SsasrOptions {
   int gemm_trace_lo, gemm_trace_hi;   // SSASR_GEMM_TRACE_LO / _HI (set_option only): device address of a uint64 buffer that the wide
                                   // GEMM kernel's workgroups stamp their phases into (tools/gemm_trace.py); 0 = off
   int gemm_wide;                  // SSASR_GEMM_WIDE (1): products of >= 256 wide tiles take the 256 x 128 stream-K kernel when its model is cheaper (0: A/B)
+  int gemm_bf16;                  // SSASR_GEMM_BF16 (0): 1 = the GEMM launcher's products take their operands rounded to bf16 (one MFMA per block instead of six, fp32 accumulation): the bf16-storage VARIANT, not the reference's arithmetic
   int gemm_x6;                    // SSASR_GEMM_X6 (1): fp32 products as six bf16 MFMAs (0: on v_mfma_f32_16x16x4_f32)
   int gemm_kcat;                  // SSASR_GEMM_KCAT (1): a layer's input gradient as ONE launch over both directions' K segments
   int no_windows;                 // SSASR_NO_WINDOWS: layers wider than 128 columns take one launch per step instead of column windows (A/B)

@@ -447,18 +447,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g, bool vecA, bo
 // third of the LDS-active cycles; the kernel's time did not change with it -- LDS is not its bound).
 // ---------------------------------------------------------------------------------------------
 constexpr int XROW = BK * 2;                                  // bytes per LDS row of one plane
-template <int BMN> struct XGeom {
+// NP = planes kept: 3 = the exact split (fp32 products), 1 = the first plane only (SSASR_GEMM_BF16: operands rounded
+// to bf16, fp32 accumulation -- the bf16-storage variant of the products, never the default)
+template <int BMN, int NP = 3> struct XGeom {
   static constexpr int PLANE = BMN * XROW;
-  static constexpr int BYTES = 3 * PLANE;
+  static constexpr int BYTES = NP * PLANE;
 };
 
 // four consecutive k of one row -> 8 bytes in each plane
-template <int BMN>
+template <int BMN, int NP = 3>
 __device__ __forceinline__ void x_store4(char* img, int row, int slot, float k0, float k1, float k2, float k3) {
+  char* dst = img + row * XROW + ((slot ^ ((row >> 1) & 6)) * 8);    // chunk (slot >> 1) ^ ((row >> 2) & 3)
+  if constexpr (NP == 1) {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(x6_pack(k0, k1), x6_pack(k2, k3));
+    return;
+  }
   uint32_t a1, a2, a3, b1, b2, b3;
   x_split2(k0, k1, a1, a2, a3);
   x_split2(k2, k3, b1, b2, b3);
-  char* dst = img + row * XROW + ((slot ^ ((row >> 1) & 6)) * 8);    // chunk (slot >> 1) ^ ((row >> 2) & 3)
   *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
   *reinterpret_cast<uint2*>(dst + XGeom<BMN>::PLANE) = make_uint2(a2, b2);
   *reinterpret_cast<uint2*>(dst + 2 * XGeom<BMN>::PLANE) = make_uint2(a3, b3);
@@ -484,7 +490,7 @@ __device__ __forceinline__ int xt_off(int k, int mn) {       // byte offset of (
   return k * (BMN * 2) + ((((mn >> 4) ^ xt_swz<BMN, W32>(k)) << 5) | ((mn & 15) * 2));
 }
 
-template <int BMN, int NT = 256, bool W32 = false>
+template <int BMN, int NT = 256, bool W32 = false, int NP = 3>
 struct XTLoader : TileLoader<BMN, true, NT> {
   static constexpr int NV = TileGeom<BMN, true, NT>::NV;
   static constexpr int PER_ROW = BMN / 4;
@@ -497,10 +503,14 @@ struct XTLoader : TileLoader<BMN, true, NT> {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid_ + i * NT;
+      char* dst = img + xt_off<BMN, W32>(f / PER_ROW, (f % PER_ROW) * 4);
+      if constexpr (NP == 1) {
+        *reinterpret_cast<uint2*>(dst) = make_uint2(x6_pack(v[i].x, v[i].y), x6_pack(v[i].z, v[i].w));
+        continue;
+      }
       uint32_t a1, a2, a3, b1, b2, b3;
       x_split2(v[i].x, v[i].y, a1, a2, a3);
       x_split2(v[i].z, v[i].w, b1, b2, b3);
-      char* dst = img + xt_off<BMN, W32>(f / PER_ROW, (f % PER_ROW) * 4);
       *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
       *reinterpret_cast<uint2*>(dst + XGeom<BMN>::PLANE) = make_uint2(a2, b2);
       *reinterpret_cast<uint2*>(dst + 2 * XGeom<BMN>::PLANE) = make_uint2(a3, b3);
@@ -509,7 +519,7 @@ struct XTLoader : TileLoader<BMN, true, NT> {
 };
 
 // K-contiguous operand: the fp32 kernel's loader, stored through the split
-template <int BMN, int NT = 256>
+template <int BMN, int NT = 256, int NP = 3>
 struct XNLoader : TileLoader<BMN, false, NT> {
   static constexpr int NV = TileGeom<BMN, false, NT>::NV;
   __device__ __forceinline__ void init(const Operand& op, int mn0, int k0, int tid, int) {
@@ -521,13 +531,13 @@ struct XNLoader : TileLoader<BMN, false, NT> {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid_ + i * NT;
-      x_store4<BMN>(img, f / (BK / 4), f % (BK / 4), v[i].x, v[i].y, v[i].z, v[i].w);
+      x_store4<BMN, NP>(img, f / (BK / 4), f % (BK / 4), v[i].x, v[i].y, v[i].z, v[i].w);
     }
   }
 };
 
-template <int BMN, bool T, int NT = 256, bool W32 = false> struct XLoaderOf { using type = XNLoader<BMN, NT>; static constexpr int NV = TileGeom<BMN, false, NT>::NV; };
-template <int BMN, int NT, bool W32> struct XLoaderOf<BMN, true, NT, W32> { using type = XTLoader<BMN, NT, W32>; static constexpr int NV = TileGeom<BMN, true, NT>::NV; };
+template <int BMN, bool T, int NT = 256, bool W32 = false, int NP = 3> struct XLoaderOf { using type = XNLoader<BMN, NT, NP>; static constexpr int NV = TileGeom<BMN, false, NT>::NV; };
+template <int BMN, int NT, bool W32, int NP> struct XLoaderOf<BMN, true, NT, W32, NP> { using type = XTLoader<BMN, NT, W32, NP>; static constexpr int NV = TileGeom<BMN, true, NT>::NV; };
 
 template <int BMN>
 __device__ __forceinline__ bf16x8 x_frag(const char* img, int plane, int row, int q) {
@@ -557,7 +567,7 @@ __device__ __forceinline__ bf16x8 x_operand(const char* img, int plane, int base
 // SEG (GemmDesc::nseg > 0, TA = TB = true): the column tiles of the launch belong to up to two segments, each
 // with its own B / C / K window over shared A rows; the workgroups of the first column tile also sum the
 // columns of the A rows they stream (GemmDesc::colsum).  One launch = one pass over A.
-template <int BM, int BN, bool TA, bool TB, bool TR, bool SEG = false>
+template <int BM, int BN, bool TA, bool TB, bool TR, bool SEG = false, int NP = 3>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc gin, bool vecA, bool vecB) {
   constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
   constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 fragments per wave
@@ -599,8 +609,8 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc gin, bool vecA, b
 
   Operand opA{g.A + (int64_t)bz * g.sa, g.ma, g.M, vecA};
   Operand opB{g.B + (int64_t)bz * g.sb, g.mb, g.N, vecB};
-  typename XLoaderOf<BM, TA>::type la;
-  typename XLoaderOf<BN, TB>::type lb;
+  typename XLoaderOf<BM, TA, 256, false, NP>::type la;
+  typename XLoaderOf<BN, TB, 256, false, NP>::type lb;
   la.init(opA, m0, kbeg, tid, 0);
   lb.init(opB, n0, kbeg, tid, 128);
   const bool interior = vecA && vecB && (!TA || g.M % 4 == 0) && (!TB || g.N % 4 == 0);
@@ -625,7 +635,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc gin, bool vecA, b
     if (interior && kbeg + BK <= kend) { la.load_fast(ra); lb.load_fast(rb); }
     else { la.load_guarded(ra, kbeg, kend, vecA); lb.load_guarded(rb, kbeg, kend, vecB); }
     la.store(xlds, ra);
-    lb.store(xlds + XGeom<BM>::BYTES, rb);
+    lb.store(xlds + XGeom<BM, NP>::BYTES, rb);
     if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
   }
   __syncthreads();
@@ -646,10 +656,10 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc gin, bool vecA, b
       else { la.load_guarded(ra, k0 + BK, kend, vecA); lb.load_guarded(rb, k0 + BK, kend, vecB); }
     }
     const char* curA = xlds;
-    const char* curB = curA + XGeom<BM>::BYTES;
-    bf16x8 fa[3][TM], fb[3][TN];
+    const char* curB = curA + XGeom<BM, NP>::BYTES;
+    bf16x8 fa[NP][TM], fb[NP][TN];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[p][i] = x_operand<BM, TA>(curA, p, wm * WM + i * 16, r, q);
 #pragma unroll
@@ -661,16 +671,20 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmDesc gin, bool vecA, b
   _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
     acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PB][j], fa[PA][i], acc[i][j], 0, 0, 0)  \
                    : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA][i], fb[PB][j], acc[i][j], 0, 0, 0)
-    SSASR_X6_STEP(2, 0);      // smallest terms first
-    SSASR_X6_STEP(0, 2);
-    SSASR_X6_STEP(1, 1);
+    if constexpr (NP == 3) {
+      SSASR_X6_STEP(2, 0);      // smallest terms first
+      SSASR_X6_STEP(0, 2);
+      SSASR_X6_STEP(1, 1);
+    }
     if (more) {
       la.store(xlds, ra);
-      lb.store(xlds + XGeom<BM>::BYTES, rb);
+      lb.store(xlds + XGeom<BM, NP>::BYTES, rb);
       if constexpr (SEG) { if (do_colsum) colsum_add(ra); }
     }
-    SSASR_X6_STEP(1, 0);
-    SSASR_X6_STEP(0, 1);
+    if constexpr (NP == 3) {
+      SSASR_X6_STEP(1, 0);
+      SSASR_X6_STEP(0, 1);
+    }
     SSASR_X6_STEP(0, 0);
 #undef SSASR_X6_STEP
     __syncthreads();          // the next tile is in place
@@ -1288,18 +1302,14 @@ bool map_vec_ok(const RowMap& m) {
   return m.inner ? (m.so % 4 == 0 && m.si % 4 == 0) : (m.ld % 4 == 0);
 }
 
-template <int BM, int BN>
-int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
-  GemmDesc g = gin;
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * g.splitk);
+// the split-bf16 tile kernel with NP planes per operand (3: fp32 products; 1: SSASR_GEMM_BF16)
+template <int BM, int BN, int NP>
+int launch_x6_tiles(const GemmDesc& g, bool vecA, bool vecB, hipStream_t st, dim3 grid) {
   dim3 block(256);
-  // split-K launches add their partial products atomically: one float per lane in rows of 16
-  // consecutive columns (TR = false); everything else stores 16 bytes per lane (TR = true)
-  if (ssasr_options().gemm_x6) {
-    constexpr size_t lds = XGeom<BM>::BYTES + XGeom<BN>::BYTES;
-#define SSASR_X6_LAUNCH(A_, B_, R_)                                                                         \
+  constexpr size_t lds = XGeom<BM, NP>::BYTES + XGeom<BN, NP>::BYTES;
+#define SSASR_X6_LAUNCH(A_, B_, R_, S_)                                                                     \
   do {                                                                                                      \
-    auto fn = gemm_x6_kernel<BM, BN, A_, B_, R_>;                                                           \
+    auto fn = gemm_x6_kernel<BM, BN, A_, B_, R_, S_, NP>;                                                   \
     static bool once = false;                                                                               \
     if (!once) {                                                                                            \
       SSASR_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -1307,33 +1317,36 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
     }                                                                                                       \
     hipLaunchKernelGGL(fn, grid, block, lds, st, g, vecA, vecB);                                            \
   } while (0)
+  // split-K launches add their partial products atomically: one float per lane in rows of 16
+  // consecutive columns (TR = false); everything else stores 16 bytes per lane (TR = true)
 #define SSASR_X6_PICK(A_, B_)                                                                               \
   do {                                                                                                      \
-    if (g.splitk > 1) SSASR_X6_LAUNCH(A_, B_, false);                                                       \
-    else SSASR_X6_LAUNCH(A_, B_, true);                                                                     \
+    if (g.splitk > 1) SSASR_X6_LAUNCH(A_, B_, false, false);                                                \
+    else SSASR_X6_LAUNCH(A_, B_, true, false);                                                              \
   } while (0)
-    if (g.nseg > 0) {                 // column segments (validated by ssasr_launch_gemm): partial products are
-      int nt = 0;                     // always ADDED (atomics): several K slices and earlier ranges meet in C
-      for (int k = 0; k < g.nseg; ++k) nt += (g.seg[k].N + BN - 1) / BN;
-      grid.x = (unsigned)nt;
-      auto fn = gemm_x6_kernel<BM, BN, true, true, false, true>;
-      static bool once_seg = false;
-      if (!once_seg) {
-        SSASR_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        once_seg = true;
-      }
-      hipLaunchKernelGGL(fn, grid, block, lds, st, g, vecA, vecB);
-      SSASR_LAUNCH_CHECK();
-      return SSASR_OK;
-    }
-    if (!g.ta && !g.tb) SSASR_X6_PICK(false, false);
-    else if (!g.ta && g.tb) SSASR_X6_PICK(false, true);
-    else if (g.ta && !g.tb) SSASR_X6_PICK(true, false);
-    else SSASR_X6_PICK(true, true);
+  if (g.nseg > 0) {                 // column segments (validated by ssasr_launch_gemm): partial products are
+    int nt = 0;                     // always ADDED (atomics): several K slices and earlier ranges meet in C
+    for (int k = 0; k < g.nseg; ++k) nt += (g.seg[k].N + BN - 1) / BN;
+    grid.x = (unsigned)nt;
+    SSASR_X6_LAUNCH(true, true, false, true);
+  } else if (!g.ta && !g.tb) SSASR_X6_PICK(false, false);
+  else if (!g.ta && g.tb) SSASR_X6_PICK(false, true);
+  else if (g.ta && !g.tb) SSASR_X6_PICK(true, false);
+  else SSASR_X6_PICK(true, true);
 #undef SSASR_X6_PICK
 #undef SSASR_X6_LAUNCH
-    SSASR_LAUNCH_CHECK();
-    return SSASR_OK;
+  SSASR_LAUNCH_CHECK();
+  return SSASR_OK;
+}
+
+template <int BM, int BN>
+int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
+  GemmDesc g = gin;
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * g.splitk);
+  dim3 block(256);
+  if (ssasr_options().gemm_x6) {
+    if (ssasr_options().gemm_bf16) return launch_x6_tiles<BM, BN, 1>(g, vecA, vecB, st, grid);
+    return launch_x6_tiles<BM, BN, 3>(g, vecA, vecB, st, grid);
   }
 #define SSASR_GEMM_LAUNCH(A_, B_)                                                                           \
   do {                                                                                                      \
@@ -1353,6 +1366,7 @@ int launch_tiles(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st) {
 // that advance without a loop.
 static bool flat_map(const RowMap& m) { return m.inner == 0 || m.inner >= BK; }
 static bool wide_eligible(const GemmDesc& g, bool vecA, bool vecB) {
+  if (ssasr_options().gemm_bf16) return false;       // the one-plane variant exists as tile kernels only
   if (!vecA || !vecB || (g.ta && g.M % 4) || (g.ta && !flat_map(g.ma))) return false;
   if (g.nseg > 0) {
     for (int k = 0; k < g.nseg; ++k)

@@ -31,6 +31,7 @@ void init_options() {
   g_opt.gemm_tile = env_int("SSASR_GEMM_TILE", 0);
   g_opt.gemm_x6 = env_int("SSASR_GEMM_X6", 1);
   g_opt.gemm_wide = env_int("SSASR_GEMM_WIDE", 1);
+  g_opt.gemm_bf16 = env_int("SSASR_GEMM_BF16", 0);
   g_opt.gemm_trace_lo = g_opt.gemm_trace_hi = 0;
   g_opt.gemm_kcat = env_int("SSASR_GEMM_KCAT", 1);
   g_opt.wgrad_fused = env_int("SSASR_WGRAD_FUSED", 1);
@@ -62,6 +63,7 @@ const Named kNames[] = {
     {"SSASR_GEMM_TRACE_HI", &SsasrOptions::gemm_trace_hi},
     {"SSASR_GEMM_X6", &SsasrOptions::gemm_x6},
     {"SSASR_GEMM_WIDE", &SsasrOptions::gemm_wide},
+    {"SSASR_GEMM_BF16", &SsasrOptions::gemm_bf16},
     {"SSASR_GEMM_KCAT", &SsasrOptions::gemm_kcat},
     {"SSASR_WGRAD_FUSED", &SsasrOptions::wgrad_fused},
     {"SSASR_BPTT_ONE_LAUNCH", &SsasrOptions::bptt_one_launch},

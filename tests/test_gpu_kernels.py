@@ -87,6 +87,44 @@ def test_gemm_wide_stream_k_grid_equals_the_tile_kernels(ta, tb, M, N, K, nb):
 
 
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('tile', [64, 128])
+def test_gemm_bf16_variant_is_the_product_of_the_rounded_operands(ta, tb, tile):
+    """SSASR_GEMM_BF16=1 (csrc/gemm.hip, the tile kernels with ONE plane per operand): the result is the fp32-accumulated
+    product of the operands rounded to bf16 (round to nearest even) -- checked against float64 on the rounded operands at
+    the fp32 kernels' tolerance, with edge tiles in M and N, a K that is not a multiple of the K step, a bias, and the
+    split-K form (parts added atomically).  The default stays the exact three-plane split (the test below)."""
+    from ss_asr_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K, nb = 333, 200, 1000, 2
+    a = rnd(nb, K, M, seed=21) if ta else rnd(nb, M, K, seed=21)
+    b = rnd(nb, K, N, seed=22) if tb else rnd(nb, N, K, seed=22)
+    bias = rnd(N, seed=23)
+    ar, br = a.float().bfloat16().double(), b.float().bfloat16().double()
+    want = (ar.transpose(1, 2) if ta else ar) @ (br if tb else br.transpose(1, 2))
+    ad, bd, biasd = a.float().to(dev()), b.float().to(dev()), bias.float().to(dev())
+    try:
+        assert lib.ssasr_set_option(b'SSASR_GEMM_BF16', 1) == 0
+        assert lib.ssasr_set_option(b'SSASR_GEMM_TILE', tile) == 0
+        got = ops.gemm(ad, bd, ta=bool(ta), tb=bool(tb), bias=biasd)
+        acc = torch.zeros(nb, M, N, device=dev())
+        ops.gemm(ad, bd, ta=bool(ta), tb=bool(tb), out=acc, splitk=3)
+        assert lib.ssasr_set_option(b'SSASR_GEMM_BF16', 0) == 0
+        exact = ops.gemm(ad, bd, ta=bool(ta), tb=bool(tb), bias=biasd)
+    finally:
+        lib.ssasr_set_option(b'SSASR_GEMM_BF16', 0)
+        lib.ssasr_set_option(b'SSASR_GEMM_TILE', 0)
+    def worst(x, y):
+        return float((x.double().cpu() - y).abs().max())
+    # |products| ~ 1, sums ~ 30: fp32 accumulation lands within ~1e-4 of float64; the operands' rounding moves the
+    # result by ~0.1 -- a variant that kept more (or less) than the rounded operands would not pass both bounds
+    assert worst(got, want + bias) < 2e-3, 'bf16 variant %d%d tile %d' % (ta, tb, tile)
+    assert worst(acc, want) < 2e-3, 'bf16 variant, split-K'
+    full = (a.transpose(1, 2) if ta else a) @ (b if tb else b.transpose(1, 2)) + bias
+    assert worst(exact, full) < 2e-3, 'default after the switch is cleared'
+    assert worst(got, full) > 2e-2
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_on_bf16_pieces_is_as_exact_as_the_fp32_instruction(ta, tb):
     """The fp32 product as six bf16 MFMAs on the exact three-way split of both operands
     (csrc/gemm.hip, SSASR_GEMM_X6) against the same product on v_mfma_f32_16x16x4_f32, both

@@ -91,6 +91,34 @@ def test_forward_matches_reference(golden, name):
         assert abs(acc - float(fx['acc'])) < 1e-3
 
 
+@pytest.mark.parametrize('name', ['full_b16_t400'] + BENCH_SHAPES)
+def test_bf16_operand_variant_stays_within_the_stated_loss_tolerance(golden, name):
+    """SSASR_GEMM_BF16=1 (the bf16-storage VARIANT of BASELINE.json configs[1]: the launcher's GEMM operands
+    rounded to bf16, fp32 accumulation; recurrences, attention, decoder and loss unchanged) against the
+    REFERENCE's fp32 loss and accuracy on the same inputs: north_star's "loss/CER within 1e-3".  Not the
+    default, never the headline; the default path's tolerance (1e-4) is test_forward_matches_reference's."""
+    from ss_asr_amd import _lib
+    from ss_asr_amd.postprocess import calc_acc
+    fx = golden(name)
+    model = build(fx)
+    lib = _lib.load()
+    assert lib.ssasr_set_option(b'SSASR_GEMM_BF16', 1) == 0
+    try:
+        enc_len, logits, att, loss = forward(fx, model)
+    finally:
+        assert lib.ssasr_set_option(b'SSASR_GEMM_BF16', 0) == 0
+    d_loss = abs(float(loss) - float(fx['loss']))
+    d_logit = float(np.abs(logits.detach().cpu().numpy() - fx['logits']).max())
+    print('bf16 variant %s: |d loss| %.2e, max |d logit| %.2e' % (name, d_loss, d_logit))
+    assert enc_len == [int(v) for v in fx['enc_len']]
+    assert d_loss < 1e-3
+    assert d_logit > 1e-6            # (the variant really ran: fp32 products land within 5e-5)
+    if 'acc' in fx.files:
+        ans_len = int(fx['ans_len'])
+        label = torch.from_numpy(fx['y'])[:, 1:ans_len + 1]
+        assert abs(calc_acc(logits[:, :ans_len], label) - float(fx['acc'])) < 1e-3
+
+
 @pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'full_b4',
                                   'full_b16_t400'] + BENCH_SHAPES + LONG_SHAPES)
 def test_backward_and_solver_step_match_reference(golden, name):
