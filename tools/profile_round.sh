@@ -11,7 +11,7 @@ set -x
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_h $R/gpurun_out/prof_r
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_h -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-config4 --no-epoch > $R/gpurun_out/prof_h.log 2>&1 &&
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_h -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-config4 --no-epoch --no-bf16-variant > $R/gpurun_out/prof_h.log 2>&1 &&
 SSASR_ROOFLINE_REPS=5 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r -- python3 $R/tools/pmc_layer.py > $R/gpurun_out/prof_r.log 2>&1 &&
 cd /tmp && rm -rf $R/gpurun_out/pmc_f $R/gpurun_out/pmc_w &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_f -- python3 $R/tools/pmc_layer.py > $R/gpurun_out/pmc_f.log 2>&1 &&
