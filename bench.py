@@ -625,22 +625,27 @@ def cpu_baseline(batches, warm):
     note('cpu baseline: warm-up %d x %d frames in %.1f s (untimed)' % (warm[0].shape[0], warm[0].shape[1], warm_s))
     utts, secs, losses = 0, [], []
     for x, y, _ in batches:
-        # two steps per batch, the faster one counts: a host step is sometimes several times slower than the same step a
-        # moment later (483 frames: 12.9 s, then 1.3 s; cgroup CPU share, thread placement), and a baseline should not
-        # be made of the slow ones
+        # two steps per batch (a third when they disagree by more than half), the fastest counts: a host step is sometimes
+        # ten times slower than the same step a moment later (483 frames: 12.9 s, then 1.3 s -- and in another run 1.3, then
+        # 11.9 and 12.4; the box's CPU share, not the arithmetic: flushing denormals changes nothing), and a baseline
+        # should not be made of the slow ones
         both = []
-        for _ in range(2):
+        for k in range(3):
+            if k == 2 and max(both) < 1.5 * min(both):
+                break                       # the two passes agree: no third one
             t0 = time.perf_counter()
             loss, _ = lo.train_step(model, optim, x.cpu(), y.cpu())
             both.append(time.perf_counter() - t0)
+        if x is warm[0]:
+            both.append(warm_s)             # (the warm-up ran this very batch: when even it was faster, it is the step's time)
         secs.append(min(both))
         losses.append(loss)
         utts += x.shape[0]
-        note('cpu baseline: %d x %d frames in %.1f s (the other pass: %.1f s)' % (x.shape[0], x.shape[1], secs[-1], max(both)))
+        note('cpu baseline: %d x %d frames in %.1f s (all passes: %s s)' % (x.shape[0], x.shape[1], secs[-1], ' '.join('%.1f' % v for v in both)))
     frames = [int(b[0].shape[1]) for b in batches]
     padded = sum(int(b[0].shape[0]) * int(b[0].shape[1]) for b in batches)
     return dict(value=round(utts / sum(secs), 4), unit='utterances/sec', cores=cores, kind='port', warmup=1,
-                sample='1 untimed warm-up step (%d frames) + %d timed train steps (each run twice, the faster pass counted; optimizer state carried over) on every '
+                sample='1 untimed warm-up step (%d frames) + %d timed train steps (each run twice, a third time when the two differ by more than half, the fastest pass counted -- the warm-up pass included for its own batch; optimizer state carried over) on every '
                        'second bucket of the timed region\'s eight-bucket rotation: %d utterances each, %s frames max '
                        '(mean %.0f; the GPU region\'s rotation: %s), fp32, torch %s'
                        % (warm[0].shape[1], len(batches), batches[0][0].shape[0], '/'.join(str(f) for f in frames),
