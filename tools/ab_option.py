@@ -1,6 +1,6 @@
 """In-process alternating A/B of one library option on the fixed train step: blocks of `n` steps with the option at
 A, then at B, in turn, `rounds` times (one process, one box, one thermal state: what ab_env.sh cannot give).
-python tools/ab_option.py NAME|env:VAR A B [frames] [n] [rounds]"""
+python tools/ab_option.py NAME|env:VAR|ops:ATTR A B [frames] [n] [rounds]"""
 import os, sys, random, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,6 +20,10 @@ def set_option(v):
     """NAME is a library option, or env:VAR for a switch the host code reads per call"""
     if name.startswith('env:'):
         os.environ[name[4:]] = str(v)
+    elif name.startswith('ops:'):           # a module-level setting of ss_asr_amd.ops (e.g. ops:bptt_segments)
+        from ss_asr_amd import ops
+        assert hasattr(ops, name[4:])
+        setattr(ops, name[4:], v)
     else:
         assert lib.ssasr_set_option(name.encode(), v) == 0
 dev = torch.device('cuda', 0)
