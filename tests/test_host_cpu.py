@@ -449,3 +449,28 @@ def test_discriminator_and_speech_autoencoder_state_dicts_are_the_references():
         assert all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)
         mine.load_state_dict(b)                      # and back
         ref.load_state_dict(mine.state_dict())
+
+
+def test_settle_collector_freezes_once_and_honours_its_switch(monkeypatch):
+    """engine.settle_collector (called by every step object after the first train step): moves what is alive to the
+    collector's permanent generation once per process; `again` repeats it; SSASR_GC_FREEZE=0 leaves the collector alone."""
+    import gc
+    from ss_asr_amd import engine
+    gc.unfreeze()
+    monkeypatch.setattr(engine, '_settled', False)
+    monkeypatch.setenv('SSASR_GC_FREEZE', '0')
+    engine.settle_collector()
+    assert gc.get_freeze_count() == 0 and engine._settled is False
+    monkeypatch.delenv('SSASR_GC_FREEZE')
+    try:
+        engine.settle_collector()
+        n = gc.get_freeze_count()
+        assert n > 1000 and engine._settled is True
+        keep = [[i] for i in range(5000)]            # made after the freeze: tracked, not frozen
+        engine.settle_collector()                    # a second call is a no-op ...
+        assert gc.get_freeze_count() == n
+        engine.settle_collector(again=True)          # ... unless asked for
+        assert gc.get_freeze_count() >= n + 5000
+        del keep
+    finally:
+        gc.unfreeze()
