@@ -71,7 +71,9 @@ int ssasr_events_destroy(void* handle);
  * the matrix cores (products as six bf16 MFMAs on the exact three-way operand split, or the fp32
  * MFMA instruction with SSASR_GEMM_X6=0: the same results to fp32 rounding).  Large products (>= 256 tiles of 256 x 128, 16-byte
  * aligned operands, K a multiple of 32) run as a stream-K grid whose cut tiles are finished through a workspace the LIBRARY allocates on
- * first use (4 x 64 MB, kept for the life of the process): the one buffer of this ABI that is not the caller's.
+ * first use (4 x 64 MB, kept for the life of the process): the one buffer of this ABI that is not the caller's.  Each quarter belongs to the
+ * first stream that launches such a product (launches of one stream follow each other; different streams never share a quarter); a fifth
+ * stream's products take the tile kernels.  Same results either way.
  * ta = 0: A is [M][K] (ld = lda); ta = 1: A is [K][M].
  * tb = 0: B is [N][K] (torch Linear weight layout); tb = 1: B is [K][N].
  * act: 0 none, 1 tanh, 4 relu, 5 leaky relu (slope 0.01), 6 sigmoid.  splitk > 1 adds partial products atomically into a

@@ -17,6 +17,7 @@
 // both operands, which lets a K-contiguous operand be fetched with a single
 // ds_read_b128 per 16x16 fragment.
 #include <atomic>
+#include <mutex>
 #include <cstdlib>
 #include "../../include/ssasr.h"
 #include "common.h"
@@ -913,6 +914,7 @@ struct WidePlan {
 };
 
 constexpr int SK_REGIONS = 4, SK_MAX_G = 512, SK_SLABS = 2;
+constexpr int WIDE_NO_REGION = -1000;      // launch_wide: no workspace region left for this stream (internal: the launcher falls back)
 constexpr size_t SK_SLAB_FLOATS = (size_t)WIDE_NT * 64;
 typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 
@@ -1422,13 +1424,25 @@ int launch_wide(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st, bool 
   if (G > 0x7fffffffll) return SSASR_EARG;
   p.G = (int)G;
   p.per = p.units / p.G; p.rem = p.units % p.G;
-  // Workspace of the cut tiles (tickets + slabs), allocated once per process on first use: SK_REGIONS regions taken in
-  // turn, so that launches in flight on different streams never share one (the one allocation this library makes).
-  static std::atomic<unsigned> region{0};
+  // Workspace of the cut tiles (tickets + slabs), allocated once per process on first use (the one allocation this
+  // library makes): SK_REGIONS regions, each OWNED by the first stream that asks -- launches of one stream follow each
+  // other, so they can share a region; launches of different streams may be in flight together and never do.  A fifth
+  // stream gets none (WIDE_NO_REGION): the caller takes the tile kernels.
+  static std::mutex sk_mu;
+  static hipStream_t sk_owner[SK_REGIONS];
+  static int sk_owners = 0;
   static unsigned* ws_base = nullptr;
   static float* slab_base = nullptr;
   if (!p.acc && G != tiles) {
     if (g.splitk > 1 || parts_bound(p.units, G, p.ksteps) > SK_SLABS + 1) return SSASR_EARG;
+    std::lock_guard<std::mutex> lock(sk_mu);
+    int r = -1;
+    for (int k = 0; k < sk_owners; ++k)
+      if (sk_owner[k] == st) r = k;
+    if (r < 0) {
+      if (sk_owners == SK_REGIONS) return WIDE_NO_REGION;
+      r = sk_owners;
+    }
     if (!ws_base) {
       unsigned* w = nullptr;
       float* sl = nullptr;
@@ -1438,7 +1452,7 @@ int launch_wide(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st, bool 
       slab_base = sl;
       ws_base = w;
     }
-    const unsigned r = region.fetch_add(1) % SK_REGIONS;
+    if (r == sk_owners) sk_owner[sk_owners++] = st;
     p.ws = ws_base + (size_t)r * SK_MAX_G * 2;
     p.slabs = slab_base + (size_t)r * SK_MAX_G * SK_SLABS * SK_SLAB_FLOATS;
   }
@@ -1534,9 +1548,15 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.batch * g.splitk;
   if (g.tile == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
   if (g.tile == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
-  if (g.tile == 256 && ssasr_options().gemm_x6 && wide_eligible(g, vecA, vecB)) return launch_wide(g, vecA, vecB, st, true);
+  if (g.tile == 256 && ssasr_options().gemm_x6 && wide_eligible(g, vecA, vecB)) {
+    const int rc = launch_wide(g, vecA, vecB, st, true);
+    if (rc != WIDE_NO_REGION) return rc;
+  }
   if (const int forced = ssasr_options().gemm_tile) {       // diagnostic: force a tile shape
-    if (forced == 256 && ssasr_options().gemm_x6 && wide_eligible(g, vecA, vecB)) return launch_wide(g, vecA, vecB, st, true);     // wide, stream-K
+    if (forced == 256 && ssasr_options().gemm_x6 && wide_eligible(g, vecA, vecB)) {                                                // wide, stream-K
+      const int rc = launch_wide(g, vecA, vecB, st, true);
+      if (rc != WIDE_NO_REGION) return rc;
+    }
     if (forced == 255 && ssasr_options().gemm_x6 && wide_eligible(g, vecA, vecB)) return launch_wide(g, vecA, vecB, st, false);    // wide, classic grid
     if (forced == 128) return launch_tiles<128, 128>(g, vecA, vecB, st);
     if (forced == 64) return launch_tiles<64, 64>(g, vecA, vecB, st);
@@ -1576,7 +1596,10 @@ int ssasr_launch_gemm(const GemmDesc& gin, hipStream_t st) {
         const double per = (double)wide * ksteps / (double)cus;
         const double twide = 2.4 * per + 16.0 * (per / ksteps + 1.0);
         const double scale = (double)ktot / 1024.0;
-        if (twide < 0.92 * scale * (t64 < t128 ? t64 : t128)) return launch_wide(g, vecA, vecB, st, true);
+        if (twide < 0.92 * scale * (t64 < t128 ? t64 : t128)) {
+          const int rc = launch_wide(g, vecA, vecB, st, true);
+          if (rc != WIDE_NO_REGION) return rc;
+        }
       }
     }
     if (t64 < t128) return launch_tiles<64, 64>(g, vecA, vecB, st);

@@ -86,6 +86,34 @@ def test_gemm_wide_stream_k_grid_equals_the_tile_kernels(ta, tb, M, N, K, nb):
     assert float((wide - tiles).abs().max()) < 1e-4 * float(tiles.abs().max())
 
 
+def test_gemm_stream_k_launches_on_several_streams_do_not_share_a_workspace():
+    """The stream-K grid's tickets and slabs (csrc/gemm.hip, launch_wide) belong to the stream that first asked for
+    them: products in flight on six streams at once -- two more than there are regions, so the last two take the
+    tile kernels -- each give their own result, twice over."""
+    from ss_asr_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K, nb = 9000, 512, 1024, 2                      # 288 wide tiles on 256 runs: 32 tiles cut in two
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    ops_in = [(rnd(nb, M, K, seed=40 + i).float().to(dev()), rnd(nb, N, K, seed=60 + i).float().to(dev())) for i in range(6)]
+    torch.cuda.synchronize()
+    try:
+        assert lib.ssasr_set_option(b'SSASR_GEMM_TILE', 256) == 0
+        outs = []
+        for rep in range(2):
+            for s, (a, b) in zip(streams, ops_in):
+                with torch.cuda.stream(s):
+                    outs.append(ops.gemm(a, b, ta=False, tb=False))
+        torch.cuda.synchronize()
+        assert lib.ssasr_set_option(b'SSASR_GEMM_TILE', 128) == 0
+        for i, (a, b) in enumerate(ops_in):
+            want = ops.gemm(a, b, ta=False, tb=False)
+            for rep in range(2):
+                got = outs[rep * 6 + i]
+                assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max()), (i, rep)
+    finally:
+        lib.ssasr_set_option(b'SSASR_GEMM_TILE', 0)
+
+
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('tile', [64, 128])
 def test_gemm_bf16_variant_is_the_product_of_the_rounded_operands(ta, tb, tile):
