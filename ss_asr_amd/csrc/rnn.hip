@@ -865,7 +865,10 @@ extern "C" int ssasr_bilstm_bwd_overlapped(const float* dy, int64_t ys_s, int64_
     done[nseg - 1] = evs->ev[nseg - 1];
     rc = ssasr_launch_bptt_persistent(nullptr, gates, cs, dy, ys_s, ys_n, lens, gx, sync_ws, S, N, H, 2, st, 0, S,
                                       ws_dc, w_hh_f, w_hh_r, armed, tsave, done[nseg - 1], &prog);
-    if (rc) return rc;
+    if (rc) {                   // nothing was launched: nothing will count into the words
+      for (int k = 0; k + 1 < nseg; ++k) evs->expected[base + k] -= signals;
+      return rc;
+    }
   } else {
     for (int k = 0; k < nseg; ++k) {
       const int64_t i0 = bound[k], i1 = bound[k + 1];
