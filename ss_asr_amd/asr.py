@@ -9,6 +9,7 @@ the reference, so checkpoints and seeded initialisations interchange.  Their
 ``forward`` is never called; all arithmetic goes through ``ss_asr_amd.ops``.
 """
 import math
+import os
 import random
 
 import torch
@@ -80,8 +81,12 @@ class pBLSTM(nn.Module):
         """[B, T, F] -> [B, T//2, 2F]; an odd last frame is dropped (src/asr.py:429-450)."""
         t_dim, f_dim = x.shape[1], x.shape[2]
         if t_dim % 2 != 0:
+            # a view, not a copy: pairs of frames merge into rows of 2F floats whatever the utterance stride is, and
+            # the next layer's kernels take strides (ops._BiLSTM.forward)
             x = x[:, :t_dim - 1, :]
             t_dim -= 1
+            if x.stride(2) == 1 and x.stride(1) == f_dim and os.environ.get('SSASR_DOWNSAMPLE_COPY') != '1':
+                return x.view([x.shape[0], int(t_dim / 2), f_dim * 2])
         return x.contiguous().view([-1, int(t_dim / 2), f_dim * 2])
 
 

@@ -281,13 +281,19 @@ class _BiLSTM(torch.autograd.Function):
         _need_gpu(x, *w)
         ctx.sinks = sinks
         ctx.slots = slots
-        x = _f32c(x)
+        # a batch-first input may come with its own frame / utterance strides (pBLSTM.downsample's view of an
+        # odd-length layer output: rows of 2F floats, utterances T * F apart): the kernels take strides, no copy
+        strided = (batch_first and x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1 and
+                   x.stride(1) % 4 == 0 and x.stride(0) % 4 == 0 and x.stride(1) >= x.shape[2] and
+                   x.stride(0) >= x.shape[1] * x.stride(1) and x.data_ptr() % 16 == 0)
+        if not strided:
+            x = _f32c(x)
         w = [_f32c(t) for t in w]
         H = w[1].shape[1]
         I = x.shape[2]
         if batch_first:
             N, S = x.shape[0], int(steps)
-            xs_s, xs_n = I, x.shape[1] * I
+            xs_s, xs_n = x.stride(1), x.stride(0)
             y = torch.empty(N, S, 2 * H, device=x.device, dtype=torch.float32)
             ys_s, ys_n = 2 * H, S * 2 * H
         else:
@@ -337,7 +343,8 @@ class _BiLSTM(torch.autograd.Function):
         if need_dx:
             # frames past `steps` of a batch-first input get no gradient
             full = (not batch_first) or x.shape[1] == S
-            dx = (torch.empty_like if full else torch.zeros_like)(x)
+            dx = (torch.empty if full else torch.zeros)(x.shape, device=dev, dtype=torch.float32)     # (contiguous whatever x's strides)
+        dxs_s, dxs_n = (I, x.shape[1] * I) if batch_first else (N * I, I)
         sinks = ctx.sinks
         if sinks is None:
             dw = [torch.empty_like(w[0]), torch.empty_like(w[1]), torch.empty(4 * H, device=dev),
@@ -367,7 +374,7 @@ class _BiLSTM(torch.autograd.Function):
             side = side_stream()
             check(lib.ssasr_bilstm_bwd_overlapped(
                 _p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens), _p(w[0]), _p(w[1]), _p(w[4]),
-                _p(w[5]), _p(gates), _p(cs), _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in sinks], _p(ws_t),
+                _p(w[5]), _p(gates), _p(cs), _p(hs), _p(dx), dxs_s, dxs_n, *[_p(t) for t in sinks], _p(ws_t),
                 _p(ws_dc), _p(gx), _p(sync), int(armed), _p(tsave), segments, _overlap_events(), _stream(),
                 C.c_void_p(side.cuda_stream)), 'ssasr_bilstm_bwd_overlapped')
             for t in (gates, x, hs):
@@ -376,7 +383,7 @@ class _BiLSTM(torch.autograd.Function):
             return (dx,) + (None,) * 13
         check(lib.ssasr_bilstm_bwd(_p(dy), ys_s, ys_n, _p(x), xs_s, xs_n, S, N, I, H, _p(lens),
                                    _p(w[0]), _p(w[1]), _p(w[4]), _p(w[5]), _p(gates), _p(cs),
-                                   _p(hs), _p(dx), xs_s, xs_n, *[_p(t) for t in dw], _p(ws_t),
+                                   _p(hs), _p(dx), dxs_s, dxs_n, *[_p(t) for t in dw], _p(ws_t),
                                    _p(ws_dc), _p(gx), _p(sync), int(armed), _p(tsave), _stream()), 'ssasr_bilstm_bwd')
         # inputs: x, lens, steps, batch_first, sinks, slots, then w_ih,w_hh,b_ih,b_hh per direction
         return (dx, None, None, None, None, None, dw[0], dw[1], dw[2], dw[2].clone(),
