@@ -281,9 +281,9 @@ class _BiLSTM(torch.autograd.Function):
         _need_gpu(x, *w)
         ctx.sinks = sinks
         ctx.slots = slots
-        # a batch-first input may come with its own frame / utterance strides (pBLSTM.downsample's view of an
+        # an input may come with its own strides (pBLSTM.downsample's view of an
         # odd-length layer output: rows of 2F floats, utterances T * F apart): the kernels take strides, no copy
-        strided = (batch_first and x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1 and
+        strided = (x.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1 and
                    x.stride(1) % 4 == 0 and x.stride(0) % 4 == 0 and x.stride(1) >= x.shape[2] and
                    x.stride(0) >= x.shape[1] * x.stride(1) and x.data_ptr() % 16 == 0)
         if not strided:
@@ -298,7 +298,7 @@ class _BiLSTM(torch.autograd.Function):
             ys_s, ys_n = 2 * H, S * 2 * H
         else:
             S, N = x.shape[0], x.shape[1]
-            xs_s, xs_n = N * I, I
+            xs_s, xs_n = x.stride(0), x.stride(1)
             y = torch.empty(S, N, 2 * H, device=x.device, dtype=torch.float32)
             ys_s, ys_n = N * 2 * H, 2 * H
         gates = torch.empty(2, S * N, 4 * H, device=x.device, dtype=torch.float32)
