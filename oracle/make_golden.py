@@ -460,6 +460,11 @@ def main(only=None):
             weights_seed=24, keep='acts')
     capture(asr_mod, 'full_b4', full, [64, 56, 48, 40], [10, 7, 5, 3], 1.0, 6,
             weights_seed=11, keep='compact')
+    # edges of the batch shape at the yaml's layer sizes: ONE utterance (every kernel's column count is 1; blstm_4 recurs over
+    # a "sequence" of one step), and utterances so short that the encoder leaves one frame (8 frames -> T' = 1: attention
+    # over a single frame) beside one of 17 (T' = 2), the longest of odd length at every layer (17 -> 8, 9 -> 4 ...)
+    capture(asr_mod, 'edge_b1', full, [123], [7], 1.0, 8, weights_seed=13, keep='compact')
+    capture(asr_mod, 'edge_short', full, [17, 9, 8], [3, 2, 2], 1.0, 9, weights_seed=14, keep='compact')
     lens16 = sorted(np.random.default_rng(9).integers(200, 401, size=16).tolist(),
                     reverse=True)
     lens16[0] = 400
