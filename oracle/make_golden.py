@@ -465,6 +465,10 @@ def main(only=None):
     # over a single frame) beside one of 17 (T' = 2), the longest of odd length at every layer (17 -> 8, 9 -> 4 ...)
     capture(asr_mod, 'edge_b1', full, [123], [7], 1.0, 8, weights_seed=13, keep='compact')
     capture(asr_mod, 'edge_short', full, [17, 9, 8], [3, 2, 2], 1.0, 9, weights_seed=14, keep='compact')
+    # more utterances than the 32 a persistent launch takes as one column chunk / the persistent decode loop takes at all
+    lens40 = sorted(np.random.default_rng(15).integers(24, 97, size=40).tolist(), reverse=True)
+    capture(asr_mod, 'full_b40', full, lens40, np.random.default_rng(16).integers(2, 12, size=40).tolist(), 1.0, 10,
+            weights_seed=15, keep='compact')
     lens16 = sorted(np.random.default_rng(9).integers(200, 401, size=16).tolist(),
                     reverse=True)
     lens16[0] = 400

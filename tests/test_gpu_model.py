@@ -55,7 +55,7 @@ def forward(fx, model):
 
 
 @pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'small_greedy',
-                                  'full_b4', 'edge_b1', 'edge_short', 'full_b16_t400'] + BENCH_SHAPES + LONG_SHAPES)
+                                  'full_b4', 'edge_b1', 'edge_short', 'full_b40', 'full_b16_t400'] + BENCH_SHAPES + LONG_SHAPES)
 def test_forward_matches_reference(golden, name):
     fx = golden(name)
     model = build(fx)
@@ -119,7 +119,7 @@ def test_bf16_operand_variant_stays_within_the_stated_loss_tolerance(golden, nam
         assert abs(calc_acc(logits[:, :ans_len], label) - float(fx['acc'])) < 1e-3
 
 
-@pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'full_b4', 'edge_b1', 'edge_short',
+@pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_padded', 'full_b4', 'edge_b1', 'edge_short', 'full_b40',
                                   'full_b16_t400'] + BENCH_SHAPES + LONG_SHAPES)
 def test_backward_and_solver_step_match_reference(golden, name):
     from ss_asr_amd.optim import FlatParameters, FusedAdadelta

@@ -290,7 +290,7 @@ def test_postprocess_metrics():
     assert calc_err(logits, label, Mapper()) == pytest.approx((1.0 + 0.0) / 2)
 
 
-@pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_greedy', 'full_b4', 'edge_b1', 'edge_short', 'full_b16_t400'])
+@pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'small_greedy', 'full_b4', 'edge_b1', 'edge_short', 'full_b40', 'full_b16_t400'])
 def test_calc_acc_equals_the_reference_value_on_reference_logits(golden, name):
     """`acc` in the fixtures is the REFERENCE's own calc_acc (src/postprocess.py:7-29, imported through
     oracle/ref_harness.py) on its own logits; the product's metric on those logits must give that number."""

@@ -10,7 +10,7 @@ import las_oracle as lo
 from conftest import fixture_att, fixture_xy
 
 CASES = ['small_tf1', 'small_odd', 'small_padded', 'small_greedy', 'small_sampled',
-         'full_b4', 'edge_b1', 'edge_short', 'bench_b32_t800', 'bench_b32_median', 'long_b32_t3000']
+         'full_b4', 'edge_b1', 'edge_short', 'full_b40', 'bench_b32_t800', 'bench_b32_median', 'long_b32_t3000']
 
 
 def build(fx):
@@ -50,7 +50,7 @@ def test_forward_matches_reference(golden, name):
     assert abs(float(loss) - float(fx['loss'])) < 1e-5
 
 
-@pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'full_b4', 'edge_b1', 'edge_short'])
+@pytest.mark.parametrize('name', ['small_tf1', 'small_odd', 'full_b4', 'edge_b1', 'edge_short', 'full_b40'])
 def test_backward_and_step_match_reference(golden, name):
     fx = golden(name)
     model = build(fx)
