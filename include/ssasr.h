@@ -57,7 +57,7 @@ int ssasr_abi_version(void);
  * ROUNDED to bf16, one MFMA per block instead of six, fp32 accumulation, tile kernels only; tensors stay fp32, the
  * recurrences, the decode loop, the loss and the optimizer are untouched).  It is the bf16-storage variant of
  * BASELINE.json configs[1], not the reference's fp32 arithmetic (/root/reference/src/trainer.py:46-53 has no
- * autocast): 1.06-1.08 x the step rate, |d loss| < 4e-5 over 60 steps (bench.py "bf16_variant"). */
+ * autocast): 1.08-1.09 x the step rate, |d loss| < 4e-5 over 60 steps (bench.py "bf16_variant"). */
 int ssasr_set_option(const char* name, int value);
 int ssasr_get_option(const char* name, int* value);
 

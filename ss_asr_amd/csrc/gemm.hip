@@ -1495,6 +1495,7 @@ int launch_wide(const GemmDesc& gin, bool vecA, bool vecB, hipStream_t st, bool 
 
 size_t ssasr_gemm_min_lds_bytes() {
   // 64 x 64 tiles: the split-bf16 kernel's dynamic image of both operands, or the fp32 kernel's two static stages
+  if (ssasr_options().gemm_x6 && ssasr_options().gemm_bf16) return XGeom<64, 1>::BYTES + XGeom<64, 1>::BYTES;
   if (ssasr_options().gemm_x6) return XGeom<64>::BYTES + XGeom<64>::BYTES;
   return sizeof(float) * 2 * (TileGeom<64, false>::FLOATS + TileGeom<64, false>::FLOATS);
 }
