@@ -325,7 +325,9 @@ def recurrence_roofline(device, S=400, N=32, H=256, reps=5):
                     shape=dict(M=S * N, N=4 * H, K=I, batch=2),
                     note='fp32 product = a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 on bf16 pieces; DESIGN.md 4.1.  The bf16 pipe '
                          'sustains ~1.25-1.3 PFLOP/s on random data at the clock the chip holds under this load (MI355X_MICROARCH.md, '
-                         'DVFS): executed_bf16.frac is against the 2.5 PFLOP/s specification'))
+                         'DVFS): executed_bf16.frac is against the 2.5 PFLOP/s specification.  profiles/r05_power.txt: this kernel back '
+                         'to back holds the socket at 1,395-1,398 W of its 1,400 W cap and the shader clock at 1,780 of 2,400 MHz -- '
+                         'a constant of that profile, not a measurement of this run'))
     return out
 
 
